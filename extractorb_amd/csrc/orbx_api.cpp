@@ -1,0 +1,592 @@
+// orbx_api.cpp — the C ABI of liborbx.so (include/orbx.h): handle, device arenas, launch sequence.
+//
+// This is the product path.  It has no CPU fallback: without a HIP device orbx_create fails with
+// ORBX_ERR_NO_DEVICE, and nothing here includes, links or calls anything under oracle/.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+#include "orbx_geometry.hpp"
+
+namespace orbx {
+// launch wrappers, defined in orbx_kernels.hip
+void launchLevel0(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, uint8_t*, int);
+void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX*, const ResizeX*, uint8_t*, int);
+void launchBlur(hipStream_t, const BlurTile*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
+void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, uint2*, unsigned*,
+                int, int, int);
+size_t octreeLdsBytes(int M, int P);
+void launchOctree(hipStream_t, const LevelGeom*, int, const uint2*, const unsigned*, unsigned short*, uint2*, int, int*,
+                  int*, const int*, int, int, int);
+void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
+                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
+hipError_t uploadUmax(const int* umax16);
+void launchUnpackCandidates(hipStream_t, const uint2*, int, Keypoint*);
+}  // namespace orbx
+
+using namespace orbx;
+
+static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
+
+namespace {
+enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL };
+const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_level0", "k_resize", "k_blur", "k_fast",
+                                            "k_octree", "k_describe", "memset+copies", "batch_total"};
+thread_local std::string g_createError;
+
+struct EventPair { hipEvent_t a, b; int slot; };
+}  // namespace
+
+struct orbx_handle {
+    int device = 0;
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
+    float scaleFactor = 0;
+    int maxW = 0, maxH = 0, maxB = 0;
+    ScaleTables tabs;
+    FrameGeom geom;        // geometry of the image size of the last call
+    FrameGeom maxGeom;     // geometry of max_width x max_height (sizes the arenas)
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::string err;
+
+    // arenas (sized once)
+    size_t pyrBytes = 0, blurBytes = 0, candEntries = 0, selEntries = 0, cellCap = 0, rxCap = 0, tileCap = 0;
+    uint8_t *d_input = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
+    uint2* d_cand = nullptr;
+    unsigned short* d_nodeOf = nullptr;
+    unsigned* d_candCount = nullptr;
+    uint2* d_sel = nullptr;
+    int *d_levelCount = nullptr, *d_levelLap = nullptr, *d_lap = nullptr;
+    LevelGeom* d_lv = nullptr;
+    CellDesc* d_cells = nullptr;
+    ResizeX *d_rx = nullptr, *d_ry = nullptr;
+    BlurTile* d_tiles = nullptr;
+    int nTiles = 0;
+    size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
+    int octM = 0, octP = 0;
+    // outputs of the host path
+    int outCap = 0;
+    Keypoint *d_outK = nullptr, *d_outLevelK = nullptr;
+    uint8_t* d_outD = nullptr;
+    int *d_nOut = nullptr, *d_monoOut = nullptr, *d_outLevelCounts = nullptr;
+    // pinned staging
+    int* h_lap = nullptr;
+    std::vector<int> lapCached;
+    Keypoint *h_outK = nullptr, *h_outLevelK = nullptr;
+    uint8_t* h_outD = nullptr;
+    int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
+    int lastB = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    double profMs[ORBX_NUM_KERNELS] = {};
+    long profN[ORBX_NUM_KERNELS] = {};
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                                 \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                \
+            return ORBX_ERR_HIP;                                                                         \
+        }                                                                                                \
+    } while (0)
+
+int fail(orbx_handle* h, int code, const std::string& msg) {
+    h->err = msg;
+    return code;
+}
+
+int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+void freeAll(orbx_handle* h) {
+    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_cand, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_tiles, h->d_outK,
+                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+// Uploads the tables of h->geom (already laid out) and checks they fit the arenas.
+int installGeometry(orbx_handle* h, int rows, int cols) {
+    FrameGeom g;
+    std::string why = makeFrameGeom(h->tabs, rows, cols, g);
+    if (!why.empty()) return fail(h, why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED, why);
+    layoutArenas(g, h->maxB);
+    const LevelGeom& last = g.lv[g.nlevels - 1];
+    if ((size_t)(last.pyrOff + last.pyrFrameBytes * h->maxB) > h->pyrBytes ||
+        (size_t)(last.blurOff + last.blurFrameBytes * h->maxB) > h->blurBytes ||
+        (size_t)(last.candOff + (long long)last.candCap * h->maxB) > h->candEntries ||
+        (size_t)g.selPerFrame * h->maxB > h->selEntries || g.cells.size() > h->cellCap || g.maxNodes > h->octM)
+        return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "image geometry does not fit the arenas sized at orbx_create");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // tables may still be in use by queued work
+    HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
+    size_t xo = 0, yo = 0;
+    for (int l = 1; l < g.nlevels; l++) {
+        h->rxOff[l] = xo; h->ryOff[l] = yo;
+        if (xo + g.rx[l].size() > h->rxCap || yo + g.ry[l].size() > h->rxCap)
+            return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "resize tables do not fit");
+        HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
+        xo += g.rx[l].size(); yo += g.ry[l].size();
+    }
+    std::vector<BlurTile> tiles;
+    for (int l = 0; l < g.nlevels; l++)
+        for (int ty = 0; ty < (g.lv[l].h + 31) / 32; ty++)
+            for (int tx = 0; tx < (g.lv[l].w + 63) / 64; tx++) tiles.push_back(BlurTile{(short)l, (short)tx, (short)ty, 0});
+    if (tiles.size() > h->tileCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur tile table does not fit");
+    HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurTile) * tiles.size(), hipMemcpyHostToDevice));
+    h->nTiles = (int)tiles.size();
+    h->geom = g;
+    return ORBX_OK;
+}
+
+struct Prof {
+    orbx_handle* h; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Prof(orbx_handle* h_, int s) : h(h_), slot(s) {
+        if (h->profiling) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    ~Prof() {
+        if (h->profiling) {
+            (void)hipEventRecord(b, h->stream);
+            h->pending.push_back(EventPair{a, b, slot});
+        }
+    }
+};
+
+int checkFrameArgs(orbx_handle* h, int n_frames, int rows, int cols) {
+    if (n_frames < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "n_frames < 1");
+    if (n_frames > h->maxB) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "n_frames exceeds max_batch");
+    if (cols > h->maxW || rows > h->maxH) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "image exceeds max_width/max_height");
+    return ORBX_OK;
+}
+
+// The launch sequence of one batch.  Everything is enqueued on h->stream; nothing synchronises.
+int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int cols, long long stride,
+                 long long frameStride, const int* lap, Keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_nOut,
+                 int* d_monoOut, Keypoint* d_levelK, int* d_levelCounts) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (rows != h->geom.rows || cols != h->geom.cols) {
+        int rc = installGeometry(h, rows, cols);
+        if (rc != ORBX_OK) return rc;
+    }
+    const FrameGeom& g = h->geom;
+    hipStream_t st = h->stream;
+    Prof total(h, S_TOTAL);
+    // lapping areas: upload only when they change (they are per-camera constants in the reference)
+    {
+        std::vector<int> want(2 * B);
+        for (int f = 0; f < B; f++) {
+            want[2 * f] = lap ? lap[2 * f] : 0;
+            want[2 * f + 1] = lap ? lap[2 * f + 1] : 1000;   // Frame.cc:307 passes {0,1000}
+        }
+        bool same = h->lapCached.size() >= want.size();
+        for (size_t i = 0; same && i < want.size(); i++) same = h->lapCached[i] == want[i];
+        if (!same) {
+            HIP_TRY(h, hipStreamSynchronize(st));   // previous async copy out of h_lap is done
+            std::memcpy(h->h_lap, want.data(), want.size() * sizeof(int));
+            HIP_TRY(h, hipMemcpyAsync(h->d_lap, h->h_lap, want.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            h->lapCached = want;
+        }
+    }
+    {
+        Prof p(h, S_MISC);
+        HIP_TRY(h, hipMemsetAsync(h->d_candCount, 0, sizeof(unsigned) * B * g.nlevels, st));
+    }
+    { Prof p(h, S_LEVEL0); launchLevel0(st, d_imgs, stride, frameStride, g.lv[0], h->d_pyr, B); }
+    for (int l = 1; l < g.nlevels; l++) {
+        Prof p(h, S_RESIZE);
+        launchResize(st, g.lv[l - 1], g.lv[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l], h->d_pyr, B);
+    }
+    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nTiles, h->d_lv, h->d_pyr, h->d_blur, B); }
+    {
+        Prof p(h, S_FAST);
+        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_cand,
+                   h->d_candCount, g.maxRoiW, g.maxRoiH, B);
+    }
+    {
+        Prof p(h, S_OCTREE);
+        launchOctree(st, h->d_lv, g.nlevels, h->d_cand, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
+                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, B);
+    }
+    {
+        Prof p(h, S_DESCRIBE);
+        launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
+                       h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, B);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->lastB = B;
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbx_abi_version(void) { return ORBX_ABI_VERSION; }
+
+const char* orbx_last_error(const orbx_handle* h) { return h ? h->err.c_str() : g_createError.c_str(); }
+
+int orbx_compute_tables(int nfeatures, float scale_factor, int nlevels, float* sf, float* isf, float* s2, float* is2,
+                        int* quota, int* umax16) {
+    if (nlevels < 1 || nlevels > kMaxLevels || nfeatures < 1 || !(scale_factor > 1.0f)) return ORBX_ERR_BAD_ARGUMENT;
+    ScaleTables t = makeScaleTables(nfeatures, scale_factor, nlevels);
+    for (int i = 0; i < nlevels; i++) {
+        if (sf) sf[i] = t.scale[i];
+        if (isf) isf[i] = t.invScale[i];
+        if (s2) s2[i] = t.sigma2[i];
+        if (is2) is2[i] = t.invSigma2[i];
+        if (quota) quota[i] = t.quota[i];
+    }
+    if (umax16) for (int i = 0; i < 16; i++) umax16[i] = t.umax[i];
+    return ORBX_OK;
+}
+
+int orbx_compute_level_sizes(float scale_factor, int nlevels, int rows, int cols, int* widths, int* heights) {
+    if (nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f)) return ORBX_ERR_BAD_ARGUMENT;
+    ScaleTables t = makeScaleTables(1000, scale_factor, nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        widths[l] = roundHalfEven((float)cols * t.invScale[l]);
+        heights[l] = roundHalfEven((float)rows * t.invScale[l]);
+    }
+    return ORBX_OK;
+}
+
+int orbx_compute_cell_grid(float scale_factor, int nlevels, int rows, int cols, int level, int* n_cols, int* n_rows,
+                           int* w_cell, int* h_cell, int* n_cells, int* n_ini, int* cand_cap) {
+    if (nlevels < 1 || nlevels > kMaxLevels || level < 0 || level >= nlevels || !(scale_factor > 1.0f))
+        return ORBX_ERR_BAD_ARGUMENT;
+    ScaleTables t = makeScaleTables(1000, scale_factor, nlevels);
+    FrameGeom g;
+    std::string why = makeFrameGeom(t, rows, cols, g);
+    if (!why.empty()) return why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED;
+    const LevelGeom& L = g.lv[level];
+    if (n_cols) *n_cols = L.nCols;
+    if (n_rows) *n_rows = L.nRows;
+    if (w_cell) *w_cell = L.wCell;
+    if (h_cell) *h_cell = L.hCell;
+    if (n_cells) *n_cells = L.cellCount;
+    if (n_ini) *n_ini = L.nIni;
+    if (cand_cap) *cand_cap = L.candCap;
+    return ORBX_OK;
+}
+
+int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                int max_width, int max_height, int max_batch, int device) {
+    if (!out) return ORBX_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th < 1 || min_th < 1 ||
+        ini_th > 254 || min_th > 254 || max_width < 1 || max_height < 1 || max_batch < 1) {
+        g_createError = "orbx_create: bad argument (need nfeatures>=1, 1<=nlevels<=16, scale>1, 1<=thresholds<=254)";
+        return ORBX_ERR_BAD_ARGUMENT;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        g_createError = "orbx_create: no HIP device (this library has no CPU path)";
+        return ORBX_ERR_NO_DEVICE;
+    }
+    orbx_handle* h = new orbx_handle();
+    auto bail = [&](int code) {
+        g_createError = h->err;
+        freeAll(h);
+        delete h;
+        return code;
+    };
+#define CREATE_TRY(expr)                                                                 \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            h->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return bail(ORBX_ERR_HIP);                                                   \
+        }                                                                                \
+    } while (0)
+    if (device < 0) CREATE_TRY(hipGetDevice(&device));
+    if (device >= ndev) { h->err = "orbx_create: device index out of range"; return bail(ORBX_ERR_BAD_ARGUMENT); }
+    h->device = device;
+    CREATE_TRY(hipSetDevice(device));
+    h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->scaleFactor = scale_factor;
+    h->maxW = max_width; h->maxH = max_height; h->maxB = max_batch;
+    h->tabs = makeScaleTables(nfeatures, scale_factor, nlevels);
+    std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom);
+    if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
+    layoutArenas(h->maxGeom, max_batch);
+    const FrameGeom& mg = h->maxGeom;
+    // a smaller image can need slightly more of a rounded quantity (cell grid, strides): 12.5 % + slack head-room
+    auto roomy = [](size_t v) { return v + v / 8 + 4096; };
+    h->pyrBytes = roomy((size_t)mg.pyrBytesPerFrame * max_batch);
+    h->blurBytes = roomy((size_t)mg.blurBytesPerFrame * max_batch);
+    h->candEntries = roomy((size_t)mg.candPerFrame * max_batch);
+    h->selEntries = (size_t)(mg.selPerFrame + 8 * nlevels) * max_batch;
+    h->cellCap = roomy(mg.cells.size());
+    h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
+    h->tileCap = roomy((size_t)((max_width + 63) / 64 + 1) * ((max_height + 31) / 32 + 1) * nlevels);
+    // quad-tree LDS: M nodes (multiple of 8), P = next power of two for the bitonic sort
+    int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
+    M = (M + 7) / 8 * 8;
+    h->octM = M; h->octP = nextPow2(M);
+    if (octreeLdsBytes(h->octM, h->octP) > 150 * 1024) {
+        h->err = "orbx_create: per-level feature quota too large for the LDS-resident quad-tree (nfeatures <= ~9000)";
+        return bail(ORBX_ERR_UNSUPPORTED);
+    }
+    h->outCap = mg.selPerFrame + 8 * nlevels;
+
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->ownStream = true;
+    CREATE_TRY(hipMalloc(&h->d_input, (size_t)max_width * max_height * max_batch));
+    CREATE_TRY(hipMalloc(&h->d_pyr, h->pyrBytes));
+    CREATE_TRY(hipMalloc(&h->d_blur, h->blurBytes));
+    CREATE_TRY(hipMalloc(&h->d_cand, h->candEntries * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(&h->d_nodeOf, h->candEntries * sizeof(unsigned short)));
+    CREATE_TRY(hipMalloc(&h->d_candCount, sizeof(unsigned) * max_batch * nlevels));
+    CREATE_TRY(hipMalloc(&h->d_sel, h->selEntries * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(&h->d_levelCount, sizeof(int) * max_batch * nlevels));
+    CREATE_TRY(hipMalloc(&h->d_levelLap, sizeof(int) * max_batch * nlevels));
+    CREATE_TRY(hipMalloc(&h->d_lap, sizeof(int) * 2 * max_batch));
+    CREATE_TRY(hipMalloc(&h->d_lv, sizeof(LevelGeom) * kMaxLevels));
+    CREATE_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * h->cellCap));
+    CREATE_TRY(hipMalloc(&h->d_rx, sizeof(ResizeX) * h->rxCap));
+    CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
+    CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurTile) * h->tileCap));
+    const size_t oc = (size_t)h->outCap * max_batch;
+    CREATE_TRY(hipMalloc(&h->d_outK, oc * sizeof(Keypoint)));
+    CREATE_TRY(hipMalloc(&h->d_outLevelK, oc * sizeof(Keypoint)));
+    CREATE_TRY(hipMalloc(&h->d_outD, oc * 32));
+    CREATE_TRY(hipMalloc(&h->d_nOut, sizeof(int) * max_batch));
+    CREATE_TRY(hipMalloc(&h->d_monoOut, sizeof(int) * max_batch));
+    CREATE_TRY(hipMalloc(&h->d_outLevelCounts, sizeof(int) * max_batch * nlevels));
+    CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
+    CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
+    CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
+    CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));
+    CREATE_TRY(hipHostMalloc(&h->h_nOut, sizeof(int) * max_batch));
+    CREATE_TRY(hipHostMalloc(&h->h_monoOut, sizeof(int) * max_batch));
+    CREATE_TRY(hipHostMalloc(&h->h_outLevelCounts, sizeof(int) * max_batch * nlevels));
+    // the border of the pyramid arena is only ever written by the kernels, but the padding bytes between
+    // rows are never written: clear once so introspection copies are deterministic
+    CREATE_TRY(hipMemset(h->d_pyr, 0, h->pyrBytes));
+    CREATE_TRY(hipMemset(h->d_blur, 0, h->blurBytes));
+    CREATE_TRY(uploadUmax(h->tabs.umax));
+#undef CREATE_TRY
+    h->geom = FrameGeom();   // installed on first use
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    freeAll(h);
+    delete h;
+}
+
+int orbx_get_levels(const orbx_handle* h) { return h ? h->nlevels : 0; }
+float orbx_get_scale_factor(const orbx_handle* h) { return h ? h->scaleFactor : 0.f; }
+int orbx_get_tables(const orbx_handle* h, float* sf, float* isf, float* s2, float* is2, int* quota, int* umax16) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    return orbx_compute_tables(h->nfeatures, h->scaleFactor, h->nlevels, sf, isf, s2, is2, quota, umax16);
+}
+int orbx_max_keypoints(const orbx_handle* h) { return h ? h->outCap : 0; }
+
+int orbx_set_stream(orbx_handle* h, void* hip_stream) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->ownStream && h->stream) { (void)hipStreamDestroy(h->stream); h->ownStream = false; }
+    h->stream = (hipStream_t)hip_stream;
+    return ORBX_OK;
+}
+void* orbx_get_stream(const orbx_handle* h) { return h ? (void*)h->stream : nullptr; }
+int orbx_synchronize(orbx_handle* h) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_handle* h, int n_frames, const uint8_t* d_imgs, int rows, int cols,
+                              ptrdiff_t stride, ptrdiff_t frame_stride, const int* lap, orbx_keypoint* d_kps,
+                              uint8_t* d_desc, int capacity, int* d_n_out, int* d_mono_out, orbx_keypoint* d_level_kps,
+                              int* d_level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_imgs || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
+    if (!d_kps || !d_desc || !d_n_out || !d_mono_out || capacity < 1 || stride < cols)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer, capacity < 1 or stride < cols");
+    int rc = checkFrameArgs(h, n_frames, rows, cols);
+    if (rc != ORBX_OK) return rc;
+    return enqueueBatch(h, n_frames, d_imgs, rows, cols, (long long)stride, (long long)frame_stride, lap,
+                        (Keypoint*)d_kps, d_desc, capacity, d_n_out, d_mono_out, (Keypoint*)d_level_kps, d_level_counts);
+}
+
+int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
+                       ptrdiff_t frame_stride, const int* lap, orbx_keypoint* kps, uint8_t* desc, int capacity,
+                       int* n_out, int* mono_out, orbx_keypoint* level_kps, int* level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!imgs || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
+    if (!kps || !desc || !n_out || !mono_out || capacity < 1 || stride < cols)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer, capacity < 1 or stride < cols");
+    int rc = checkFrameArgs(h, n_frames, rows, cols);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int B = n_frames;
+    // H2D into a tight cols x rows x B slab
+    if (stride == cols && frame_stride == (ptrdiff_t)rows * cols) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_input, imgs, (size_t)rows * cols * B, hipMemcpyHostToDevice, st));
+    } else {
+        for (int f = 0; f < B; f++)
+            HIP_TRY(h, hipMemcpy2DAsync(h->d_input + (size_t)f * rows * cols, cols, imgs + f * frame_stride, stride, cols,
+                                        rows, hipMemcpyHostToDevice, st));
+    }
+    const int cap = h->outCap;
+    rc = enqueueBatch(h, B, h->d_input, rows, cols, cols, (long long)rows * cols, lap, h->d_outK, h->d_outD, cap,
+                      h->d_nOut, h->d_monoOut, h->d_outLevelK, h->d_outLevelCounts);
+    if (rc != ORBX_OK) return rc;
+    const size_t oc = (size_t)cap * B;
+    HIP_TRY(h, hipMemcpyAsync(h->h_nOut, h->d_nOut, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_monoOut, h->d_monoOut, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_outK, h->d_outK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->h_outD, h->d_outD, oc * 32, hipMemcpyDeviceToHost, st));
+    if (level_kps) HIP_TRY(h, hipMemcpyAsync(h->h_outLevelK, h->d_outLevelK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
+    if (level_counts)
+        HIP_TRY(h, hipMemcpyAsync(h->h_outLevelCounts, h->d_outLevelCounts, sizeof(int) * B * h->nlevels, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    int status = ORBX_OK;
+    for (int f = 0; f < B; f++) {
+        const int n = h->h_nOut[f];
+        n_out[f] = n;
+        mono_out[f] = h->h_monoOut[f];
+        if (n > capacity || n > cap) {
+            status = fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the caller's capacity");
+            continue;
+        }
+        std::memcpy(kps + (size_t)f * capacity, h->h_outK + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
+        std::memcpy(desc + (size_t)f * capacity * 32, h->h_outD + (size_t)f * cap * 32, (size_t)n * 32);
+        if (level_kps) std::memcpy(level_kps + (size_t)f * capacity, h->h_outLevelK + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
+        if (level_counts) std::memcpy(level_counts + (size_t)f * h->nlevels, h->h_outLevelCounts + (size_t)f * h->nlevels, sizeof(int) * h->nlevels);
+    }
+    return status;
+}
+
+int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out, orbx_keypoint* level_kps,
+                 int* level_counts) {
+    const int lap[2] = {lap0, lap1};
+    return orbx_extract_batch(h, 1, img, rows, cols, stride, (ptrdiff_t)rows * stride, lap, kps, desc, capacity, n_out,
+                              mono_out, level_kps, level_counts);
+}
+
+int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride, int* width,
+                   int* height) {
+    if (!h || !dst) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_get_level: no such frame/level in the last batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const LevelGeom& L = h->geom.lv[level];
+    const int w = bordered ? L.w + 2 * kEdge : L.w, hh = bordered ? L.h + 2 * kEdge : L.h;
+    if (dst_stride < w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_get_level: dst_stride too small");
+    const uint8_t* src = h->d_pyr + L.pyrOff + (long long)frame * L.pyrFrameBytes +
+                         (bordered ? (kPadL - kEdge) : ((long long)kEdge * L.pyrStride + kPadL));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(dst, dst_stride, src, L.pyrStride, w, hh, hipMemcpyDeviceToHost));
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    return ORBX_OK;
+}
+
+int orbx_debug_num_candidates(orbx_handle* h, int frame, int level, int* n) {
+    if (!h || !n) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "no such frame/level in the last batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned v = 0;
+    HIP_TRY(h, hipMemcpy(&v, h->d_candCount + frame * h->nlevels + level, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *n = (int)v;
+    return ORBX_OK;
+}
+
+int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoint* out, int capacity) {
+    int n = 0;
+    int rc = orbx_debug_num_candidates(h, frame, level, &n);
+    if (rc != ORBX_OK) return rc;
+    const LevelGeom& L = h->geom.lv[level];
+    if (n > L.candCap) return fail(h, ORBX_ERR_CAPACITY, "candidate arena overflow (internal bound violated)");
+    if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity too small");
+    if (n == 0) return ORBX_OK;
+    Keypoint* tmp = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, sizeof(Keypoint) * n));
+    launchUnpackCandidates(h->stream, h->d_cand + L.candOff + (long long)frame * L.candCap, n, tmp);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, sizeof(Keypoint) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    HIP_TRY(h, e);
+    return ORBX_OK;
+}
+
+int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride) {
+    if (!h || !dst) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "no such frame/level in the last batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const LevelGeom& L = h->geom.lv[level];
+    if (dst_stride < L.w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "dst_stride too small");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
+                           L.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_profile_enable(orbx_handle* h, int enable) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    h->profiling = enable != 0;
+    return ORBX_OK;
+}
+int orbx_profile_reset(orbx_handle* h) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    h->pending.clear();
+    for (int i = 0; i < ORBX_NUM_KERNELS; i++) { h->profMs[i] = 0; h->profN[i] = 0; }
+    return ORBX_OK;
+}
+int orbx_profile_read(orbx_handle* h, double* total_ms, long* launches) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (auto& ev : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { h->profMs[ev.slot] += ms; h->profN[ev.slot]++; }
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    h->pending.clear();
+    for (int i = 0; i < ORBX_NUM_KERNELS; i++) {
+        if (total_ms) total_ms[i] = h->profMs[i];
+        if (launches) launches[i] = h->profN[i];
+    }
+    return ORBX_OK;
+}
+const char* orbx_profile_kernel_name(int slot) { return slot >= 0 && slot < ORBX_NUM_KERNELS ? kSlotNames[slot] : ""; }
+
+long orbx_algorithmic_bytes(const orbx_handle* h, int rows, int cols, int n_out) {
+    if (!h) return 0;
+    FrameGeom g;
+    if (!makeFrameGeom(h->tabs, rows, cols, g).empty()) return 0;
+    return (long)rows * cols + 2 * (long)g.sumPixels + 60L * n_out;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// orbx_device.hpp — plain-old-data shared by the host geometry code and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace orbx {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD, ORBextractor.cc:72
+constexpr int kPadL = 32;        // bytes in front of each interior row in HBM (>= kEdge, keeps rows 32-B aligned)
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, ORBextractor.cc:71
+constexpr int kPatch = 31;       // PATCH_SIZE, ORBextractor.cc:70
+constexpr int kMaxLevels = 16;
+constexpr int kCellW = 30;       // W, ORBextractor.cc:777
+constexpr int kMinBorder = kEdge - 3;   // minBorderX/Y, ORBextractor.cc:781-782
+
+
+struct Keypoint {             // == orbx_keypoint == cv::KeyPoint (28 bytes)
+    float x, y, size, angle, response;
+    int octave, class_id;
+};
+static_assert(sizeof(Keypoint) == 28, "cv::KeyPoint layout");
+
+struct BlurTile { short level, tx, ty, pad; };   // one 64x32 output tile of the blur kernel
+
+// ---- per-level geometry, shared verbatim with the device (plain ints/floats) -------------------
+struct LevelGeom {
+    int w, h;                 // level image size
+    int pyrStride;            // bytes per row of the bordered level buffer (multiple of 64)
+    int pyrRows;              // h + 2*kEdge
+    long long pyrOff;         // byte offset of frame 0's bordered buffer inside the pyramid arena
+    long long pyrFrameBytes;  // bytes per frame at this level (level-major arena: all frames of a level are adjacent)
+    int blurStride;           // bytes per row of the blurred level (multiple of 64)
+    long long blurOff, blurFrameBytes;
+    int nCols, nRows, wCell, hCell;   // FAST cell grid (ORBextractor.cc:789-795)
+    int rectW, rectH;         // maxBorder - minBorder (ORBextractor.cc:783-790)
+    int quota;                // mnFeaturesPerLevel[level]
+    int nIni;                 // quad-tree roots (ORBextractor.cc:548)
+    float hX;                 // root width (ORBextractor.cc:550)
+    int candCap;              // exact upper bound of FAST candidates of one frame at this level
+    long long candOff;        // entry offset of frame 0 in the candidate arena (level-major)
+    int selCap;               // upper bound of keypoints kept at this level
+    int selOff;               // entry offset of this level inside one frame's selection slab
+    float scale;              // mvScaleFactor[level]
+    int patchSize;            // keypoint size written to the output
+    int cellFirst, cellCount; // this level's cells inside the per-frame cell table
+};
+
+struct CellDesc {             // one FAST cell == one cv::FAST call of the reference (ORBextractor.cc:818-819)
+    short level;
+    short roiW, roiH;         // maxX-iniX, maxY-iniY
+    short x0, y0;             // iniX, iniY in level pixel coordinates
+    short shiftX, shiftY;     // j*wCell, i*hCell (ORBextractor.cc:857-858)
+    short pad;
+    int cellId;               // i*nCols + j: raster rank of the cell inside its level
+};
+static_assert(sizeof(CellDesc) == 20, "CellDesc layout");
+
+struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
+
+
+}  // namespace orbx

@@ -1,0 +1,206 @@
+// orbx_geometry.hpp — host-side geometry and tables of the ORB extractor (pure C++, no HIP).
+//
+// Everything here is computed once per (handle, image size) on the host with the reference's own
+// float/double sequence, so the device kernels only see integers and pre-rounded floats:
+//   * scale tables / per-level quotas / umax      reference ORBextractor.cc:419-474
+//   * pyramid level sizes                         reference ORBextractor.cc:1171
+//   * bilinear resize coefficient tables          cv::resize INTER_LINEAR 8u
+//   * FAST cell grid per level                    reference ORBextractor.cc:781-814
+//   * quad-tree roots per level                   reference ORBextractor.cc:548-568
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "orbx_device.hpp"
+
+namespace orbx {
+
+inline int roundHalfEven(float v) { return (int)std::lrintf(v); }   // cvRound(float)
+inline int roundHalfEven(double v) { return (int)std::lrint(v); }   // cvRound(double)
+inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- tables of the constructor ---------------------------------------------------------------
+struct ScaleTables {
+    int nlevels = 0;
+    float scale[kMaxLevels] = {}, invScale[kMaxLevels] = {}, sigma2[kMaxLevels] = {}, invSigma2[kMaxLevels] = {};
+    int quota[kMaxLevels] = {};   // mnFeaturesPerLevel
+    int patchSize[kMaxLevels] = {};   // (int)(PATCH_SIZE * scale[level]), ORBextractor.cc:872
+    int umax[kHalfPatch + 1] = {};
+};
+
+inline ScaleTables makeScaleTables(int nfeatures, float scaleFactorF, int nlevels) {
+    ScaleTables t;
+    t.nlevels = nlevels;
+    const double scaleFactor = scaleFactorF;   // the member is a double holding the float argument (ORBextractor.h:98)
+    t.scale[0] = 1.0f;
+    t.sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        t.scale[i] = (float)(t.scale[i - 1] * scaleFactor);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    for (int i = 0; i < nlevels; i++) {
+        t.invScale[i] = 1.0f / t.scale[i];
+        t.invSigma2[i] = 1.0f / t.sigma2[i];
+        t.patchSize[i] = (int)(kPatch * t.scale[i]);
+    }
+    // geometric split of nfeatures over the levels, remainder to the coarsest (ORBextractor.cc:439-451)
+    const float factor = (float)(1.0f / scaleFactor);
+    float want = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+        t.quota[l] = roundHalfEven(want);
+        sum += t.quota[l];
+        want *= factor;
+    }
+    t.quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    // half-widths of the radius-15 disc rows (ORBextractor.cc:459-474)
+    const float halfDiag = kHalfPatch * std::sqrt(2.f) / 2;
+    const int vmax = (int)std::floor(halfDiag + 1), vmin = (int)std::ceil(halfDiag);
+    const double r2 = (double)kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; v++) t.umax[v] = roundHalfEven(std::sqrt(r2 - (double)v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (t.umax[v0] == t.umax[v0 + 1]) ++v0;
+        t.umax[v] = v0;
+        ++v0;
+    }
+    return t;
+}
+
+inline short satShort(float v) {
+    int i = roundHalfEven(v);
+    return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
+}
+
+// cv::resize(INTER_LINEAR) coefficient set-up for one axis, 8u fixed-point path.
+// zeroAtEdges: the x axis zeroes the fraction in clamped columns, the y axis only clamps the rows.
+inline void resizeAxis(int srcN, int dstN, bool isX, std::vector<ResizeX>& out) {
+    out.resize(dstN);
+    const double scale = 1.0 / ((double)dstN / srcN);
+    for (int d = 0; d < dstN; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        int s0, s1;
+        if (isX) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= srcN - 1) { f = 0; s = srcN - 1; }
+            s0 = s;
+            s1 = s + 1 < srcN ? s + 1 : srcN - 1;   // weight of s1 is 0 whenever it was clamped
+        } else {
+            auto clip = [&](int v) { return v < 0 ? 0 : (v < srcN ? v : srcN - 1); };
+            s0 = clip(s);
+            s1 = clip(s + 1);
+        }
+        out[d] = ResizeX{(short)s0, (short)s1, satShort((1.f - f) * 2048), satShort(f * 2048)};
+    }
+}
+
+struct FrameGeom {
+    int rows = 0, cols = 0, nlevels = 0;
+    LevelGeom lv[kMaxLevels];
+    std::vector<CellDesc> cells;             // all levels, level 0 first, raster order inside a level
+    std::vector<ResizeX> rx[kMaxLevels];     // level l from level l-1 (l >= 1)
+    std::vector<ResizeX> ry[kMaxLevels];
+    long long pyrBytesPerFrame = 0, blurBytesPerFrame = 0;
+    long long candPerFrame = 0;              // sum of candCap
+    int selPerFrame = 0;                     // sum of selCap
+    int maxRoiW = 0, maxRoiH = 0;            // largest FAST ROI over all cells
+    int maxNodes = 0;                        // largest quad-tree node count over all levels
+    long long sumPixels = 0;                 // S of SURVEY.md §8d
+};
+
+// Returns an empty string on success, else the reason the geometry is unsupported.
+inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g) {
+    g = FrameGeom();
+    g.rows = rows; g.cols = cols; g.nlevels = t.nlevels;
+    for (int l = 0; l < t.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.w = roundHalfEven((float)cols * t.invScale[l]);
+        L.h = roundHalfEven((float)rows * t.invScale[l]);
+        const int maxBorderX = L.w - kEdge + 3, maxBorderY = L.h - kEdge + 3;
+        L.rectW = maxBorderX - kMinBorder;
+        L.rectH = maxBorderY - kMinBorder;
+        const float width = (float)L.rectW, height = (float)L.rectH;
+        L.nCols = (int)(width / (float)kCellW);
+        L.nRows = (int)(height / (float)kCellW);
+        if (L.nCols < 1 || L.nRows < 1) return "image too small: a pyramid level is narrower than one 30-px FAST cell";
+        if (L.w + 2 * kEdge > 4096 + 2 * kEdge || L.h > 4096) return "image too large: packed coordinates hold 12 bits";
+        L.wCell = (int)std::ceil(width / L.nCols);
+        L.hCell = (int)std::ceil(height / L.nRows);
+        if (L.wCell > 63 || L.hCell > 63) return "unsupported cell size (> 63 px)";
+        L.pyrStride = roundUp(kPadL + L.w + kEdge, 64);
+        L.pyrRows = L.h + 2 * kEdge;
+        L.blurStride = roundUp(L.w, 64);
+        L.quota = t.quota[l];
+        L.nIni = (int)std::round((float)L.rectW / (float)L.rectH);
+        if (L.nIni < 1) return "unsupported aspect ratio: the reference builds zero quad-tree roots (height > 2*width)";
+        L.hX = (float)L.rectW / (float)L.nIni;
+        L.scale = t.scale[l];
+        L.patchSize = t.patchSize[l];
+        // cells in the reference's loop order; a skipped cell (continue at :802-803, :811-812) is simply absent
+        L.cellFirst = (int)g.cells.size();
+        long long cap = 0;
+        for (int i = 0; i < L.nRows; i++) {
+            const int iniY = kMinBorder + i * L.hCell;
+            int maxY = iniY + L.hCell + 6;
+            if (iniY >= maxBorderY - 3) continue;
+            if (maxY > maxBorderY) maxY = maxBorderY;
+            for (int j = 0; j < L.nCols; j++) {
+                const int iniX = kMinBorder + j * L.wCell;
+                int maxX = iniX + L.wCell + 6;
+                if (iniX >= maxBorderX - 6) continue;
+                if (maxX > maxBorderX) maxX = maxBorderX;
+                CellDesc c;
+                c.level = (short)l;
+                c.roiW = (short)(maxX - iniX);
+                c.roiH = (short)(maxY - iniY);
+                c.x0 = (short)iniX; c.y0 = (short)iniY;
+                c.shiftX = (short)(j * L.wCell); c.shiftY = (short)(i * L.hCell);
+                c.pad = 0;
+                c.cellId = i * L.nCols + j;
+                if (c.roiW < 7 || c.roiH < 7) continue;   // cv::FAST tests nothing on such an ROI
+                g.cells.push_back(c);
+                if (c.roiW > g.maxRoiW) g.maxRoiW = c.roiW;
+                if (c.roiH > g.maxRoiH) g.maxRoiH = c.roiH;
+                // strict 3x3 NMS: no two 8-adjacent survivors inside one cell
+                cap += (long long)((c.roiW - 6 + 1) / 2) * ((c.roiH - 6 + 1) / 2);
+            }
+        }
+        L.cellCount = (int)g.cells.size() - L.cellFirst;
+        L.candCap = (int)cap;
+        int nodes = L.quota + 3 > 4 * L.nIni ? L.quota + 3 : 4 * L.nIni;
+        L.selCap = nodes + 1;
+        if (nodes + 1 > g.maxNodes) g.maxNodes = nodes + 1;
+        L.selOff = g.selPerFrame;
+        g.selPerFrame += L.selCap;
+        g.candPerFrame += L.candCap;
+        g.sumPixels += (long long)L.w * L.h;
+        if (l > 0) {
+            resizeAxis(g.lv[l - 1].w, L.w, true, g.rx[l]);
+            resizeAxis(g.lv[l - 1].h, L.h, false, g.ry[l]);
+        }
+    }
+    return std::string();
+}
+
+// Level-major arenas: all frames of level 0, then all frames of level 1, ...
+inline void layoutArenas(FrameGeom& g, int maxBatch) {
+    long long pyr = 0, blur = 0, cand = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.pyrFrameBytes = (long long)L.pyrStride * L.pyrRows;
+        L.pyrOff = pyr;
+        pyr += L.pyrFrameBytes * maxBatch;
+        L.blurFrameBytes = (long long)L.blurStride * L.h;
+        L.blurOff = blur;
+        blur += L.blurFrameBytes * maxBatch;
+        L.candOff = cand;
+        cand += (long long)L.candCap * maxBatch;
+    }
+    g.pyrBytesPerFrame = pyr / maxBatch;
+    g.blurBytesPerFrame = blur / maxBatch;
+}
+
+}  // namespace orbx

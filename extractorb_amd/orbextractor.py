@@ -1,0 +1,290 @@
+"""ctypes binding of liborbx.so and the Python mirror of ORB_SLAM3::ORBextractor.
+
+Reference interface mirrored here: inc/ORBextractor.h:44-111 (constructor, operator(), scale getters,
+mvImagePyramid), called from Frame::ExtractORB (src/Frame.cc:419-427).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_LIB = os.path.join(_PKG, "liborbx.so")
+_HEADER = os.path.join(_ROOT, "include", "orbx.h")
+
+# numpy mirror of cv::KeyPoint / orbx_keypoint (28 bytes)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+ORBX_OK = 0
+ORBX_ERR_EMPTY_IMAGE = -1
+ORBX_NUM_KERNELS = 8
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compiles liborbx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    csrc = os.path.join(_PKG, "csrc")
+    args = ["make", "-C", csrc]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return _LIB
+
+
+def header_symbols():
+    """Names of every function include/orbx.h declares."""
+    text = open(_HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads liborbx.so; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise OrbxError(-100, "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C extractorb_amd/csrc` (the HIP library is the only compute path)" % _LIB)
+    L = C.CDLL(_LIB)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.orbx_abi_version.restype = C.c_int
+    L.orbx_create.restype = C.c_int
+    L.orbx_create.argtypes = [C.POINTER(vp), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_last_error.argtypes = [vp]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = C.c_float
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_tables.argtypes = [vp] + [vp] * 6
+    L.orbx_max_keypoints.argtypes = [vp]
+    L.orbx_compute_tables.argtypes = [C.c_int, C.c_float, C.c_int] + [vp] * 6
+    L.orbx_compute_level_sizes.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.orbx_compute_cell_grid.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [ip] * 7
+    L.orbx_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp, C.c_int, ip, ip, vp, vp]
+    L.orbx_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, C.c_int,
+                                     vp, vp, vp, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp,
+                                            C.c_int, vp, vp, vp, vp]
+    L.orbx_get_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, ip, ip]
+    L.orbx_set_stream.argtypes = [vp, vp]
+    L.orbx_get_stream.restype = vp
+    L.orbx_get_stream.argtypes = [vp]
+    L.orbx_synchronize.argtypes = [vp]
+    L.orbx_debug_num_candidates.argtypes = [vp, C.c_int, C.c_int, ip]
+    L.orbx_debug_get_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.orbx_debug_get_blurred.argtypes = [vp, C.c_int, C.c_int, vp, C.c_ssize_t]
+    L.orbx_profile_enable.argtypes = [vp, C.c_int]
+    L.orbx_profile_reset.argtypes = [vp]
+    L.orbx_profile_read.argtypes = [vp, vp, vp]
+    L.orbx_profile_kernel_name.restype = C.c_char_p
+    L.orbx_profile_kernel_name.argtypes = [C.c_int]
+    L.orbx_algorithmic_bytes.restype = C.c_long
+    L.orbx_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- handle-free host helpers (no GPU needed) -------------------------------------------------------------
+def compute_tables(nfeatures=1000, scale_factor=1.2, nlevels=8):
+    L = load_library()
+    sf = np.zeros(nlevels, np.float32); isf = sf.copy(); s2 = sf.copy(); is2 = sf.copy()
+    q = np.zeros(nlevels, np.int32); um = np.zeros(16, np.int32)
+    rc = L.orbx_compute_tables(nfeatures, scale_factor, nlevels, _ptr(sf), _ptr(isf), _ptr(s2), _ptr(is2), _ptr(q), _ptr(um))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_compute_tables")
+    return dict(scale_factors=sf, inv_scale_factors=isf, level_sigma2=s2, inv_level_sigma2=is2,
+                features_per_level=q, umax=um)
+
+
+def compute_level_sizes(rows, cols, scale_factor=1.2, nlevels=8):
+    L = load_library()
+    w = np.zeros(nlevels, np.int32); h = np.zeros(nlevels, np.int32)
+    rc = L.orbx_compute_level_sizes(scale_factor, nlevels, rows, cols, _ptr(w), _ptr(h))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_compute_level_sizes")
+    return list(zip(w.tolist(), h.tolist()))
+
+
+def compute_cell_grid(rows, cols, level, scale_factor=1.2, nlevels=8):
+    L = load_library()
+    v = [C.c_int() for _ in range(7)]
+    rc = L.orbx_compute_cell_grid(scale_factor, nlevels, rows, cols, level, *[C.byref(x) for x in v])
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_compute_cell_grid")
+    keys = ["n_cols", "n_rows", "w_cell", "h_cell", "n_cells", "n_ini", "cand_cap"]
+    return dict(zip(keys, [x.value for x in v]))
+
+
+class ORBextractor:
+    """Mirror of ``ORB_SLAM3::ORBextractor`` (reference inc/ORBextractor.h:44-111) on one MI355X.
+
+    ``ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)`` as in the reference; the
+    extra keyword arguments size the device arenas once (the reference reallocates per call).
+    ``extractor(image, mask=None, lapping=(0, 1000))`` mirrors ``operator()``: it returns
+    ``(mono_index, keypoints, descriptors, all_levels_keypoints)`` where the reference fills its output
+    arguments; ``mono_index`` is the reference's return value (-1 for an empty image).
+    """
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, *,
+                 max_width=640, max_height=480, max_batch=1, device=-1):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.orbx_create(C.byref(self._h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                                 max_width, max_height, max_batch, device)
+        if rc != ORBX_OK:
+            self._h = None
+            raise OrbxError(rc, (self._L.orbx_last_error(None) or b"").decode())
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.scaleFactor, self.iniThFAST, self.minThFAST = scaleFactor, iniThFAST, minThFAST
+        self.max_width, self.max_height, self.max_batch = max_width, max_height, max_batch
+        self.capacity = self._L.orbx_max_keypoints(self._h)
+        t = compute_tables(nfeatures, scaleFactor, nlevels)
+        self.mvScaleFactor, self.mvInvScaleFactor = t["scale_factors"], t["inv_scale_factors"]
+        self.mvLevelSigma2, self.mvInvLevelSigma2 = t["level_sigma2"], t["inv_level_sigma2"]
+        self.mnFeaturesPerLevel, self.umax = t["features_per_level"], t["umax"]
+
+    # ---- reference getters (inc/ORBextractor.h:63-83) ----
+    def GetLevels(self): return self.nlevels
+    def GetScaleFactor(self): return self._L.orbx_get_scale_factor(self._h)
+    def GetScaleFactors(self): return self.mvScaleFactor.copy()
+    def GetInverseScaleFactors(self): return self.mvInvScaleFactor.copy()
+    def GetScaleSigmaSquares(self): return self.mvLevelSigma2.copy()
+    def GetInverseScaleSigmaSquares(self): return self.mvInvLevelSigma2.copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != ORBX_OK:
+            raise OrbxError(rc, (self._L.orbx_last_error(self._h) or b"").decode())
+
+    # ---- operator() ----
+    def __call__(self, image, mask=None, lapping=(0, 1000)):
+        image = np.asarray(image)
+        if image.size == 0:
+            return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8), [np.zeros(0, KEYPOINT_DTYPE)] * self.nlevels
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1:
+            raise ValueError("image must be a 2-D uint8 array with contiguous rows (CV_8UC1)")   # assert at ORBextractor.cc:1087
+        cap = self.capacity
+        kps = np.zeros(cap, KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        lvl = np.zeros(cap, KEYPOINT_DTYPE); counts = np.zeros(self.nlevels, np.int32)
+        n, mono = C.c_int(), C.c_int()
+        self._check(self._L.orbx_extract(self._h, _ptr(image), image.shape[0], image.shape[1], image.strides[0],
+                                         int(lapping[0]), int(lapping[1]), _ptr(kps), _ptr(desc), cap,
+                                         C.byref(n), C.byref(mono), _ptr(lvl), _ptr(counts)))
+        per_level, o = [], 0
+        for c in counts.tolist():
+            per_level.append(lvl[o:o + c].copy()); o += c
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy(), per_level
+
+    def extract_batch(self, images, lapping=None):
+        """images: uint8 [B, rows, cols].  Returns a list of (mono_index, keypoints, descriptors, per_level)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        B, rows, cols = images.shape
+        cap = self.capacity
+        kps = np.zeros((B, cap), KEYPOINT_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
+        lvl = np.zeros((B, cap), KEYPOINT_DTYPE); counts = np.zeros((B, self.nlevels), np.int32)
+        n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
+        lap = None
+        if lapping is not None:
+            lap = np.ascontiguousarray(np.broadcast_to(np.asarray(lapping, np.int32).reshape(-1, 2), (B, 2)))
+        self._check(self._L.orbx_extract_batch(self._h, B, _ptr(images), rows, cols, cols, rows * cols, _ptr(lap),
+                                               _ptr(kps), _ptr(desc), cap, _ptr(n), _ptr(mono), _ptr(lvl), _ptr(counts)))
+        out = []
+        for f in range(B):
+            per_level, o = [], 0
+            for c in counts[f].tolist():
+                per_level.append(lvl[f, o:o + c].copy()); o += c
+            out.append((int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), per_level))
+        return out
+
+    def extract_batch_device(self, d_images, n_frames, rows, cols, d_kps, d_desc, d_n, d_mono, capacity,
+                             stride=None, frame_stride=None, lapping=None, d_level_kps=0, d_level_counts=0):
+        """Device-pointer form (ints or objects with .data_ptr()); asynchronous on the handle's stream."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        stride = cols if stride is None else stride
+        frame_stride = rows * stride if frame_stride is None else frame_stride
+        lap = None
+        if lapping is not None:
+            lap = np.ascontiguousarray(np.broadcast_to(np.asarray(lapping, np.int32).reshape(-1, 2), (n_frames, 2)))
+        self._check(self._L.orbx_extract_batch_device(self._h, n_frames, dp(d_images), rows, cols, stride, frame_stride,
+                                                      _ptr(lap), dp(d_kps), dp(d_desc), capacity, dp(d_n), dp(d_mono),
+                                                      dp(d_level_kps), dp(d_level_counts)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._L.orbx_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def synchronize(self):
+        self._check(self._L.orbx_synchronize(self._h))
+
+    # ---- mvImagePyramid (inc/ORBextractor.h:85) ----
+    def image_pyramid_level(self, level, frame=0, bordered=False):
+        w, h = C.c_int(), C.c_int()
+        sizes = compute_level_sizes(self.max_height, self.max_width, self.scaleFactor, self.nlevels)
+        buf = np.zeros((sizes[0][1] + 38, sizes[0][0] + 38), np.uint8)
+        self._check(self._L.orbx_get_level(self._h, frame, level, int(bordered), _ptr(buf), buf.strides[0], C.byref(w), C.byref(h)))
+        if bordered:
+            return buf[:h.value + 38, :w.value + 38].copy()
+        return buf[:h.value, :w.value].copy()
+
+    @property
+    def mvImagePyramid(self):
+        return [self.image_pyramid_level(l) for l in range(self.nlevels)]
+
+    # ---- introspection for tests/bench ----
+    def debug_candidates(self, level, frame=0):
+        n = C.c_int()
+        self._check(self._L.orbx_debug_num_candidates(self._h, frame, level, C.byref(n)))
+        out = np.zeros(max(n.value, 1), KEYPOINT_DTYPE)
+        self._check(self._L.orbx_debug_get_candidates(self._h, frame, level, _ptr(out), len(out)))
+        return out[:n.value].copy()
+
+    def debug_blurred(self, level, frame=0):
+        w, h = self.image_pyramid_level(level, frame).shape[::-1]
+        out = np.zeros((h, w), np.uint8)
+        self._check(self._L.orbx_debug_get_blurred(self._h, frame, level, _ptr(out), out.strides[0]))
+        return out
+
+    def profile(self, enable=True):
+        self._check(self._L.orbx_profile_enable(self._h, int(enable)))
+        self._check(self._L.orbx_profile_reset(self._h))
+
+    def profile_read(self):
+        ms = np.zeros(ORBX_NUM_KERNELS, np.float64); n = np.zeros(ORBX_NUM_KERNELS, np.int64)
+        self._check(self._L.orbx_profile_read(self._h, _ptr(ms), _ptr(n)))
+        return {self._L.orbx_profile_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(ORBX_NUM_KERNELS)}
+
+    def algorithmic_bytes(self, rows, cols, n_out):
+        return int(self._L.orbx_algorithmic_bytes(self._h, rows, cols, n_out))

@@ -1,0 +1,162 @@
+/* orbx.h — C ABI of the MI355X-native ORB extractor (liborbx.so).
+ *
+ * Drop-in boundary for the reference's ORB_SLAM3::ORBextractor (reference
+ * inc/ORBextractor.h:44-111): every entry point below names the reference interface it replaces.
+ * The C++ shim include/orbx_extractor.hpp rebuilds the reference class on top of these calls;
+ * INTEGRATION.md shows the binding a maintainer adds at Frame::ExtractORB (reference
+ * src/Frame.cc:419-427).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; no exceptions cross this boundary
+ *   - return value: ORBX_OK (0) or a negative orbx_status; orbx_last_error() gives the text
+ *   - one handle == one camera == one HIP stream + its device buffers (the reference keeps one
+ *     ORBextractor per camera: src/Tracking.cc:768-774).  Calls on one handle are serialised by
+ *     the caller, calls on different handles may run concurrently (as Frame.cc:109-112 does)
+ *   - "device" pointers are HIP device pointers valid on the handle's GPU
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_ABI_VERSION 1
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE_THRESHOLD 19 /* reference ORBextractor.cc:72 */
+
+typedef enum orbx_status {
+    ORBX_OK = 0,
+    ORBX_ERR_EMPTY_IMAGE = -1,    /* reference operator() returns -1 (ORBextractor.cc:1083-1084) */
+    ORBX_ERR_BAD_ARGUMENT = -2,
+    ORBX_ERR_CAPACITY = -3,       /* caller's output capacity too small */
+    ORBX_ERR_IMAGE_TOO_LARGE = -4,/* exceeds max_width/max_height/max_batch given at create */
+    ORBX_ERR_IMAGE_TOO_SMALL = -5,/* coarsest level narrower than one 30-px FAST cell (reference divides by 0) */
+    ORBX_ERR_HIP = -6,            /* HIP runtime error, see orbx_last_error */
+    ORBX_ERR_NO_DEVICE = -7,
+    ORBX_ERR_UNSUPPORTED = -8
+} orbx_status;
+
+/* Layout-identical to cv::KeyPoint (28 bytes; reference consumers read pt/octave/angle/size/response:
+ * src/Frame.cc:383-417, 748-782).  The shim memcpy's arrays of these into std::vector<cv::KeyPoint>. */
+typedef struct orbx_keypoint {
+    float x, y;     /* pt: level-0 pixel coordinates in the final arrays; level coordinates in per-level arrays */
+    float size;     /* (int)(31 * scale[level])                         ORBextractor.cc:872,881 */
+    float angle;    /* IC_Angle, degrees in [0,360)                      ORBextractor.cc:75-102 */
+    float response; /* FAST-9 corner score                                ORBextractor.cc:818-819 */
+    int32_t octave; /* pyramid level                                      ORBextractor.cc:880 */
+    int32_t class_id; /* always -1 */
+} orbx_keypoint;
+
+typedef struct orbx_handle orbx_handle; /* opaque */
+
+/* Replaces ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (inc/ORBextractor.h:50-51, ORBextractor.cc:408-475).  All device memory for images up to
+ * max_width x max_height and batches up to max_batch frames is allocated here, once.
+ * device < 0 selects the current HIP device. */
+int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                int min_th_fast, int max_width, int max_height, int max_batch, int device);
+void orbx_destroy(orbx_handle* h);
+const char* orbx_last_error(const orbx_handle* h); /* h may be NULL: error of the last failed orbx_create */
+int orbx_abi_version(void);
+
+/* Replaces the getters inc/ORBextractor.h:63-83 (GetLevels, GetScaleFactor, GetScaleFactors,
+ * GetInverseScaleFactors, GetScaleSigmaSquares, GetInverseScaleSigmaSquares) plus the public members
+ * mnFeaturesPerLevel / umax (:103-105).  Arrays hold nlevels (umax: 16) entries.  Host-only. */
+int orbx_get_levels(const orbx_handle* h);
+float orbx_get_scale_factor(const orbx_handle* h);
+int orbx_get_tables(const orbx_handle* h, float* scale_factors, float* inv_scale_factors,
+                    float* level_sigma2, float* inv_level_sigma2, int* features_per_level, int* umax16);
+/* Max keypoints one frame can produce: sum over levels of max(quota+3, 4*nIni) for the widest
+ * supported aspect; callers size kps/desc with it (nfeatures + 3*nlevels for ordinary aspects). */
+int orbx_max_keypoints(const orbx_handle* h);
+
+/* Handle-free host helpers (no GPU touched; usable on a machine without one).
+ * orbx_compute_tables: the constructor's tables for (nfeatures, scaleFactor, nlevels), ORBextractor.cc:419-474.
+ * orbx_compute_level_sizes: pyramid level sizes of a cols x rows image, ORBextractor.cc:1171.
+ * orbx_compute_cell_grid: FAST cell grid of one level (nCols, nRows, wCell, hCell: ORBextractor.cc:789-795),
+ *   the number of cv::FAST calls the reference makes on it, the quad-tree root count nIni (:548) and the
+ *   exact upper bound of FAST candidates the level can produce. */
+int orbx_compute_tables(int nfeatures, float scale_factor, int nlevels, float* scale_factors,
+                        float* inv_scale_factors, float* level_sigma2, float* inv_level_sigma2,
+                        int* features_per_level, int* umax16);
+int orbx_compute_level_sizes(float scale_factor, int nlevels, int rows, int cols, int* widths, int* heights);
+int orbx_compute_cell_grid(float scale_factor, int nlevels, int rows, int cols, int level, int* n_cols,
+                           int* n_rows, int* w_cell, int* h_cell, int* n_cells, int* n_ini, int* cand_cap);
+
+/* Replaces int ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea,
+ * allLevelsKeypoints) (inc/ORBextractor.h:58-61, ORBextractor.cc:1078-1162) for one CV_8UC1 host image.
+ *   img/rows/cols/stride : the cv::Mat (data, rows, cols, step); mask is ignored by the reference
+ *   lap0, lap1           : vLappingArea[0], [1]
+ *   kps, desc, capacity  : caller-owned outputs, desc is capacity x 32 bytes, row i <-> kps[i]
+ *   *n_out               : number of keypoints == keypoints.size()
+ *   *mono_out            : the reference's return value (monoIndex)
+ *   level_kps, level_counts (optional, may be NULL): allLevelsKeypoints flattened level by level in
+ *                          level coordinates (capacity entries), and the nlevels per-level counts
+ * Returns ORBX_ERR_EMPTY_IMAGE (-1) for rows==0||cols==0||img==NULL exactly as the reference returns -1.
+ * Synchronous: results are in host memory on return. */
+int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0,
+                 int lap1, orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out,
+                 orbx_keypoint* level_kps, int* level_counts);
+
+/* Batched form for a video stream or a stereo pair (the two std::threads of Frame.cc:109-112 become one
+ * launch sequence).  All frames share rows/cols/stride; frame f starts at imgs + f*frame_stride.
+ * Outputs are frame-major with a fixed per-frame capacity: kps[f*capacity + i], desc[(f*capacity+i)*32],
+ * n_out[f], mono_out[f], level_counts[f*nlevels + l].  lap0/lap1 may be NULL (=> {0,1000}, the mono
+ * default of Frame.cc:307) or hold one pair per frame: lap[2*f], lap[2*f+1]. */
+int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols,
+                       ptrdiff_t stride, ptrdiff_t frame_stride, const int* lap, orbx_keypoint* kps,
+                       uint8_t* desc, int capacity, int* n_out, int* mono_out, orbx_keypoint* level_kps,
+                       int* level_counts);
+
+/* Device-resident batched form: d_imgs and the outputs are device pointers; the work is enqueued on the
+ * handle's stream and NOT synchronised (call orbx_synchronize or sync the stream yourself).  Same output
+ * layout as orbx_extract_batch; d_level_kps/d_level_counts may be NULL.  lap is a HOST pointer (or NULL). */
+int orbx_extract_batch_device(orbx_handle* h, int n_frames, const uint8_t* d_imgs, int rows, int cols,
+                              ptrdiff_t stride, ptrdiff_t frame_stride, const int* lap,
+                              orbx_keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_n_out,
+                              int* d_mono_out, orbx_keypoint* d_level_kps, int* d_level_counts);
+
+/* Replaces reads of the public member mvImagePyramid (inc/ORBextractor.h:85; read by
+ * Frame::ComputeStereoMatches, src/Frame.cc:820,910,929) after a call: copies level `level` of frame
+ * `frame` of the last batch to host.  bordered==0: width x height pixels; bordered!=0: the
+ * (width+38) x (height+38) buffer with the BORDER_REFLECT_101 frame of ORBextractor.cc:1193-1215. */
+int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride,
+                   int* width, int* height);
+
+/* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
+ * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
+ * and graphs see the work. */
+int orbx_set_stream(orbx_handle* h, void* hip_stream);
+void* orbx_get_stream(const orbx_handle* h);
+int orbx_synchronize(orbx_handle* h);
+
+/* ---- introspection used by tests and bench.py (not part of the reference surface) ------------- */
+
+/* Stage outputs of frame `frame` of the last batch, copied to host.  Candidates are the reference's
+ * vToDistributeKeys of one level (ORBextractor.cc:786-864) in rectangle coordinates; their order is
+ * unspecified (the octree result does not depend on it), sort before comparing. */
+int orbx_debug_num_candidates(orbx_handle* h, int frame, int level, int* n);
+int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoint* out, int capacity);
+/* The 7x7 sigma-2 blurred level (ORBextractor.cc:1126-1127), width x height. */
+int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride);
+
+/* Per-kernel timing with HIP events on the handle's stream.  enable=1 brackets every kernel launch of
+ * subsequent extract calls with events (adds launch overhead: use for attribution, not for fps). */
+#define ORBX_NUM_KERNELS 8
+int orbx_profile_enable(orbx_handle* h, int enable);
+int orbx_profile_reset(orbx_handle* h);
+/* Resolves pending events; fills total milliseconds and launch counts per kernel slot. */
+int orbx_profile_read(orbx_handle* h, double* total_ms, long* launches);
+const char* orbx_profile_kernel_name(int slot);
+
+/* Algorithmic HBM bytes of one frame at this geometry (P0 + 2*S + 60*n_out). */
+long orbx_algorithmic_bytes(const orbx_handle* h, int rows, int cols, int n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,779 @@
+// orb_oracle.cpp — CPU ORACLE for the ORB extraction hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// The product path (extractorb_amd/, liborbx.so) never links, imports or calls it.
+//
+// PARITY UNPINNED: the reference (/root/reference/src/orb_extractor/ORBextractor.cc) delegates all
+// pixel arithmetic to OpenCV 3 (CMakeLists.txt:23), which is neither vendored in the reference nor
+// installed in this image, and the reference ships no tests or golden vectors.
+// This file therefore restates (a) the control flow, constants, float/int conversion points and
+// container order of ORBextractor.cc, each function citing the lines it follows, and (b) the
+// published OpenCV 3.4 generic-C++ semantics of the seven primitives the reference calls
+// (SURVEY.md Appendix A).  The primitives are pinned by independent definitions in tests/
+// (brute-force FAST-9 predicate/score, scipy mirror convolution for the blur, double-precision
+// atan2, exhaustive glibc sinf/cosf comparison), not by a real OpenCV run.
+//
+// One declared divergence: the std::sort tie at ORBextractor.cc:689 is by heap address in the
+// reference (allocator dependent); the oracle breaks ties by node creation order, newest first
+// (SURVEY.md §8c).
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off: the reference is built for baseline
+// x86-64, i.e. without FMA contraction — CMakeLists.txt:4-5 has no -march flag).
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// OpenCV scalar helpers
+// ---------------------------------------------------------------------------------------------
+inline int cvRoundF(float v) { return (int)lrintf(v); }    // round-half-even under default MXCSR
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+inline int cvCeilF(float v) { int i = (int)v; return i + (i < v); }
+inline short saturateShort(float v) {
+    int i = cvRoundF(v);
+    return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
+}
+
+const int PATCH_SIZE = 31;        // ORBextractor.cc:70
+const int HALF_PATCH_SIZE = 15;   // ORBextractor.cc:71
+const int EDGE_THRESHOLD = 19;    // ORBextractor.cc:72
+
+const int8_t kPattern[1024] = {
+#include "../include/orbx_brief_pattern.inc"
+};
+
+// cv::KeyPoint layout: 28 bytes, no padding.
+struct KeyPoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+};
+static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
+
+struct Gray {   // tightly described 8-bit view
+    int w = 0, h = 0, stride = 0;
+    const uint8_t* p = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// A.1  cv::resize(INTER_LINEAR), CV_8UC1, generic fixed-point path.
+// Call site: ORBextractor.cc:1183-1188.
+// ---------------------------------------------------------------------------------------------
+void resizeLinear8u(const uint8_t* src, int sw, int sh, int sstride,
+                    uint8_t* dst, int dw, int dh, int dstride) {
+    const double scale_x = 1.0 / ((double)dw / sw);
+    const double scale_y = 1.0 / ((double)dh / sh);
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> alpha(2 * dw), beta(2 * dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = saturateShort((1.f - fx) * 2048);
+        alpha[2 * dx + 1] = saturateShort(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[2 * dy] = saturateShort((1.f - fy) * 2048);
+        beta[2 * dy + 1] = saturateShort(fy * 2048);
+    }
+    std::vector<int> row0(dw), row1(dw);
+    auto hpass = [&](int sy, std::vector<int>& out) {
+        const uint8_t* S = src + (size_t)sy * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            if (sx >= sw - 1) out[dx] = S[sx] * 2048;   // right-clamped columns use one tap
+            else out[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+        }
+    };
+    auto clip = [](int v, int n) { return v < 0 ? 0 : (v < n ? v : n - 1); };
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = clip(yofs[dy], sh), sy1 = clip(yofs[dy] + 1, sh);
+        hpass(sy0, row0);
+        hpass(sy1, row1);
+        int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// A.4  BORDER_REFLECT_101 index map.
+inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        else p = 2 * (n - 1) - p;
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A.2  cv::GaussianBlur(7x7, sigma 2, REFLECT_101), CV_8UC1.  Call site: ORBextractor.cc:1127.
+// Taps: getGaussianKernel(7, 2) in float, converted to 8-bit fixed point by rounding.
+// ---------------------------------------------------------------------------------------------
+void gaussTaps(int taps[7]) {
+    // getGaussianKernel: exp in double, stored float, normalised by the double sum of the floats.
+    float cf[7];
+    double sum = 0, scale2X = -0.5 / (2.0 * 2.0);
+    for (int i = 0; i < 7; i++) {
+        double x = i - 3;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        taps[i] = cvRoundD((double)cf[i] * 256.0);
+    }
+}
+
+void gaussianBlur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+    int k[7];
+    gaussTaps(k);
+    std::vector<int> rows((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstride;
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int t = 0; t < 7; t++) s += k[t] * S[reflect101(x + t - 3, w)];
+            rows[(size_t)y * w + x] = s;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int t = 0; t < 7; t++) s += k[t] * rows[(size_t)reflect101(y + t - 3, h) * w + x];
+            int v = (s + 32768) >> 16;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A.3  cv::FAST(img, kps, t, true) == TYPE_9_16 with cornerScore<16> and 3x3 strict NMS over the
+// ROI only.  Call sites: ORBextractor.cc:818-819, 837-838.
+// ---------------------------------------------------------------------------------------------
+const int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+const int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// corner test + score, written from the definition: arc of 9 contiguous ring pixels all darker
+// than v-t or all brighter than v+t; score = max(t, S_dark, S_bright) - 1.
+inline int fastScoreAt(const uint8_t* p, int stride, int t, bool* isCorner) {
+    int v = p[0];
+    int d[25];
+    for (int k = 0; k < 16; k++) d[k] = v - p[kRingDy[k] * stride + kRingDx[k]];
+    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+    int sDark = -1000, sBright = -1000;
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+        for (int j = 1; j < 9; j++) { mn = std::min(mn, d[k + j]); mx = std::max(mx, d[k + j]); }
+        sDark = std::max(sDark, mn);       // all d > t  <=> ring darker than v - t
+        sBright = std::max(sBright, -mx);  // all -d > t <=> ring brighter than v + t
+    }
+    int s = std::max(sDark, sBright);
+    *isCorner = s > t;
+    return std::max(t, s) - 1;
+}
+
+void fastDetect(const Gray& roi, int threshold, bool nms, std::vector<KeyPoint>& out) {
+    out.clear();
+    const int W = roi.w, H = roi.h;
+    if (W < 7 || H < 7) return;
+    std::vector<uint8_t> score((size_t)W * H, 0);   // 0 outside the tested interior / non-corners
+    std::vector<uint8_t> corner((size_t)W * H, 0);
+    for (int y = 3; y < H - 3; y++)
+        for (int x = 3; x < W - 3; x++) {
+            bool c;
+            int s = fastScoreAt(roi.p + (size_t)y * roi.stride + x, roi.stride, threshold, &c);
+            if (c) { score[(size_t)y * W + x] = (uint8_t)s; corner[(size_t)y * W + x] = 1; }
+        }
+    for (int y = 3; y < H - 3; y++)
+        for (int x = 3; x < W - 3; x++) {
+            if (!corner[(size_t)y * W + x]) continue;
+            int s = score[(size_t)y * W + x];
+            if (nms) {
+                const uint8_t* c = &score[(size_t)y * W + x];
+                if (!(s > c[-1] && s > c[1] && s > c[-W - 1] && s > c[-W] && s > c[-W + 1] &&
+                      s > c[W - 1] && s > c[W] && s > c[W + 1]))
+                    continue;
+            }
+            out.push_back(KeyPoint{(float)x, (float)y, 7.f, -1.f, (float)s, 0, -1});
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A.5  cv::fastAtan2 (degrees).  Call site: ORBextractor.cc:101.
+// ---------------------------------------------------------------------------------------------
+float fastAtan2f(float y, float x) {
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale,
+                p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// glibc >= 2.28 sinf/cosf algorithm restated (double-precision minimax polynomials after a
+// quadrant reduction), valid for 0 <= x < 120.  The oracle itself calls the host's cosf/sinf as
+// the reference does (ORBextractor.cc:111); this restatement is what the HIP kernel evaluates, and
+// tests/test_oracle_primitives.py checks it against the host libm over every float in [0, 2*pi].
+// ---------------------------------------------------------------------------------------------
+void sincosRestated(float y, float* s_out, float* c_out) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                 C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    auto polySin = [&](double x, double x2) {
+        double x3 = x * x2, s1 = S2 + x2 * S3, x7 = x3 * x2, s = x + x3 * S1;
+        return s + x7 * s1;
+    };
+    auto polyCos = [&](double x2, double sgn) {   // sgn = -1 evaluates the negated table
+        double x4 = x2 * x2, c2 = sgn * C3 + x2 * (sgn * C4), c1 = sgn * C0 + x2 * (sgn * C1),
+               x6 = x4 * x2, c = c1 + x4 * (sgn * C2);
+        return c + x6 * c2;
+    };
+    double x = y;
+    // glibc compares only the top 12 bits (sign stripped) of y with those of pi/4, i.e. y < 0.75
+    uint32_t yb;
+    std::memcpy(&yb, &y, 4);
+    const uint32_t top12 = (yb >> 20) & 0x7ff;
+    if (top12 < 0x3f4) {
+        double x2 = x * x;
+        if (top12 < 0x398) { *s_out = y; *c_out = 1.0f; return; }   // y < 2^-12
+        *s_out = (float)polySin(x, x2);
+        *c_out = (float)polyCos(x2, 1.0);
+        return;
+    }
+    double r = x * hpi_inv;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * hpi;
+    const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    double x2 = x * x;
+    {   // sin
+        double s = sign[n & 3];
+        double sg = (n & 2) ? -1.0 : 1.0;
+        *s_out = (n & 1) ? (float)polyCos(x2, sg) : (float)polySin(x * s, x2);
+    }
+    {   // cos
+        double s = sign[(n + 1) & 3];
+        double sg = ((n + 1) & 2) ? -1.0 : 1.0;
+        *c_out = ((n ^ 1) & 1) ? (float)polyCos(x2, sg) : (float)polySin(x * s, x2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ExtractorNode / DivideNode: ORBextractor.h:31-42, ORBextractor.cc:486-542
+// ---------------------------------------------------------------------------------------------
+struct Pt2i { int x = 0, y = 0; };
+
+struct Node {
+    std::vector<KeyPoint> vKeys;
+    Pt2i UL, UR, BL, BR;
+    std::list<Node>::iterator lit;
+    bool bNoMore = false;
+    long seq = 0;   // creation order: the oracle's declared tie-break for the sort at :689
+
+    void divide(Node& n1, Node& n2, Node& n3, Node& n4) const {
+        const int halfX = (int)std::ceil(static_cast<float>(UR.x - UL.x) / 2);
+        const int halfY = (int)std::ceil(static_cast<float>(BR.y - UL.y) / 2);
+        n1.UL = UL;
+        n1.UR = Pt2i{UL.x + halfX, UL.y};
+        n1.BL = Pt2i{UL.x, UL.y + halfY};
+        n1.BR = Pt2i{UL.x + halfX, UL.y + halfY};
+        n2.UL = n1.UR; n2.UR = UR; n2.BL = n1.BR; n2.BR = Pt2i{UR.x, UL.y + halfY};
+        n3.UL = n1.BL; n3.UR = n1.BR; n3.BL = BL; n3.BR = Pt2i{n1.BR.x, BL.y};
+        n4.UL = n3.UR; n4.UR = n2.BR; n4.BL = n3.BR; n4.BR = BR;
+        for (size_t i = 0; i < vKeys.size(); i++) {
+            const KeyPoint& kp = vKeys[i];
+            if (kp.x < n1.UR.x) {
+                if (kp.y < n1.BR.y) n1.vKeys.push_back(kp);
+                else n3.vKeys.push_back(kp);
+            } else if (kp.y < n1.BR.y) n2.vKeys.push_back(kp);
+            else n4.vKeys.push_back(kp);
+        }
+        if (n1.vKeys.size() == 1) n1.bNoMore = true;
+        if (n2.vKeys.size() == 1) n2.bNoMore = true;
+        if (n3.vKeys.size() == 1) n3.bNoMore = true;
+        if (n4.vKeys.size() == 1) n4.bNoMore = true;
+    }
+};
+
+// DistributeOctTree: ORBextractor.cc:544-771.
+std::vector<KeyPoint> distributeOctTree(const std::vector<KeyPoint>& vToDistributeKeys, int minX,
+                                        int maxX, int minY, int maxY, int N) {
+    const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+    std::vector<KeyPoint> vResultKeys;
+    if (nIni < 1) return vResultKeys;   // reference indexes an empty vector here (undefined)
+    const float hX = static_cast<float>(maxX - minX) / nIni;
+    long seq = 0;
+
+    std::list<Node> lNodes;
+    std::vector<Node*> vpIniNodes(nIni);
+    for (int i = 0; i < nIni; i++) {
+        Node ni;
+        ni.UL = Pt2i{(int)(hX * static_cast<float>(i)), 0};
+        ni.UR = Pt2i{(int)(hX * static_cast<float>(i + 1)), 0};
+        ni.BL = Pt2i{ni.UL.x, maxY - minY};
+        ni.BR = Pt2i{ni.UR.x, maxY - minY};
+        ni.seq = seq++;
+        lNodes.push_back(ni);
+        vpIniNodes[i] = &lNodes.back();
+    }
+    for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+        const KeyPoint& kp = vToDistributeKeys[i];
+        vpIniNodes[(int)(kp.x / hX)]->vKeys.push_back(kp);
+    }
+    auto lit = lNodes.begin();
+    while (lit != lNodes.end()) {
+        if (lit->vKeys.size() == 1) { lit->bNoMore = true; lit++; }
+        else if (lit->vKeys.empty()) lit = lNodes.erase(lit);
+        else lit++;
+    }
+
+    bool bFinish = false;
+    typedef std::pair<std::pair<int, long>, Node*> SizeSeqNode;   // (size, seq) then pointer payload
+    std::vector<SizeSeqNode> vSizeAndPointerToNode;
+
+    auto pushChildren = [&](Node& n1, Node& n2, Node& n3, Node& n4, int* nToExpand) {
+        Node* ch[4] = {&n1, &n2, &n3, &n4};
+        for (int c = 0; c < 4; c++) {
+            if (ch[c]->vKeys.size() > 0) {
+                ch[c]->seq = seq++;
+                lNodes.push_front(*ch[c]);
+                if (ch[c]->vKeys.size() > 1) {
+                    if (nToExpand) (*nToExpand)++;
+                    vSizeAndPointerToNode.push_back(
+                        {{(int)ch[c]->vKeys.size(), lNodes.front().seq}, &lNodes.front()});
+                    lNodes.front().lit = lNodes.begin();
+                }
+            }
+        }
+    };
+
+    while (!bFinish) {
+        int prevSize = (int)lNodes.size();
+        lit = lNodes.begin();
+        int nToExpand = 0;
+        vSizeAndPointerToNode.clear();
+        while (lit != lNodes.end()) {
+            if (lit->bNoMore) { lit++; continue; }
+            Node n1, n2, n3, n4;
+            lit->divide(n1, n2, n3, n4);
+            pushChildren(n1, n2, n3, n4, &nToExpand);
+            lit = lNodes.erase(lit);
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+            bFinish = true;
+        } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+            while (!bFinish) {
+                prevSize = (int)lNodes.size();
+                std::vector<SizeSeqNode> vPrev = vSizeAndPointerToNode;
+                vSizeAndPointerToNode.clear();
+                // reference: sort by (size, heap pointer); oracle: by (size, creation seq)
+                std::sort(vPrev.begin(), vPrev.end(),
+                          [](const SizeSeqNode& a, const SizeSeqNode& b) { return a.first < b.first; });
+                for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+                    Node n1, n2, n3, n4;
+                    vPrev[j].second->divide(n1, n2, n3, n4);
+                    pushChildren(n1, n2, n3, n4, nullptr);
+                    lNodes.erase(vPrev[j].second->lit);
+                    if ((int)lNodes.size() >= N) break;
+                }
+                if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+            }
+        }
+    }
+    vResultKeys.reserve(lNodes.size());
+    for (auto it = lNodes.begin(); it != lNodes.end(); it++) {
+        const std::vector<KeyPoint>& vNodeKeys = it->vKeys;
+        const KeyPoint* pKP = &vNodeKeys[0];
+        float maxResponse = pKP->response;
+        for (size_t k = 1; k < vNodeKeys.size(); k++)
+            if (vNodeKeys[k].response > maxResponse) { pKP = &vNodeKeys[k]; maxResponse = vNodeKeys[k].response; }
+        vResultKeys.push_back(*pKP);
+    }
+    return vResultKeys;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The extractor: ORBextractor.cc:408-475 (ctor), :773-888, :1078-1219.
+// ---------------------------------------------------------------------------------------------
+struct Level {
+    int w = 0, h = 0;
+    std::vector<uint8_t> buf;   // (w+38) x (h+38), interior at (19,19)
+    int stride() const { return w + 2 * EDGE_THRESHOLD; }
+    uint8_t* interior() { return buf.data() + (size_t)EDGE_THRESHOLD * stride() + EDGE_THRESHOLD; }
+    const uint8_t* interior() const { return buf.data() + (size_t)EDGE_THRESHOLD * stride() + EDGE_THRESHOLD; }
+};
+
+struct Oracle {
+    int nfeatures, nlevels, iniThFAST, minThFAST;
+    double scaleFactor;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    std::vector<Level> pyr;
+    std::vector<std::vector<uint8_t>> blurred;
+    std::vector<std::vector<KeyPoint>> candidates, levelKeys;
+
+    Oracle(int nf, float sf, int nl, int ini, int mn)
+        : nfeatures(nf), nlevels(nl), iniThFAST(ini), minThFAST(mn), scaleFactor(sf) {
+        mvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f;
+        mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) {
+            mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor);   // float*double -> float
+            mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+        }
+        mvInvScaleFactor.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        for (int i = 0; i < nlevels; i++) {
+            mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+            mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+        }
+        mnFeaturesPerLevel.resize(nlevels);
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+        int sumFeatures = 0;
+        for (int level = 0; level < nlevels - 1; level++) {
+            mnFeaturesPerLevel[level] = cvRoundF(nDesired);
+            sumFeatures += mnFeaturesPerLevel[level];
+            nDesired *= factor;
+        }
+        mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+
+        umax.resize(HALF_PATCH_SIZE + 1);
+        int v, v0, vmax = cvFloorF(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1);
+        int vmin = cvCeilF(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+        for (v = 0; v <= vmax; ++v) umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+        pyr.resize(nlevels);
+        blurred.resize(nlevels);
+        candidates.resize(nlevels);
+        levelKeys.resize(nlevels);
+    }
+
+    // ORBextractor.cc:1164-1219
+    void computePyramid(const Gray& image) {
+        for (int level = 0; level < nlevels; ++level) {
+            float scale = mvInvScaleFactor[level];
+            Level& L = pyr[level];
+            L.w = cvRoundF((float)image.w * scale);
+            L.h = cvRoundF((float)image.h * scale);
+            L.buf.assign((size_t)(L.w + 2 * EDGE_THRESHOLD) * (L.h + 2 * EDGE_THRESHOLD), 0);
+            if (level != 0) {
+                const Level& P = pyr[level - 1];
+                resizeLinear8u(P.interior(), P.w, P.h, P.stride(), L.interior(), L.w, L.h, L.stride());
+            } else {
+                for (int y = 0; y < L.h; y++)
+                    std::memcpy(L.interior() + (size_t)y * L.stride(), image.p + (size_t)y * image.stride, L.w);
+            }
+            // copyMakeBorder(..., 19,19,19,19, BORDER_REFLECT_101) around the interior
+            const int S = L.stride(), E = EDGE_THRESHOLD;
+            for (int by = 0; by < L.h + 2 * E; by++) {
+                int sy = reflect101(by - E, L.h);
+                for (int bx = 0; bx < S; bx++) {
+                    if (by >= E && by < E + L.h && bx >= E && bx < E + L.w) continue;
+                    int sx = reflect101(bx - E, L.w);
+                    L.buf[(size_t)by * S + bx] = L.interior()[(size_t)sy * S + sx];
+                }
+            }
+        }
+    }
+
+    // ORBextractor.cc:75-102
+    float icAngle(const Level& L, float ptx, float pty) const {
+        int m_01 = 0, m_10 = 0;
+        const int step = L.stride();
+        const uint8_t* center = L.interior() + (size_t)cvRoundF(pty) * step + cvRoundF(ptx);
+        for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+        for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+            int v_sum = 0;
+            int d = umax[v];
+            for (int u = -d; u <= d; ++u) {
+                int val_plus = center[u + v * step], val_minus = center[u - v * step];
+                v_sum += (val_plus - val_minus);
+                m_10 += u * (val_plus + val_minus);
+            }
+            m_01 += v * v_sum;
+        }
+        return fastAtan2f((float)m_01, (float)m_10);
+    }
+
+    // ORBextractor.cc:773-888
+    void computeKeyPointsOctTree() {
+        const float W = 30;
+        for (int level = 0; level < nlevels; ++level) {
+            const Level& L = pyr[level];
+            const int minBorderX = EDGE_THRESHOLD - 3;
+            const int minBorderY = minBorderX;
+            const int maxBorderX = L.w - EDGE_THRESHOLD + 3;
+            const int maxBorderY = L.h - EDGE_THRESHOLD + 3;
+            std::vector<KeyPoint>& vToDistributeKeys = candidates[level];
+            vToDistributeKeys.clear();
+            const float width = (float)(maxBorderX - minBorderX);
+            const float height = (float)(maxBorderY - minBorderY);
+            const int nCols = (int)(width / W);
+            const int nRows = (int)(height / W);
+            const int wCell = (int)std::ceil(width / nCols);
+            const int hCell = (int)std::ceil(height / nRows);
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(minBorderY + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBorderY - 3) continue;
+                if (maxY > maxBorderY) maxY = (float)maxBorderY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(minBorderX + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBorderX - 6) continue;
+                    if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                    Gray roi;
+                    roi.w = (int)maxX - (int)iniX;
+                    roi.h = (int)maxY - (int)iniY;
+                    roi.stride = L.stride();
+                    roi.p = L.interior() + (size_t)(int)iniY * L.stride() + (int)iniX;
+                    std::vector<KeyPoint> vKeysCell;
+                    fastDetect(roi, iniThFAST, true, vKeysCell);
+                    if (vKeysCell.empty()) fastDetect(roi, minThFAST, true, vKeysCell);
+                    for (auto& kp : vKeysCell) {
+                        kp.x += j * wCell;
+                        kp.y += i * hCell;
+                        vToDistributeKeys.push_back(kp);
+                    }
+                }
+            }
+            std::vector<KeyPoint>& keypoints = levelKeys[level];
+            keypoints = distributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                          mnFeaturesPerLevel[level]);
+            const int scaledPatchSize = (int)(PATCH_SIZE * mvScaleFactor[level]);
+            for (auto& kp : keypoints) {
+                kp.x += minBorderX;
+                kp.y += minBorderY;
+                kp.octave = level;
+                kp.size = (float)scaledPatchSize;
+            }
+        }
+        for (int level = 0; level < nlevels; ++level)
+            for (auto& kp : levelKeys[level]) kp.angle = icAngle(pyr[level], kp.x, kp.y);
+    }
+
+    // ORBextractor.cc:106-145
+    static void computeOrbDescriptor(const KeyPoint& kpt, const uint8_t* img, int step, uint8_t* desc) {
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float angle = (float)kpt.angle * factorPI;
+        float a = (float)cosf(angle), b = (float)sinf(angle);
+        const uint8_t* center = img + (ptrdiff_t)cvRoundF(kpt.y) * step + cvRoundF(kpt.x);
+        const int8_t* pattern = kPattern;
+        auto GET = [&](int idx) -> int {
+            float px = pattern[2 * idx], py = pattern[2 * idx + 1];
+            return center[cvRoundF(px * b + py * a) * step + cvRoundF(px * a - py * b)];
+        };
+        for (int i = 0; i < 32; ++i, pattern += 32) {
+            int val = 0;
+            for (int k = 0; k < 8; k++) {
+                int t0 = GET(2 * k), t1 = GET(2 * k + 1);
+                val |= (t0 < t1) << k;
+            }
+            desc[i] = (uint8_t)val;
+        }
+    }
+
+    // ORBextractor.cc:1078-1162.  Returns nkeypoints (>= 0) or -1 for an empty image; *mono = return
+    // value of the reference's operator().
+    int extract(const Gray& image, int lap0, int lap1, KeyPoint* outK, uint8_t* outD, int capacity, int* mono) {
+        if (image.w <= 0 || image.h <= 0 || !image.p) { *mono = -1; return -1; }
+        computePyramid(image);
+        computeKeyPointsOctTree();
+        int nkeypoints = 0;
+        for (int level = 0; level < nlevels; ++level) nkeypoints += (int)levelKeys[level].size();
+        if (nkeypoints > capacity) { *mono = -2; return -2; }
+        int monoIndex = 0, stereoIndex = nkeypoints - 1;
+        for (int level = 0; level < nlevels; ++level) {
+            const Level& L = pyr[level];
+            blurred[level].assign((size_t)L.w * L.h, 0);
+            std::vector<KeyPoint> keypoints = levelKeys[level];   // copy: levelKeys keeps level coords
+            if (keypoints.empty()) continue;
+            // clone() drops the border, so REFLECT_101 mirrors the level itself
+            gaussianBlur7(L.interior(), L.w, L.h, L.stride(), blurred[level].data(), L.w);
+            float scale = mvScaleFactor[level];
+            for (auto& kp : keypoints) {
+                uint8_t d[32];
+                computeOrbDescriptor(kp, blurred[level].data(), L.w, d);
+                if (level != 0) { kp.x *= scale; kp.y *= scale; }
+                int at;
+                if (kp.x >= lap0 && kp.x <= lap1) at = stereoIndex--;
+                else at = monoIndex++;
+                outK[at] = kp;
+                std::memcpy(outD + (size_t)at * 32, d, 32);
+            }
+        }
+        *mono = monoIndex;
+        return nkeypoints;
+    }
+};
+
+}  // namespace
+
+// =============================================================================================
+// C API for ctypes (tests / smoke / bench cpu_baseline only)
+// =============================================================================================
+extern "C" {
+
+void* oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+    return new Oracle(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+}
+void oracle_destroy(void* h) { delete (Oracle*)h; }
+
+int oracle_extract(void* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                   void* kps, uint8_t* desc, int capacity, int* mono_index) {
+    Gray g; g.w = cols; g.h = rows; g.stride = stride; g.p = img;
+    return ((Oracle*)h)->extract(g, lap0, lap1, (KeyPoint*)kps, desc, capacity, mono_index);
+}
+
+void oracle_get_tables(void* h, float* sf, float* isf, float* s2, float* is2, int* nfeat, int* umax16) {
+    Oracle* o = (Oracle*)h;
+    for (int i = 0; i < o->nlevels; i++) {
+        sf[i] = o->mvScaleFactor[i]; isf[i] = o->mvInvScaleFactor[i];
+        s2[i] = o->mvLevelSigma2[i]; is2[i] = o->mvInvLevelSigma2[i];
+        nfeat[i] = o->mnFeaturesPerLevel[i];
+    }
+    for (int i = 0; i < 16; i++) umax16[i] = o->umax[i];
+}
+void oracle_level_size(void* h, int level, int* w, int* hh) {
+    Oracle* o = (Oracle*)h; *w = o->pyr[level].w; *hh = o->pyr[level].h;
+}
+// bordered != 0: (w+38)x(h+38) tight; else w x h tight
+void oracle_get_level(void* h, int level, int bordered, uint8_t* dst) {
+    const Level& L = ((Oracle*)h)->pyr[level];
+    if (bordered) { std::memcpy(dst, L.buf.data(), L.buf.size()); return; }
+    for (int y = 0; y < L.h; y++) std::memcpy(dst + (size_t)y * L.w, L.interior() + (size_t)y * L.stride(), L.w);
+}
+void oracle_get_blurred(void* h, int level, uint8_t* dst) {
+    Oracle* o = (Oracle*)h;
+    std::memcpy(dst, o->blurred[level].data(), o->blurred[level].size());
+}
+int oracle_num_candidates(void* h, int level) { return (int)((Oracle*)h)->candidates[level].size(); }
+void oracle_get_candidates(void* h, int level, void* out) {
+    Oracle* o = (Oracle*)h;
+    std::memcpy(out, o->candidates[level].data(), o->candidates[level].size() * sizeof(KeyPoint));
+}
+int oracle_num_level_keys(void* h, int level) { return (int)((Oracle*)h)->levelKeys[level].size(); }
+void oracle_get_level_keys(void* h, int level, void* out) {
+    Oracle* o = (Oracle*)h;
+    std::memcpy(out, o->levelKeys[level].data(), o->levelKeys[level].size() * sizeof(KeyPoint));
+}
+
+// ---- primitives, exposed so tests can pin each one by an independent definition -------------
+void oracle_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride) {
+    resizeLinear8u(src, sw, sh, sstride, dst, dw, dh, dstride);
+}
+void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+    gaussianBlur7(src, w, h, sstride, dst, dstride);
+}
+void oracle_gauss_taps(int* taps7) { gaussTaps(taps7); }
+int oracle_fast(const uint8_t* img, int w, int h, int stride, int threshold, int nms, void* out, int cap) {
+    Gray g; g.w = w; g.h = h; g.stride = stride; g.p = img;
+    std::vector<KeyPoint> v;
+    fastDetect(g, threshold, nms != 0, v);
+    int n = (int)std::min<size_t>(v.size(), (size_t)cap);
+    std::memcpy(out, v.data(), (size_t)n * sizeof(KeyPoint));
+    return (int)v.size();
+}
+float oracle_fast_atan2(float y, float x) { return fastAtan2f(y, x); }
+void oracle_fast_atan2_array(const float* y, const float* x, float* out, int n) {
+    for (int i = 0; i < n; i++) out[i] = fastAtan2f(y[i], x[i]);
+}
+int oracle_distribute(const void* keys, int n, int minX, int maxX, int minY, int maxY, int N, void* out, int cap) {
+    std::vector<KeyPoint> v((const KeyPoint*)keys, (const KeyPoint*)keys + n);
+    std::vector<KeyPoint> r = distributeOctTree(v, minX, maxX, minY, maxY, N);
+    int m = (int)std::min<size_t>(r.size(), (size_t)cap);
+    std::memcpy(out, r.data(), (size_t)m * sizeof(KeyPoint));
+    return (int)r.size();
+}
+void oracle_sincos_restated(float x, float* s, float* c) { sincosRestated(x, s, c); }
+// compares the restated sinf/cosf with the host libm over every float in [lo, hi]; returns #mismatches
+long oracle_sincos_check(float lo, float hi, long* ntested) {
+    uint32_t a, b;
+    std::memcpy(&a, &lo, 4); std::memcpy(&b, &hi, 4);
+    long bad = 0, n = 0;
+    for (uint32_t u = a; u <= b; u++) {
+        float x; std::memcpy(&x, &u, 4);
+        float s, c; sincosRestated(x, &s, &c);
+        if (s != sinf(x) || c != cosf(x)) bad++;
+        n++;
+    }
+    *ntested = n;
+    return bad;
+}
+void oracle_describe(const uint8_t* blurredImg, int step, float x, float y, float angle, uint8_t* desc32) {
+    KeyPoint kp{x, y, 31.f, angle, 0.f, 0, -1};
+    Oracle::computeOrbDescriptor(kp, blurredImg, step, desc32);
+}
+
+// ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,
+// the reference's own execution model per Frame.cc:109-112); returns wall seconds. ------------
+double oracle_time_frames(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,
+                          const uint8_t* frames, int nframes, int rows, int cols, int lap0, int lap1,
+                          int nthreads, long* total_keypoints) {
+    if (nthreads < 1) nthreads = 1;
+    std::vector<long> counts(nthreads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) {
+        th.emplace_back([&, t]() {
+            Oracle o(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+            int cap = nfeatures + 3 * nlevels + 64;
+            std::vector<KeyPoint> k(cap);
+            std::vector<uint8_t> d((size_t)cap * 32);
+            for (int f = t; f < nframes; f += nthreads) {
+                Gray g; g.w = cols; g.h = rows; g.stride = cols; g.p = frames + (size_t)f * rows * cols;
+                int mono;
+                int n = o.extract(g, lap0, lap1, k.data(), d.data(), cap, &mono);
+                if (n > 0) counts[t] += n;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    auto t1 = std::chrono::steady_clock::now();
+    long tot = 0;
+    for (long c : counts) tot += c;
+    if (total_keypoints) *total_keypoints = tot;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product
+package `extractorb_amd`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+
+# numpy mirror of cv::KeyPoint (28 bytes)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+
+def build_oracle(force=False):
+    src = os.path.join(ORACLE_DIR, "orb_oracle.cpp")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "liborb_oracle.so"])
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        u8p, vp, ip, fp = C.POINTER(C.c_uint8), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.oracle_create.restype = vp
+        L.oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_destroy.argtypes = [vp]
+        L.oracle_extract.restype = C.c_int
+        L.oracle_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+        L.oracle_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.oracle_level_size.argtypes = [vp, C.c_int, ip, ip]
+        L.oracle_get_level.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.oracle_get_blurred.argtypes = [vp, C.c_int, vp]
+        L.oracle_num_candidates.restype = C.c_int
+        L.oracle_num_candidates.argtypes = [vp, C.c_int]
+        L.oracle_get_candidates.argtypes = [vp, C.c_int, vp]
+        L.oracle_num_level_keys.restype = C.c_int
+        L.oracle_num_level_keys.argtypes = [vp, C.c_int]
+        L.oracle_get_level_keys.argtypes = [vp, C.c_int, vp]
+        L.oracle_resize_linear.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+        L.oracle_gaussian_blur7.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_gauss_taps.argtypes = [vp]
+        L.oracle_fast.restype = C.c_int
+        L.oracle_fast.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_fast_atan2.restype = C.c_float
+        L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_fast_atan2_array.argtypes = [vp, vp, vp, C.c_int]
+        L.oracle_distribute.restype = C.c_int
+        L.oracle_distribute.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_sincos_restated.argtypes = [C.c_float, fp, fp]
+        L.oracle_sincos_check.restype = C.c_long
+        L.oracle_sincos_check.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_long)]
+        L.oracle_describe.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
+        L.oracle_time_frames.restype = C.c_double
+        L.oracle_time_frames.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """CPU restatement of ORB_SLAM3::ORBextractor (reference inc/ORBextractor.h:44-111)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        sf = np.zeros(nlevels, np.float32); isf = sf.copy(); s2 = sf.copy(); is2 = sf.copy()
+        nf = np.zeros(nlevels, np.int32); um = np.zeros(16, np.int32)
+        self.L.oracle_get_tables(self.h, _ptr(sf), _ptr(isf), _ptr(s2), _ptr(is2), _ptr(nf), _ptr(um))
+        self.scale_factors, self.inv_scale_factors = sf, isf
+        self.level_sigma2, self.inv_level_sigma2 = s2, is2
+        self.features_per_level, self.umax = nf, um
+
+    def __del__(self):
+        try:
+            self.L.oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def extract(self, image, lapping=(0, 1000)):
+        """Returns (mono_index, keypoints[structured], descriptors[n,32]); mono_index -1 for empty."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        mono = C.c_int(0)
+        n = self.L.oracle_extract(self.h, _ptr(image), image.shape[0], image.shape[1], image.strides[0],
+                                  int(lapping[0]), int(lapping[1]), _ptr(kps), _ptr(desc), cap, C.byref(mono))
+        if n < 0:
+            raise RuntimeError("oracle_extract failed: %d" % n)
+        return mono.value, kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        self.L.oracle_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level(self, level, bordered=False):
+        w, h = self.level_size(level)
+        if bordered:
+            out = np.zeros((h + 38, w + 38), np.uint8)
+        else:
+            out = np.zeros((h, w), np.uint8)
+        self.L.oracle_get_level(self.h, level, int(bordered), _ptr(out))
+        return out
+
+    def blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self.L.oracle_get_blurred(self.h, level, _ptr(out))
+        return out
+
+    def candidates(self, level):
+        n = self.L.oracle_num_candidates(self.h, level)
+        out = np.zeros(n, KEYPOINT_DTYPE)
+        if n:
+            self.L.oracle_get_candidates(self.h, level, _ptr(out))
+        return out
+
+    def level_keypoints(self, level):
+        n = self.L.oracle_num_level_keys(self.h, level)
+        out = np.zeros(n, KEYPOINT_DTYPE)
+        if n:
+            self.L.oracle_get_level_keys(self.h, level, _ptr(out))
+        return out
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_linear(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().oracle_gaussian_blur7(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(dst), src.shape[1])
+    return dst
+
+
+def gauss_taps():
+    t = np.zeros(7, np.int32)
+    lib().oracle_gauss_taps(_ptr(t))
+    return t
+
+
+def fast(img, threshold, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(cap, KEYPOINT_DTYPE)
+    n = lib().oracle_fast(_ptr(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nms), _ptr(out), cap)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(y)
+    lib().oracle_fast_atan2_array(_ptr(y), _ptr(x), _ptr(out), y.size)
+    return out
+
+
+def distribute(keys, min_x, max_x, min_y, max_y, n_target):
+    keys = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    cap = max(len(keys), 1)
+    out = np.zeros(cap, KEYPOINT_DTYPE)
+    n = lib().oracle_distribute(_ptr(keys), len(keys), min_x, max_x, min_y, max_y, n_target, _ptr(out), cap)
+    return out[:n].copy()
+
+
+def sincos_restated(x):
+    s, c = C.c_float(), C.c_float()
+    lib().oracle_sincos_restated(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sincos_check(lo, hi):
+    n = C.c_long()
+    bad = lib().oracle_sincos_check(float(lo), float(hi), C.byref(n))
+    return bad, n.value
+
+
+def describe(blurred, x, y, angle):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().oracle_describe(_ptr(blurred), blurred.strides[0], float(x), float(y), float(angle), _ptr(d))
+    return d
+
+
+def time_frames(frames, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, lapping=(0, 1000),
+                nthreads=1):
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, rows, cols = frames.shape
+    tot = C.c_long()
+    sec = lib().oracle_time_frames(nfeatures, scale_factor, nlevels, ini_th, min_th, _ptr(frames), n, rows, cols,
+                                   int(lapping[0]), int(lapping[1]), nthreads, C.byref(tot))
+    return sec, tot.value
