@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the full ORB extraction hot path on N MI355X (one process per GPU).
+
+A "step" is one pass of the whole path (pyramid -> FAST -> quad-tree -> orientation -> blur -> rBRIEF, final
+keypoint + descriptor arrays) over one batch of B synthetic frames that are already resident in HBM when the
+timed region starts; outputs stay in HBM.  With N > 1 every rank processes its own B frames of the stream
+(weak scaling, frames are independent units) and the per-frame result slabs are gathered to rank 0 over
+RCCL inside the timed region (BASELINE.json north_star; disable with --no-gather).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mono640|hd1080|stereo640] [--batch B]
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=64, variant="noise",
+                    desc="640x480 mono stream, 8 levels, 1000 features, synthetic noise frames"),
+    # configs[2]
+    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=16, variant="noise",
+                   desc="1920x1080 mono stream, 8 levels, 2000 features, synthetic noise frames"),
+    # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
+    "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=64, variant="noise",
+                      desc="stereo 640x480 L+R pairs (32 pairs per step), 8 levels, 1200 features per eye"),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="mono640", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: per workload)")
+    ap.add_argument("--variant", default="", help="noise|textured|sparse (default: per workload)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave results on their GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import extractorb_amd as X
+    from extractorb_amd import synth
+
+    wl = dict(WORKLOADS[args.workload])
+    B = args.batch or wl["batch"]
+    variant = args.variant or wl["variant"]
+    rows, cols, nf = wl["rows"], wl["cols"], wl["nfeatures"]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if world != N and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (N, world))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: this rank's B frames of the stream, generated on the host, parked in HBM ----
+    frames = synth.frames(variant, rank * B, B, rows, cols)
+    d_img = torch.from_numpy(frames).cuda()
+    ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ex.set_stream(stream.cuda_stream)
+    cap = ex.capacity
+    # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
+    off_k, off_d = 0, B * cap * 28
+    off_n = off_d + B * cap * 32
+    off_m = off_n + 4 * B
+    slab_bytes = (off_m + 4 * B + 255) // 256 * 256
+    slab = torch.zeros(slab_bytes, dtype=torch.uint8, device="cuda")
+    base = slab.data_ptr()
+    gathered = None
+    if distributed and not args.no_gather and rank == 0:
+        gathered = [torch.empty_like(slab) for _ in range(world)]
+
+    def step():
+        ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
+                                lapping=wl["lapping"])
+        if distributed and not args.no_gather:
+            dist.gather(slab, gathered, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_host = slab[off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
+    fps = N * B * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel durations, HIP events on the handle's stream (separate, untimed pass) ----
+        ex.profile(True)
+        psteps = max(3, min(args.steps, 20))
+        for _ in range(psteps):
+            ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
+                                    lapping=wl["lapping"])
+        prof = ex.profile_read()
+        ex.profile(False)
+        kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
+        per_step_ms = {k: v[0] / psteps for k, v in kern.items()}
+        dominant = max(per_step_ms, key=per_step_ms.get)
+        dom_avg_ms = kern[dominant][0] / kern[dominant][1]            # average duration of ONE launch
+        n_mean = float(n_host.mean())
+        b_alg = ex.algorithmic_bytes(rows, cols, int(round(n_mean)))   # P0 + 2*S + 60*n_out per frame
+        achieved = b_alg * B / (dom_avg_ms * 1e-3) / 1e9               # GB/s: algorithmic bytes of one launch / its duration
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.workload, {}).get(str(B), {}).get(dominant)
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),
+                        path_achieved=round(fps / N * b_alg / 1e9, 2), path_frac=round(fps / N * b_alg / 1e9 / HBM_PEAK_GBS, 5),
+                        kernel_ms_per_step={k: round(v, 4) for k, v in sorted(per_step_ms.items())})
+        cpu = None
+        if N == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O      # the checker, timed as the CPU baseline; never the product path
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            sample = 8 * threads if rows * cols <= 640 * 480 else 2 * threads
+            cf = synth.frames(variant, 0, min(sample, 64), rows, cols)
+            cf = np.concatenate([cf] * ((sample + len(cf) - 1) // len(cf)))[:sample]
+            sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=threads)
+            cpu = dict(value=round(sample / sec, 2), unit="frames/s", cores=threads, kind="port",
+                       sample="%d %s frames %dx%d, one oracle extractor per thread, %.1f s wall; scalar C++ restatement "
+                              "of ORBextractor.cc + OpenCV primitives (not OpenCV's SIMD build)" % (sample, variant, cols, rows, sec))
+        result = {
+            "metric": "frames/sec (ORB extract, %dx%dx8-level x%d feat)" % (cols, rows, nf),
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "variant": variant, "frames_per_gpu_per_step": B,
+                       "global_frames_per_step": N * B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
+                       "fast_thresholds": [20, 7], "lapping": list(wl["lapping"]),
+                       "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
+                       "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0" if (distributed and not args.no_gather) else "")},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,181 @@
+"""Parity of the HIP path (through the C ABI of liborbx.so) with the CPU oracle: bit-exact at every stage
+boundary and in the final keypoints/descriptors.  Runs on the GPU box only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import extractorb_amd as X
+from extractorb_amd import synth
+from helpers import GOLDEN_CASES, assert_same_result, load_case, load_gray, sort_kps
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(img, nf=1000, lap=(0, 1000), nlevels=8, sf=1.2, ini=20, mn=7):
+    o = O.Oracle(nf, sf, nlevels, ini, mn)
+    return o, o.extract(img, lap)
+
+
+def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
+    for l in range(nlevels):
+        assert np.array_equal(ex.image_pyramid_level(l, frame), o.level(l)), "pyramid level %d" % l
+        assert np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)), "border %d" % l
+        if len(o.level_keypoints(l)):      # the reference only blurs levels that hold keypoints (:1122-1127)
+            assert np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)), "blur level %d" % l
+        cg, co = sort_kps(ex.debug_candidates(l, frame)), sort_kps(o.candidates(l))
+        assert cg.tobytes() == co.tobytes(), "FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co))
+        assert lvl_gpu[l].tobytes() == o.level_keypoints(l).tobytes(), "quad-tree/orientation level %d" % l
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_golden_fixtures(case):
+    c = load_case(case)
+    rows, cols = c["image"].shape
+    ex = X.ORBextractor(c["nfeatures"], 1.2, 8, 20, 7, max_width=cols, max_height=rows)
+    mono, k, d, lvl = ex(c["image"], None, c["lapping"])
+    assert_same_result((mono, k, d), (c["mono_index"], c["keypoints"], c["descriptors"]), case)
+    assert [len(x) for x in lvl] == c["level_counts"].tolist()
+    assert [len(ex.debug_candidates(l)) for l in range(8)] == c["candidate_counts"].tolist()
+
+
+@pytest.mark.parametrize("variant", ["noise", "textured", "sparse"])
+@pytest.mark.parametrize("shape,nf", [((480, 640), 1000), ((512, 512), 1000), ((333, 517), 700)])
+def test_synthetic_stagewise(variant, shape, nf):
+    rows, cols = shape
+    img = synth.frames(variant, 11, 1, rows, cols)[0]
+    o, want = oracle_run(img, nf)
+    ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, "%s %s" % (variant, shape))
+
+
+def test_full_hd_2000_features():
+    # BASELINE.json configs[2]: two quad-tree roots per level, 6342 cell slots
+    img = synth.frames("textured", 2, 1, 1080, 1920)[0]
+    o, want = oracle_run(img, 2000)
+    ex = X.ORBextractor(2000, 1.2, 8, 20, 7, max_width=1920, max_height=1080)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, "1080p")
+    assert mono > 0      # x > 1000 is outside the mono lapping window {0,1000}: both branches of :1147-1156 taken
+
+
+def test_adversarial_images():
+    rows, cols = 300, 400
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    imgs = {
+        "constant": np.full((rows, cols), 128, np.uint8),
+        "black": np.zeros((rows, cols), np.uint8),
+        "white": np.full((rows, cols), 255, np.uint8),
+        "checker8": (((yy // 8 + xx // 8) % 2) * 255).astype(np.uint8),      # tie-heavy: equal scores everywhere
+        "checker1": (((yy + xx) % 2) * 255).astype(np.uint8),
+        "saturated_noise": np.where(synth.noise_frame(5, rows, cols) > 127, 255, 0).astype(np.uint8),
+        "ramp": ((xx * 255) // (cols - 1)).astype(np.uint8),
+        "dots": np.where((yy % 23 == 0) & (xx % 29 == 0), 255, 40).astype(np.uint8),
+    }
+    ex = X.ORBextractor(500, 1.2, 8, 20, 7, max_width=cols, max_height=rows)
+    for name, img in imgs.items():
+        o, want = oracle_run(img, 500)
+        mono, k, d, lvl = ex(img)
+        check_stages(ex, o, lvl)
+        assert_same_result((mono, k, d), want, name)
+
+
+@pytest.mark.parametrize("lap", [(0, 0), (0, 1000), (100, 300), (250, 250), (-5, 5000)])
+def test_lapping_area_split(lap):
+    img = load_gray("robot_865_gray.png")
+    o, want = oracle_run(img, 1200, lap)
+    ex = X.ORBextractor(1200, 1.2, 8, 20, 7)
+    mono, k, d, _ = ex(img, None, lap)
+    assert_same_result((mono, k, d), want, "lap %s" % (lap,))
+
+
+@pytest.mark.parametrize("params", [dict(nf=300, nlevels=4, sf=1.5, ini=30, mn=10), dict(nf=2000, nlevels=8, sf=1.2, ini=12, mn=3),
+                                    dict(nf=150, nlevels=1, sf=1.2, ini=20, mn=7), dict(nf=800, nlevels=12, sf=1.1, ini=20, mn=7)])
+def test_other_constructor_parameters(params):
+    img = load_gray("luna_gray.png")
+    o, want = oracle_run(img, params["nf"], (0, 1000), params["nlevels"], params["sf"], params["ini"], params["mn"])
+    ex = X.ORBextractor(params["nf"], params["sf"], params["nlevels"], params["ini"], params["mn"], max_width=512, max_height=512)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl, params["nlevels"])
+    assert_same_result((mono, k, d), want, str(params))
+
+
+def test_batch_equals_single_frames_and_stereo_pair():
+    # BASELINE.json configs[3]: L+R in one launch sequence, 1200 features per eye, lapping {0,0} (Frame.cc:109-110)
+    frames = synth.frames("textured", 40, 6, 480, 640)
+    ex = X.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=6)
+    out = ex.extract_batch(frames, lapping=(0, 0))
+    for f in range(6):
+        o, want = oracle_run(frames[f], 1200, (0, 0))
+        assert_same_result(out[f][:3], want, "frame %d" % f)
+        for l in range(8):
+            assert out[f][3][l].tobytes() == o.level_keypoints(l).tobytes()
+    pair = ex.extract_batch(frames[2:4], lapping=[(0, 0), (0, 1000)])      # per-frame lapping areas
+    assert_same_result(pair[0][:3], oracle_run(frames[2], 1200, (0, 0))[1])
+    assert_same_result(pair[1][:3], oracle_run(frames[3], 1200, (0, 1000))[1])
+    # pyramids of both eyes stay readable afterwards (Frame::ComputeStereoMatches reads them: Frame.cc:910,929)
+    o, _ = oracle_run(frames[3], 1200)
+    assert np.array_equal(ex.image_pyramid_level(3, frame=1), o.level(3))
+
+
+def test_row_stride_and_submatrix_input():
+    big = synth.frames("noise", 1, 1, 500, 700)[0]
+    view = big[10:490, 30:670]                      # 480 x 640 window with a 700-byte row step (cv::Mat::step)
+    assert view.strides == (700, 1)
+    o, want = oracle_run(np.ascontiguousarray(view))
+    ex = X.ORBextractor(1000)
+    assert_same_result(ex(view)[:3], want, "strided")
+
+
+def test_size_changes_between_calls():
+    ex = X.ORBextractor(600, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    for shape in [(480, 640), (300, 400), (480, 640), (241, 333)]:
+        img = synth.frames("textured", shape[0], 1, *shape)[0]
+        assert_same_result(ex(img)[:3], oracle_run(img, 600)[1], str(shape))
+
+
+def test_error_behaviour_matches_reference():
+    ex = X.ORBextractor(1000)
+    mono, k, d, lvl = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0 and d.shape == (0, 32)          # ORBextractor.cc:1083-1084
+    L = X.load_library()
+    n, m = C.c_int(), C.c_int()
+    kp = np.zeros(2000, X.KEYPOINT_DTYPE); de = np.zeros((2000, 32), np.uint8)
+    img = synth.frames("noise", 0, 1, 480, 640)[0]
+    args = lambda im, rows, cols, cap: (ex._h, im.ctypes.data_as(C.c_void_p), rows, cols, cols, 0, 1000,
+                                         kp.ctypes.data_as(C.c_void_p), de.ctypes.data_as(C.c_void_p), cap,
+                                         C.byref(n), C.byref(m), None, None)
+    assert L.orbx_extract(ex._h, None, 480, 640, 640, 0, 1000, kp.ctypes.data_as(C.c_void_p),
+                          de.ctypes.data_as(C.c_void_p), 2000, C.byref(n), C.byref(m), None, None) == -1
+    assert L.orbx_extract(*args(img, 480, 640, 100)) == -3 and n.value > 100       # capacity too small, count reported
+    small = np.zeros((120, 160), np.uint8)
+    assert L.orbx_extract(*args(small, 120, 160, 2000)) == -5                       # reference would divide by zero
+    with pytest.raises(X.OrbxError):
+        ex(synth.frames("noise", 0, 1, 600, 800)[0])                                # larger than max_width/height
+    with pytest.raises(ValueError):
+        ex(np.zeros((480, 640), np.float32))                                        # assert(type==CV_8UC1) :1087
+    assert_same_result(ex(img)[:3], oracle_run(img)[1], "after errors")              # handle still usable
+
+
+def test_device_resident_path_with_torch_tensors():
+    import torch
+    B, rows, cols = 4, 480, 640
+    frames = synth.frames("noise", 100, B, rows, cols)
+    ex = X.ORBextractor(1000, max_batch=B)
+    cap = ex.capacity
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_m = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img, B, rows, cols, d_k, d_d, d_n, d_m, cap)
+    torch.cuda.synchronize()
+    n, m = d_n.cpu().numpy(), d_m.cpu().numpy()
+    kraw = d_k.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    for f in range(B):
+        k = kraw[f, :n[f]].copy().view(X.KEYPOINT_DTYPE).reshape(-1)
+        assert_same_result((int(m[f]), k, d_d[f, :n[f]].cpu().numpy()), oracle_run(frames[f])[1], "device frame %d" % f)

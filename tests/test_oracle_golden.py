@@ -1,0 +1,41 @@
+"""The oracle against the committed golden vectors (tests/golden/*.npz, made by tools/make_golden.py from the
+reference's own demo images).  These fixtures are oracle outputs — the reference has none — so this guards the
+oracle against drift; the GPU suite compares the HIP path with the same files.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import GOLDEN_CASES, assert_same_result, load_case
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_oracle_reproduces_golden(case):
+    c = load_case(case)
+    o = O.Oracle(c["nfeatures"], 1.2, 8, 20, 7)
+    got = o.extract(c["image"], c["lapping"])
+    assert_same_result(got, (c["mono_index"], c["keypoints"], c["descriptors"]), case)
+    assert [len(o.level_keypoints(l)) for l in range(8)] == c["level_counts"].tolist()
+    assert [len(o.candidates(l)) for l in range(8)] == c["candidate_counts"].tolist()
+
+
+def test_output_contract_on_luna():
+    c = load_case("luna_1000")
+    k, d = c["keypoints"], c["descriptors"]
+    # mono {0,1000} on a 512-wide image: every point is "lapping", so the array is filled from the back and the
+    # reference returns 0 (ORBextractor.cc:1147-1161)
+    assert c["mono_index"] == 0
+    assert (np.diff(k["octave"]) <= 0).all()                      # reversed level order
+    assert len(k) <= 1000 + 3 * 8 and d.shape == (len(k), 32)
+    assert (k["class_id"] == -1).all() and ((k["angle"] >= 0) & (k["angle"] < 360)).all()
+    sizes = {0: 31, 1: 37, 2: 44, 3: 53, 4: 64, 5: 77, 6: 92, 7: 111}
+    assert all(sizes[int(o)] == s for o, s in zip(k["octave"], k["size"]))
+    c2 = load_case("luna_1000_lap00")
+    # lapping {0,0}: nothing laps, so the same points come out front-to-back
+    assert c2["mono_index"] == len(k)
+    assert c2["keypoints"][::-1].tobytes() == k.tobytes() and np.array_equal(c2["descriptors"][::-1], d)
+
+
+def test_empty_image_returns_minus_one():
+    o = O.Oracle(1000)
+    mono, k, d = o.extract(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0
