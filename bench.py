@@ -52,7 +52,7 @@ def main():
     import torch
     import torch.distributed as dist
     import extractorb_amd as X
-    from extractorb_amd import synth
+    from extractorb_amd import sharding, synth
 
     wl = dict(WORKLOADS[args.workload])
     B = args.batch or wl["batch"]
@@ -80,11 +80,9 @@ def main():
     ex.set_stream(stream.cuda_stream)
     cap = ex.capacity
     # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
-    off_k, off_d = 0, B * cap * 28
-    off_n = off_d + B * cap * 32
-    off_m = off_n + 4 * B
-    slab_bytes = (off_m + 4 * B + 255) // 256 * 256
-    slab = torch.zeros(slab_bytes, dtype=torch.uint8, device="cuda")
+    lay = sharding.slab_layout(B, cap)
+    off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
+    slab = torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda")
     base = slab.data_ptr()
     gathered = None
     if distributed and not args.no_gather and rank == 0:

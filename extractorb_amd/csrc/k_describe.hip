@@ -1,0 +1,201 @@
+// k_describe.hip — IC_Angle orientation, rotated BRIEF and final placement
+// (reference ORBextractor.cc:75-145, 1137-1158).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbx_device.hpp"
+
+namespace orbx {
+// ================================================================================================
+// IC_Angle + rotated BRIEF + final placement.  One wave64 per kept keypoint.
+// ================================================================================================
+__constant__ int8_t c_pattern[1024] = {
+#include "orbx_brief_pattern.inc"
+};
+__constant__ int c_umax[16];
+
+// cv::fastAtan2: every operation rounded separately in binary32.
+__device__ __forceinline__ float fastAtan2Deg(float y, float x) {
+    const float sc = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc,
+                p7 = -0.04432655554792128f * sc;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// sinf/cosf as glibc >= 2.28 evaluates them for 0 <= y < 120: double-precision minimax polynomials after
+// a quadrant reduction (constants of the published algorithm; tests compare the CPU twin of this routine
+// with the host libm over every float in [0, 2*pi]).  Doubles, no contraction.
+__device__ __forceinline__ void sincosGlibc(float y, float* s_out, float* c_out) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    double x = (double)y;
+    const unsigned top12 = (__float_as_uint(y) >> 20) & 0x7ff;
+    int n = 0;
+    if (top12 < 0x3f4) {
+        if (top12 < 0x398) { *s_out = y; *c_out = 1.0f; return; }
+    } else {
+        const double r = __dmul_rn(x, hpi_inv);
+        n = ((int)r + 0x800000) >> 24;
+        x = __dsub_rn(x, __dmul_rn((double)n, hpi));
+    }
+    const double x2 = __dmul_rn(x, x);
+    auto polySin = [&](double xx) {
+        const double x3 = __dmul_rn(xx, x2), s1 = __dadd_rn(S2, __dmul_rn(x2, S3)), x7 = __dmul_rn(x3, x2),
+                     s = __dadd_rn(xx, __dmul_rn(x3, S1));
+        return __dadd_rn(s, __dmul_rn(x7, s1));
+    };
+    auto polyCos = [&](double sg) {
+        const double x4 = __dmul_rn(x2, x2), c2 = __dadd_rn(sg * C3, __dmul_rn(x2, sg * C4)),
+                     c1 = __dadd_rn(sg * C0, __dmul_rn(x2, sg * C1)), x6 = __dmul_rn(x4, x2),
+                     c = __dadd_rn(c1, __dmul_rn(x4, sg * C2));
+        return __dadd_rn(c, __dmul_rn(x6, c2));
+    };
+    {
+        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[n & 3]
+        *s_out = (n & 1) ? (float)polyCos((n & 2) ? -1.0 : 1.0) : (float)polySin(x * sgn);
+    }
+    {
+        const int m = n + 1;
+        const double sgn = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+        *c_out = (m & 1) ? (float)polyCos((m & 2) ? -1.0 : 1.0) : (float)polySin(x * sgn);
+    }
+}
+
+constexpr int kDescWaves = 4;
+
+__global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels,
+                                                   const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                   const uint2* __restrict__ sel, int selPerFrame,
+                                                   const int* __restrict__ levelCount, const int* __restrict__ levelLap,
+                                                   Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
+                                                   int* __restrict__ nOut, int* __restrict__ monoOut,
+                                                   Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * kDescWaves + wave, f = blockIdx.y;
+    if (slot >= selPerFrame) return;
+    // totals of this frame
+    int total = 0, totalLap = 0, level = 0, seqBase = 0, lapBase = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int c = levelCount[f * nlevels + l], lp = levelLap[f * nlevels + l];
+        if (slot >= lv[l].selOff) { level = l; seqBase = total; lapBase = totalLap; }
+        total += c;
+        totalLap += lp;
+    }
+    if (slot == 0 && lane == 0) {
+        nOut[f] = total;
+        monoOut[f] = total - totalLap;   // monoIndex after the loop (:1161)
+    }
+    if (slot == 0 && outLevelCounts && lane < nlevels) outLevelCounts[f * nlevels + lane] = levelCount[f * nlevels + lane];
+    const LevelGeom g = lv[level];
+    const int i = slot - g.selOff;
+    if (i >= levelCount[f * nlevels + level]) return;
+    const uint2 e = sel[(long long)f * selPerFrame + slot];
+    int kx = e.x & 0xfff, ky = (e.x >> 12) & 0xfff;
+    const float response = (float)(e.x >> 24);
+    // the quad-tree only emits points of the FAST rectangle; clamp anyway so a corrupted entry can never
+    // turn into an out-of-bounds gather
+    kx = min(max(kx, kEdge), g.w - kEdge - 1);
+    ky = min(max(ky, kEdge), g.h - kEdge - 1);
+
+    // ---- IC_Angle (:75-102): integer moments over the radius-15 disc of the unblurred level ----
+    const uint8_t* center = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + ky) * g.pyrStride + kPadL + kx;
+    int m10 = 0, m01 = 0;
+    {
+        const int col = lane & 31, u = col - kHalfPatch, half = lane >> 5;
+        if (col <= 2 * kHalfPatch) {
+            const int au = u < 0 ? -u : u;
+            // half 0: rows v = 0..15, half 1: rows v = -1..-15
+            for (int a = half; a <= kHalfPatch; a++) {
+                if (au <= c_umax[a]) {
+                    const int v = half ? -a : a;
+                    const int val = center[(long long)v * g.pyrStride + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = fastAtan2Deg((float)m01, (float)m10);
+
+    // ---- computeOrbDescriptor (:106-145) on the blurred level ----
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);   // (float)(CV_PI/180.f)
+    float a, b;
+    sincosGlibc(__fmul_rn(angle, factorPI), &b, &a);
+    const uint8_t* bc = blur + g.blurOff + (long long)f * g.blurFrameBytes + (long long)ky * g.blurStride + kx;
+    unsigned long long word[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = lane + 64 * j;   // test pair index; bit (p & 7) of descriptor byte (p >> 3)
+        const float x0 = (float)c_pattern[4 * p], y0 = (float)c_pattern[4 * p + 1];
+        const float x1 = (float)c_pattern[4 * p + 2], y1 = (float)c_pattern[4 * p + 3];
+        const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int q0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int q1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bc[(long long)r0 * g.blurStride + q0], t1 = bc[(long long)r1 * g.blurStride + q1];
+        word[j] = __ballot(t0 < t1);
+    }
+
+    // ---- placement (:1137-1158): non-lapping keys fill from the front, lapping keys from the back ----
+    const int lapRank = (int)(e.y & 0x7fffffff), isLap = (int)(e.y >> 31);
+    const int lapBefore = lapBase + lapRank;
+    const int monoBefore = (seqBase - lapBase) + (i - lapRank);
+    const int at = isLap ? total - 1 - lapBefore : monoBefore;
+    float ox = (float)kx, oy = (float)ky;
+    if (level != 0) { ox = __fmul_rn(ox, g.scale); oy = __fmul_rn(oy, g.scale); }
+    if (at < capacity) {
+        if (lane == 0) {
+            Keypoint k;
+            k.x = ox; k.y = oy; k.size = (float)g.patchSize; k.angle = angle; k.response = response;
+            k.octave = level; k.class_id = -1;
+            outK[(long long)f * capacity + at] = k;
+        }
+        if (lane < 4) {
+            unsigned long long w = word[0];
+            w = lane == 1 ? word[1] : w;
+            w = lane == 2 ? word[2] : w;
+            w = lane == 3 ? word[3] : w;
+            ((unsigned long long*)(outD + ((long long)f * capacity + at) * 32))[lane] = w;
+        }
+    }
+    if (outLevelK && lane == 0 && seqBase + i < capacity) {
+        Keypoint k;
+        k.x = (float)kx; k.y = (float)ky; k.size = (float)g.patchSize; k.angle = angle; k.response = response;
+        k.octave = level; k.class_id = -1;
+        outLevelK[(long long)f * capacity + seqBase + i] = k;
+    }
+}
+
+void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint8_t* pyr, const uint8_t* blur,
+                    const uint2* sel, int selPerFrame, const int* levelCount, const int* levelLap, Keypoint* outK,
+                    uint8_t* outD, int capacity, int* nOut, int* monoOut, Keypoint* outLevelK, int* outLevelCounts,
+                    int B) {
+    hipLaunchKernelGGL(k_describe, dim3((selPerFrame + kDescWaves - 1) / kDescWaves, B), dim3(256), 0, st, lv, nlevels,
+                       pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
+                       outLevelCounts);
+}
+hipError_t uploadUmax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }
+
+
+}  // namespace orbx

@@ -13,19 +13,19 @@
 #include "orbx_geometry.hpp"
 
 namespace orbx {
-// launch wrappers, defined in orbx_kernels.hip
+// launch wrappers, defined in the k_*.hip files
 void launchLevel0(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, uint8_t*, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX*, const ResizeX*, uint8_t*, int);
 void launchBlur(hipStream_t, const BlurTile*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
-void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, uint2*, unsigned*,
-                int, int, int);
+void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
+                unsigned*, int, int, int);
 size_t octreeLdsBytes(int M, int P);
-void launchOctree(hipStream_t, const LevelGeom*, int, const uint2*, const unsigned*, unsigned short*, uint2*, int, int*,
-                  int*, const int*, int, int, int);
+void launchOctree(hipStream_t, const LevelGeom*, int, const unsigned*, const unsigned*, const unsigned*, unsigned short*,
+                  uint2*, int, int*, int*, const int*, int, int, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
-void launchUnpackCandidates(hipStream_t, const uint2*, int, Keypoint*);
+void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
 }  // namespace orbx
 
 using namespace orbx;
@@ -56,7 +56,7 @@ struct orbx_handle {
     // arenas (sized once)
     size_t pyrBytes = 0, blurBytes = 0, candEntries = 0, selEntries = 0, cellCap = 0, rxCap = 0, tileCap = 0;
     uint8_t *d_input = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
-    uint2* d_cand = nullptr;
+    unsigned *d_candPos = nullptr, *d_candOrd = nullptr;   // packed (x,y,response) / reference list-order word
     unsigned short* d_nodeOf = nullptr;
     unsigned* d_candCount = nullptr;
     uint2* d_sel = nullptr;
@@ -106,7 +106,7 @@ int fail(orbx_handle* h, int code, const std::string& msg) {
 int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
-    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_cand, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
+    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candOrd, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_tiles, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -214,12 +214,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nTiles, h->d_lv, h->d_pyr, h->d_blur, B); }
     {
         Prof p(h, S_FAST);
-        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_cand,
-                   h->d_candCount, g.maxRoiW, g.maxRoiH, B);
+        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candPos,
+                   h->d_candOrd, h->d_candCount, g.maxRoiW, g.maxRoiH, B);
     }
     {
         Prof p(h, S_OCTREE);
-        launchOctree(st, h->d_lv, g.nlevels, h->d_cand, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
+        launchOctree(st, h->d_lv, g.nlevels, h->d_candPos, h->d_candOrd, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                      h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, B);
     }
     {
@@ -348,7 +348,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_input, (size_t)max_width * max_height * max_batch));
     CREATE_TRY(hipMalloc(&h->d_pyr, h->pyrBytes));
     CREATE_TRY(hipMalloc(&h->d_blur, h->blurBytes));
-    CREATE_TRY(hipMalloc(&h->d_cand, h->candEntries * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(&h->d_candPos, h->candEntries * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc(&h->d_candOrd, h->candEntries * sizeof(unsigned)));
     CREATE_TRY(hipMalloc(&h->d_nodeOf, h->candEntries * sizeof(unsigned short)));
     CREATE_TRY(hipMalloc(&h->d_candCount, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_sel, h->selEntries * sizeof(uint2)));
@@ -529,7 +530,7 @@ int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoin
     if (n == 0) return ORBX_OK;
     Keypoint* tmp = nullptr;
     HIP_TRY(h, hipMalloc(&tmp, sizeof(Keypoint) * n));
-    launchUnpackCandidates(h->stream, h->d_cand + L.candOff + (long long)frame * L.candCap, n, tmp);
+    launchUnpackCandidates(h->stream, h->d_candPos + L.candOff + (long long)frame * L.candCap, n, tmp);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, sizeof(Keypoint) * n, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);

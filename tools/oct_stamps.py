@@ -1,0 +1,25 @@
+"""Diagnostic: where one level-0 quad-tree workgroup spends its time (needs a -DORBX_OCT_STAMPS build)."""
+import ctypes as C, sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import extractorb_amd.orbextractor as M
+M._LIB = sys.argv[1]
+import extractorb_amd as X
+from extractorb_amd import synth
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+fr = synth.frames("noise", 0, B, 480, 640)
+ex = X.ORBextractor(1000, max_batch=B)
+for _ in range(3):
+    ex.extract_batch(fr)
+L = X.load_library()
+buf = np.zeros(128, np.uint64)
+L.orbx_debug_oct_stamps(buf.ctypes.data_as(C.c_void_p))
+n = int(buf[0])
+names = {0: "start", 1: "roots+sweep0", 2: "node-level(ph1)", 3: "node-level(ph2)", 4: "build+zero", 5: "sweep", 6: "final"}
+prev = None
+for i in range(n):
+    t, sid = int(buf[1 + i]) >> 8, int(buf[1 + i]) & 0xff
+    if prev is not None:
+        print("%-18s %8.2f us" % (names[sid], (t - prev) / 100.0))   # s_memrealtime ticks at 100 MHz
+    prev = t
