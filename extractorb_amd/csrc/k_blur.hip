@@ -1,59 +1,86 @@
 // k_blur.hip — 7x7 sigma-2 integer Gaussian of every pyramid level (reference ORBextractor.cc:1126-1127).
+//
+// Arithmetic: taps {18,34,49,55,49,34,18} per axis, row sums first (<= 257*255 = 65535),
+// then (column sum + 2^15) >> 16, saturated to 255.  The bordered pyramid already holds the
+// BORDER_REFLECT_101 frame of the level (19 px >= the 3 px the blur reaches over the edge), so the
+// kernel never special-cases an image edge.
+//
+// HBM-bound design: a lane owns 4 adjacent output columns and walks down a block of 32 rows, keeping the
+// last seven rows of horizontal sums in registers.  Per row it reads three aligned dwords (12 pixels, two of
+// the three served by L1), forms the four horizontal sums with v_alignbyte + v_dot4_u32_u8 (2 dot products
+// per sum), the four vertical sums with 24-bit mads, and stores one dword: no LDS, every HBM byte of the
+// level is read once (plus the 6-row halo per block) and every blurred byte is written once, coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "orbx_device.hpp"
 
 namespace orbx {
-// ================================================================================================
-// Gaussian blur 7x7, sigma 2: integer taps {18,34,49,55,49,34,18} per axis, (sum + 2^15) >> 16, saturate
-// (SURVEY.md A.2).  The bordered pyramid already holds the REFLECT_101 frame the blur needs.
-// One workgroup = one 64x32 output tile; tiles of all levels are enumerated by a table.
-// ================================================================================================
-constexpr int kBlurTW = 64, kBlurTH = 32;
 
-__global__ __launch_bounds__(256) void k_blur(const BlurTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
+constexpr int kBlurRows = 32;   // output rows per lane
+
+__device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
+    // lo = pixels x-3..x, hi = pixels x+1..x+4 (the last one weighted 0)
+    const unsigned KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
+    return __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
+}
+
+// items: one per (level, row block); lanes of the whole grid.x enumerate (item, column group) pairs.
+__global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items, int nLanes, const LevelGeom* __restrict__ lv,
                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t in[kBlurTH + 6][kBlurTW + 8];       // 38 x 72
-    __shared__ uint16_t hs[kBlurTH + 6][kBlurTW];          // row sums <= 257*255 = 65535
-    const BlurTile t = tiles[blockIdx.x];
-    const LevelGeom g = lv[t.level];
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int x0 = t.tx * kBlurTW, y0 = t.ty * kBlurTH;
-    const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)kEdge * g.pyrStride + kPadL;
-    // the bordered buffer has 19 valid pixels on each side of the interior; clamp reads to it
-    const int xLo = -kEdge, xHi = g.w + kEdge - 1, yLo = -kEdge, yHi = g.h + kEdge - 1;
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
-        int gx = x0 + c - 3, gy = y0 + r - 3;
-        gx = gx < xLo ? xLo : (gx > xHi ? xHi : gx);
-        gy = gy < yLo ? yLo : (gy > yHi ? yHi : gy);
-        in[r][c] = sp[(long long)gy * g.pyrStride + gx];
+    const int gl = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (gl >= nLanes) return;
+    // binary search the item whose lane range holds gl (items are sorted by firstLane; <= ~200 of them)
+    int lo = 0, hi = (int)items[0].count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].firstLane <= gl) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &in[r][c];
-        const int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        hs[r][c] = (uint16_t)s;
-    }
-    __syncthreads();
-    uint8_t* dp = blur + g.blurOff + (long long)f * g.blurFrameBytes;
-    for (int i = tid; i < kBlurTH * kBlurTW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int gx = x0 + c, gy = y0 + r;
-        if (gx >= g.w || gy >= g.h) continue;
-        const int s = 18 * (hs[r][c] + hs[r + 6][c]) + 34 * (hs[r + 1][c] + hs[r + 5][c]) +
-                      49 * (hs[r + 2][c] + hs[r + 4][c]) + 55 * hs[r + 3][c];
-        int v = (s + 32768) >> 16;
-        v = v > 255 ? 255 : v;
-        dp[(long long)gy * g.blurStride + gx] = (uint8_t)v;
+    const BlurItem it = items[lo];
+    const LevelGeom g = lv[it.level];
+    const int grp = gl - it.firstLane;          // column group inside the row block
+    const int x0 = 4 * grp, y0 = it.y0;
+    // dword containing pixels x0-4..x0-1 of row y0-3 (kPadL keeps x0 dword-aligned)
+    const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + y0 - 3) * g.pyrStride + kPadL + x0 - 4;
+    uint8_t* dp = blur + g.blurOff + (long long)f * g.blurFrameBytes + (long long)y0 * g.blurStride + x0;
+    const int rowsValid = min(kBlurRows, g.h - y0);     // output rows this block really owns
+    const int lastIn = g.h + kEdge - 1 - (y0 - 3);      // input rows below the bordered buffer are clamped (their outputs are not stored)
+
+    unsigned h[7][4] = {};
+#pragma unroll
+    for (int i = 0; i < kBlurRows + 6; i++) {
+        const int r = i < lastIn ? i : lastIn;
+        const unsigned* row = (const unsigned*)(sp + (long long)r * g.pyrStride);
+        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
+        unsigned hn[4];
+        hn[0] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1));
+        hn[1] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2));
+        hn[2] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3));
+        hn[3] = hsum4(d1, d2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int t = 0; t < 6; t++) h[t][j] = h[t + 1][j];
+            h[6][j] = hn[j];
+        }
+        if (i >= 6) {
+            unsigned outw = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned s = 18u * (h[0][j] + h[6][j]) + 34u * (h[1][j] + h[5][j]) + 49u * (h[2][j] + h[4][j]) + 55u * h[3][j];
+                unsigned v = (s + 32768u) >> 16;
+                v = v > 255u ? 255u : v;
+                outw |= v << (8 * j);
+            }
+            const int orow = i - 6;
+            if (orow < rowsValid) *(unsigned*)(dp + (long long)orow * g.blurStride) = outw;
+        }
     }
 }
 
-void launchBlur(hipStream_t st, const BlurTile* tiles, int nTiles, const LevelGeom* lv, const uint8_t* pyr,
-                uint8_t* blur, int B) {
-    hipLaunchKernelGGL(k_blur, dim3(nTiles, B), dim3(256), 0, st, tiles, lv, pyr, blur);
+void launchBlur(hipStream_t st, const BlurItem* items, int nLanes, const LevelGeom* lv, const uint8_t* pyr, uint8_t* blur,
+                int B) {
+    hipLaunchKernelGGL(k_blur, dim3((nLanes + 255) / 256, B), dim3(256), 0, st, items, nLanes, lv, pyr, blur);
 }
 
 }  // namespace orbx

@@ -16,7 +16,7 @@ namespace orbx {
 // launch wrappers, defined in the k_*.hip files
 void launchLevel0(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, uint8_t*, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX*, const ResizeX*, uint8_t*, int);
-void launchBlur(hipStream_t, const BlurTile*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
+void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 unsigned*, int, int, int);
 size_t octreeLdsBytes(int M, int P);
@@ -64,8 +64,8 @@ struct orbx_handle {
     LevelGeom* d_lv = nullptr;
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
-    BlurTile* d_tiles = nullptr;
-    int nTiles = 0;
+    BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel
+    int nBlurLanes = 0;
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     int octM = 0, octP = 0;
     // outputs of the host path
@@ -140,13 +140,17 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
         xo += g.rx[l].size(); yo += g.ry[l].size();
     }
-    std::vector<BlurTile> tiles;
+    std::vector<BlurItem> tiles;
+    int lanes = 0;
     for (int l = 0; l < g.nlevels; l++)
-        for (int ty = 0; ty < (g.lv[l].h + 31) / 32; ty++)
-            for (int tx = 0; tx < (g.lv[l].w + 63) / 64; tx++) tiles.push_back(BlurTile{(short)l, (short)tx, (short)ty, 0});
-    if (tiles.size() > h->tileCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur tile table does not fit");
-    HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurTile) * tiles.size(), hipMemcpyHostToDevice));
-    h->nTiles = (int)tiles.size();
+        for (int y0 = 0; y0 < g.lv[l].h; y0 += 32) {
+            tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
+            lanes += (g.lv[l].w + 3) / 4;
+        }
+    tiles[0].count = (int)tiles.size();
+    if (tiles.size() > h->tileCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
+    HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
+    h->nBlurLanes = lanes;
     h->geom = g;
     return ORBX_OK;
 }
@@ -211,7 +215,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         Prof p(h, S_RESIZE);
         launchResize(st, g.lv[l - 1], g.lv[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l], h->d_pyr, B);
     }
-    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nTiles, h->d_lv, h->d_pyr, h->d_blur, B); }
+    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     {
         Prof p(h, S_FAST);
         launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candPos,
@@ -360,7 +364,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * h->cellCap));
     CREATE_TRY(hipMalloc(&h->d_rx, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
-    CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurTile) * h->tileCap));
+    CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurItem) * h->tileCap));
     const size_t oc = (size_t)h->outCap * max_batch;
     CREATE_TRY(hipMalloc(&h->d_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipMalloc(&h->d_outLevelK, oc * sizeof(Keypoint)));

@@ -19,7 +19,9 @@ struct Keypoint {             // == orbx_keypoint == cv::KeyPoint (28 bytes)
 };
 static_assert(sizeof(Keypoint) == 28, "cv::KeyPoint layout");
 
-struct BlurTile { short level, tx, ty, pad; };   // one 64x32 output tile of the blur kernel
+// One 32-row block of one level for the blur kernel: lanes [firstLane, firstLane + ceil(w/4)) own its 4-column groups.
+// items[0].count holds the number of items.
+struct BlurItem { int firstLane; int count; short level; short y0; };
 
 // ---- per-level geometry, shared verbatim with the device (plain ints/floats) -------------------
 struct LevelGeom {
