@@ -1,113 +1,165 @@
 // k_fast.hip — per-cell FAST-9/16 detection with threshold retry and NMS (reference ORBextractor.cc:797-864).
+//
+// One wave64 == one 30-px cell == one cv::FAST call of the reference (two when the first returns nothing).
+//
+// Score.  With ring pixels r_k and centre v:  S_dark = v - min_arcs(max_arc r),  S_bright = max_arcs(min_arc r) - v,
+// S = max(S_dark, S_bright, 0) over the 16 arcs of 9 contiguous ring pixels.  "corner at threshold t" <=> S > t
+// and the reference's response is S - 1, so ONE score serves iniThFAST and the minThFAST retry.
+// The arc minima/maxima use the 3-input VALU ops: m3[k] = min3(r_k, r_k+1, r_k+2), m9[k] = min3(m3[k], m3[k+3],
+// m3[k+6]) — 2 x 32 instructions for all 16 arcs of both polarities, plus 2 x 8 for the reductions.
+//
+// NMS is a strict 3x3 maximum of S with everything outside the cell interior counted as 0; a surviving centre has
+// S > t, so neighbours below t can never suppress it: NMS is threshold independent and runs once.
+//
+// LDS: each wave stages its ROI (<= 45 x 45 for the usual 31..37-px cells) as aligned dwords with every global load
+// in flight at once, then keeps the 8-bit score tile next to it.  Strides are compile-time so all 16 ring
+// offsets and the 8 NMS neighbours are instruction immediates.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "orbx_device.hpp"
 
 namespace orbx {
-// ================================================================================================
-// FAST-9/16 per cell.  One wave64 == one cell == one cv::FAST call of the reference (two when the first
-// is empty).  S(p) = max(S_dark, S_bright) with S_dark = max over the 16 arcs of min(v - ring) and
-// S_bright the mirror image; "corner at threshold t" <=> S > t and the reference's response is S-1
-// (SURVEY.md A.3), so one score serves iniThFAST and the minThFAST retry.  NMS is a strict 3x3 maximum
-// of S with everything outside the cell interior counted as 0; since a surviving centre has S > t,
-// neighbours below t can never suppress it, so NMS is threshold independent.
-// ================================================================================================
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
 
-__device__ __forceinline__ int fastScore(const uint8_t* c, int st) {
+__device__ __forceinline__ unsigned vmin3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned vmax3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int TS>
+__device__ __forceinline__ int fastScore(const uint8_t* c) {
+    // ring order of cv::FAST: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),(-3,-1),
+    // (-3,0),(-3,1),(-2,2),(-1,3)
+    unsigned r[16];
+    r[0] = c[3 * TS];       r[1] = c[3 * TS + 1];   r[2] = c[2 * TS + 2];   r[3] = c[TS + 3];
+    r[4] = c[3];            r[5] = c[-TS + 3];      r[6] = c[-2 * TS + 2];  r[7] = c[-3 * TS + 1];
+    r[8] = c[-3 * TS];      r[9] = c[-3 * TS - 1];  r[10] = c[-2 * TS - 2]; r[11] = c[-TS - 3];
+    r[12] = c[-3];          r[13] = c[TS - 3];      r[14] = c[2 * TS - 2];  r[15] = c[3 * TS - 1];
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * st];          d[1] = v - c[3 * st + 1];   d[2] = v - c[2 * st + 2];   d[3] = v - c[st + 3];
-    d[4] = v - c[3];               d[5] = v - c[-st + 3];      d[6] = v - c[-2 * st + 2];  d[7] = v - c[-3 * st + 1];
-    d[8] = v - c[-3 * st];         d[9] = v - c[-3 * st - 1];  d[10] = v - c[-2 * st - 2]; d[11] = v - c[-st - 3];
-    d[12] = v - c[-3];             d[13] = v - c[st - 3];      d[14] = v - c[2 * st - 2];  d[15] = v - c[3 * st - 1];
-    int lo3[16], hi3[16];
+    unsigned lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        lo3[k] = vmin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+        hi3[k] = vmax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
     }
-    int sDark = -256, sBrightNeg = 256;
+    unsigned lo9[16], hi9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int lo9 = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);   // min of d over the arc k..k+8
-        const int hi9 = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);   // max of d over the arc
-        sDark = max(sDark, lo9);
-        sBrightNeg = min(sBrightNeg, hi9);
+        lo9[k] = vmin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);   // min of the arc k..k+8
+        hi9[k] = vmax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);   // max of the arc
     }
-    const int s = max(sDark, -sBrightNeg);
-    return s < 0 ? 0 : s;   // <= 255
+    // brightest "darkest pixel of an arc" and darkest "brightest pixel of an arc"
+    unsigned a = vmax3(lo9[0], lo9[1], lo9[2]), b = vmax3(lo9[3], lo9[4], lo9[5]), cc = vmax3(lo9[6], lo9[7], lo9[8]),
+             d = vmax3(lo9[9], lo9[10], lo9[11]), e = vmax3(lo9[12], lo9[13], lo9[14]);
+    const unsigned maxMin = vmax3(vmax3(a, b, cc), vmax3(d, e, lo9[15]), 0u);
+    a = vmin3(hi9[0], hi9[1], hi9[2]); b = vmin3(hi9[3], hi9[4], hi9[5]); cc = vmin3(hi9[6], hi9[7], hi9[8]);
+    d = vmin3(hi9[9], hi9[10], hi9[11]); e = vmin3(hi9[12], hi9[13], hi9[14]);
+    const unsigned minMax = vmin3(vmin3(a, b, cc), vmin3(d, e, hi9[15]), 255u);
+    const int sDark = v - (int)minMax, sBright = (int)maxMin - v;
+    return max(max(sDark, sBright), 0);
 }
 
 constexpr int kFastWaves = 4;
 
-// dynamic LDS per wave: tile[tileRows*tileStride] + score[(maxCh+2)*scoreStride]
+// LDS operations of one wave execute in issue order, so lanes of a wave only need the COMPILER to keep the
+// order of the stores before and the loads after this point.
+__device__ __forceinline__ void waveLdsSync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.
+template <int TS, int ROWS>
 __global__ __launch_bounds__(256) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                unsigned* __restrict__ candPos, unsigned* __restrict__ candOrd,
-                                               unsigned* __restrict__ candCount,
-                                               int tileStride, int tileBytes, int scoreStride, int scoreBytes) {
-    extern __shared__ __align__(16) uint8_t smem[];
+                                               unsigned* __restrict__ candCount) {
+    constexpr int kTileBytes = TS * ROWS;             // pixel tile
+    constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
+    constexpr int DW = TS / 4;                        // dwords per tile row
+    constexpr int LPR = DW <= 16 ? 16 : 32;           // lanes per row while staging
+    constexpr int RPI = 64 / LPR;                     // rows per staging step
+    constexpr int STEPS = (ROWS + RPI - 1) / RPI;
+    __shared__ __align__(16) uint8_t smem[kFastWaves * (kTileBytes + kScoreBytes)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ci = blockIdx.x * kFastWaves + wave, f = blockIdx.y;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
-    uint8_t* tile = smem + wave * (tileBytes + scoreBytes);
-    uint8_t* score = tile + tileBytes;
+    uint8_t* tile = smem + wave * (kTileBytes + kScoreBytes);
+    uint8_t* score = tile + kTileBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
 
-    const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride +
-                        kPadL + c.x0;
-    for (int r = 0; r < roiH; r++) {
-        if (lane < roiW) tile[r * tileStride + lane] = sp[(long long)r * g.pyrStride + lane];
-        if (lane + 64 < roiW) tile[r * tileStride + lane + 64] = sp[(long long)r * g.pyrStride + lane + 64];
-    }
-    // zero the score tile (its 1-px apron stands for "outside the ROI interior")
-    for (int i = lane * 4; i < scoreBytes; i += 256) *(uint32_t*)(score + i) = 0;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done
-
-    const int npix = cw * ch;
-    // pass 1: scores
+    // ---- stage the ROI: row r of the tile holds the aligned dwords covering pixels [x0, x0+roiW) ----
+    const int gx0 = kPadL + c.x0;                       // byte column of the ROI's first pixel in the bordered row
+    const int mis = gx0 & 3;                            // its offset inside the first dword
+    const int nd = (mis + roiW + 3) >> 2;               // dwords per row actually needed (<= DW)
     {
-        int x = lane % cw, y = lane / cw;
-        for (int p = lane; p < npix; p += 64) {
-            const int s = fastScore(tile + (y + 3) * tileStride + x + 3, tileStride);
-            score[(y + 1) * scoreStride + x + 1] = (uint8_t)s;
-            x += 64;
-            while (x >= cw) { x -= cw; y++; }
+        const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride + (gx0 - mis);
+        const int dcol = lane & (LPR - 1), rsub = lane / LPR;
+        unsigned w[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int r = s * RPI + rsub;
+            w[s] = (dcol < nd && r < roiH) ? *(const unsigned*)(sp + (long long)r * g.pyrStride + 4 * dcol) : 0u;
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int r = s * RPI + rsub;
+            if (dcol < DW && r < ROWS) *(unsigned*)(tile + r * TS + 4 * dcol) = w[s];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // zero the score tile (its 1-px apron stands for "outside the ROI interior")
+#pragma unroll
+    for (int i = 0; i < (kScoreBytes + 255) / 256; i++)
+        if (lane * 4 + i * 256 < kScoreBytes) *(unsigned*)(score + lane * 4 + i * 256) = 0u;
+    waveLdsSync();
 
-    // pass 2: strict local maxima; lane i keeps the ballots of sweep i
+    const int npix = cw * ch;
+    const int qx = 64 % cw, qy = 64 / cw;               // how (x, y) advance when the pixel index advances by 64
+    const int x00 = lane % cw, y00 = lane / cw;
+    // ---- pass 1: scores ----
+    {
+        int x = x00, y = y00;
+        for (int p = lane; p < npix; p += 64) {
+            const int s = fastScore<TS>(tile + (y + 3) * TS + mis + x + 3);
+            score[(y + 1) * TS + x + 1] = (uint8_t)s;
+            x += qx; y += qy;
+            if (x >= cw) { x -= cw; y++; }
+        }
+    }
+    waveLdsSync();
+
+    // ---- pass 2: strict local maxima; lane i keeps the ballots of sweep i ----
     unsigned long long myIni = 0, myMin = 0;
     int nIni = 0, nMin = 0;
     {
-        int x = lane % cw, y = lane / cw, it = 0;
+        int x = x00, y = y00, it = 0;
         for (int base = 0; base < npix; base += 64, it++) {
             bool lm = false;
             int s = 0;
             if (base + lane < npix) {
-                const uint8_t* q = score + (y + 1) * scoreStride + x + 1;
+                const uint8_t* q = score + (y + 1) * TS + x + 1;
                 s = q[0];
-                lm = s > q[-1] && s > q[1] && s > q[-scoreStride - 1] && s > q[-scoreStride] &&
-                     s > q[-scoreStride + 1] && s > q[scoreStride - 1] && s > q[scoreStride] && s > q[scoreStride + 1];
+                lm = s > q[-1] && s > q[1] && s > q[-TS - 1] && s > q[-TS] && s > q[-TS + 1] && s > q[TS - 1] &&
+                     s > q[TS] && s > q[TS + 1];
             }
             const unsigned long long bIni = __ballot(lm && s > iniTh);
             const unsigned long long bMin = __ballot(lm && s > minTh);
             if (lane == it) { myIni = bIni; myMin = bMin; }
             nIni += __popcll(bIni);
             nMin += __popcll(bMin);
-            x += 64;
-            while (x >= cw) { x -= cw; y++; }
+            x += qx; y += qy;
+            if (x >= cw) { x -= cw; y++; }
         }
     }
     // the reference retries the cell at minThFAST only when the first call returned nothing (:835-838)
@@ -121,13 +173,13 @@ __global__ __launch_bounds__(256) void k_fast(const CellDesc* __restrict__ cells
     unsigned* outPos = candPos + g.candOff + (long long)f * g.candCap;
     unsigned* outOrd = candOrd + g.candOff + (long long)f * g.candCap;
     {
-        int x = lane % cw, y = lane / cw, it = 0;
+        int x = x00, y = y00, it = 0;
         for (int b0 = 0; b0 < npix; b0 += 64, it++) {
             const unsigned lo = __builtin_amdgcn_readlane((unsigned)mine, it);
             const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), it);
             const unsigned long long m = ((unsigned long long)hi << 32) | lo;
             if ((m >> lane) & 1) {
-                const int s = score[(y + 1) * scoreStride + x + 1];
+                const int s = score[(y + 1) * TS + x + 1];
                 const unsigned before = __popcll(m & ((1ull << lane) - 1));
                 const unsigned px = (unsigned)(c.shiftX + x + 3), py = (unsigned)(c.shiftY + y + 3);
                 const unsigned at = base + before;
@@ -137,27 +189,23 @@ __global__ __launch_bounds__(256) void k_fast(const CellDesc* __restrict__ cells
                 }
             }
             base += __popcll(m);
-            x += 64;
-            while (x >= cw) { x -= cw; y++; }
+            x += qx; y += qy;
+            if (x >= cw) { x -= cw; y++; }
         }
     }
 }
 
-void fastLdsLayout(int maxRoiW, int maxRoiH, int* tileStride, int* tileBytes, int* scoreStride, int* scoreBytes) {
-    *tileStride = (maxRoiW + 3) / 4 * 4 + 4;
-    *tileBytes = (*tileStride * maxRoiH + 15) / 16 * 16;
-    *scoreStride = (maxRoiW - 6 + 2 + 3) / 4 * 4 + 4;
-    *scoreBytes = (*scoreStride * (maxRoiH - 6 + 2) + 15) / 16 * 16;
-}
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candPos, unsigned* candOrd, unsigned* candCount,
                 int maxRoiW, int maxRoiH, int B) {
-    int ts, tb, ss, sb;
-    fastLdsLayout(maxRoiW, maxRoiH, &ts, &tb, &ss, &sb);
-    const size_t lds = (size_t)kFastWaves * (tb + sb);
-    hipLaunchKernelGGL(k_fast, dim3((nCells + kFastWaves - 1) / kFastWaves, B), dim3(256), lds, st, cells, nCells, lv,
-                       nlevels, pyr, iniTh, minTh, candPos, candOrd, candCount, ts, tb, ss, sb);
+    const dim3 grid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
+    // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
+    if (maxRoiW <= 45 && maxRoiH <= 45)
+        hipLaunchKernelGGL((k_fast<48, 45>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candPos, candOrd, candCount);
+    else   // cells up to 63 px (the geometry code rejects larger ones)
+        hipLaunchKernelGGL((k_fast<72, 69>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candPos, candOrd, candCount);
 }
+
 // unpack one level's candidates into reference KeyPoints (introspection for tests)
 __global__ void k_unpackCandidates(const unsigned* __restrict__ keys, int n, Keypoint* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -172,6 +220,5 @@ void launchUnpackCandidates(hipStream_t st, const unsigned* keys, int n, Keypoin
     if (n <= 0) return;
     hipLaunchKernelGGL(k_unpackCandidates, dim3((n + 255) / 256), dim3(256), 0, st, keys, n, out);
 }
-
 
 }  // namespace orbx

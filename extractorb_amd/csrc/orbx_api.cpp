@@ -14,7 +14,8 @@
 
 namespace orbx {
 // launch wrappers, defined in the k_*.hip files
-void launchLevel0(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, uint8_t*, int);
+void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, const ResizeX*,
+                    const ResizeX*, uint8_t*, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX*, const ResizeX*, uint8_t*, int);
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
@@ -34,7 +35,7 @@ static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout")
 
 namespace {
 enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL };
-const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_level0", "k_resize", "k_blur", "k_fast",
+const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total"};
 thread_local std::string g_createError;
 
@@ -210,8 +211,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         Prof p(h, S_MISC);
         HIP_TRY(h, hipMemsetAsync(h->d_candCount, 0, sizeof(unsigned) * B * g.nlevels, st));
     }
-    { Prof p(h, S_LEVEL0); launchLevel0(st, d_imgs, stride, frameStride, g.lv[0], h->d_pyr, B); }
-    for (int l = 1; l < g.nlevels; l++) {
+    {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
+        Prof p(h, S_LEVEL0);
+        launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, h->d_rx + h->rxOff[1],
+                       h->d_ry + h->ryOff[1], h->d_pyr, B);
+    }
+    for (int l = 2; l < g.nlevels; l++) {
         Prof p(h, S_RESIZE);
         launchResize(st, g.lv[l - 1], g.lv[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l], h->d_pyr, B);
     }
