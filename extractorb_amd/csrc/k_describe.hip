@@ -9,7 +9,7 @@ namespace orbx {
 // ================================================================================================
 // IC_Angle + rotated BRIEF + final placement.  One wave64 per kept keypoint.
 // ================================================================================================
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "orbx_brief_pattern.inc"
 };
 __constant__ int c_umax[16];
@@ -78,6 +78,12 @@ __device__ __forceinline__ void sincosGlibc(float y, float* s_out, float* c_out)
 }
 
 constexpr int kDescWaves = 4;
+constexpr int kBriefReach = 18;                       // |rounded rotated pattern coordinate| <= 18 (max radius 18.385)
+constexpr int kRawRows = 2 * kHalfPatch + 1;          // 31
+constexpr int kRawStride = 36;                        // 3 + 31 bytes -> 9 dwords
+constexpr int kBlurRows = 2 * kBriefReach + 1;        // 37
+constexpr int kBlurStride = 40;                       // 3 + 37 bytes -> 10 dwords
+constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per wave (dword multiple)
 
 __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels,
                                                    const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                    Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
                                                    int* __restrict__ nOut, int* __restrict__ monoOut,
                                                    Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts) {
+    __shared__ __align__(16) uint8_t smem[kDescWaves * kPatchLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = blockIdx.x * kDescWaves + wave, f = blockIdx.y;
     if (slot >= selPerFrame) return;
@@ -113,18 +120,54 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     kx = min(max(kx, kEdge), g.w - kEdge - 1);
     ky = min(max(ky, kEdge), g.h - kEdge - 1);
 
+    // ---- stage both patches in LDS: every global load of the wave is an aligned dword and in flight at once ----
+    // raw level, rows/cols +-15 (IC_Angle); blurred level, rows/cols +-18 (the rotated pattern reaches radius 18.4)
+    uint8_t* rawT = smem + wave * kPatchLds;
+    uint8_t* blurT = rawT + kRawRows * kRawStride;
+    const int rawCol0 = kPadL + kx - kHalfPatch, rawMis = rawCol0 & 3;
+    const int blurCol0 = kx - kBriefReach, blurMis = blurCol0 & 3;
+    {
+        const uint8_t* rp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + ky - kHalfPatch) * g.pyrStride + (rawCol0 - rawMis);
+        const uint8_t* bp = blur + g.blurOff + (long long)f * g.blurFrameBytes + (long long)(ky - kBriefReach) * g.blurStride + (blurCol0 - blurMis);
+        constexpr int nRaw = kRawRows * (kRawStride / 4), nBlur = kBlurRows * (kBlurStride / 4);
+        constexpr int steps = (nRaw + nBlur + 63) / 64;
+        unsigned w[steps];
+#pragma unroll
+        for (int s = 0; s < steps; s++) {
+            const int i = lane + 64 * s;
+            if (i < nRaw) {
+                const int r = i / (kRawStride / 4), c = i - r * (kRawStride / 4);
+                w[s] = *(const unsigned*)(rp + (long long)r * g.pyrStride + 4 * c);
+            } else if (i < nRaw + nBlur) {
+                const int k = i - nRaw, r = k / (kBlurStride / 4), c = k - r * (kBlurStride / 4);
+                // the last dword of a row can start past the blurred row's padded end when the patch touches the right edge
+                w[s] = (blurCol0 - blurMis + 4 * c) < g.blurStride ? *(const unsigned*)(bp + (long long)r * g.blurStride + 4 * c) : 0u;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < steps; s++) {
+            const int i = lane + 64 * s;
+            if (i < nRaw + nBlur) *(unsigned*)(rawT + 4 * i) = w[s];   // the two tiles are adjacent and dword-granular
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
     // ---- IC_Angle (:75-102): integer moments over the radius-15 disc of the unblurred level ----
-    const uint8_t* center = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + ky) * g.pyrStride + kPadL + kx;
+    const uint8_t* center = rawT + kHalfPatch * kRawStride + rawMis + kHalfPatch;
     int m10 = 0, m01 = 0;
     {
         const int col = lane & 31, u = col - kHalfPatch, half = lane >> 5;
         if (col <= 2 * kHalfPatch) {
             const int au = u < 0 ? -u : u;
             // half 0: rows v = 0..15, half 1: rows v = -1..-15
-            for (int a = half; a <= kHalfPatch; a++) {
-                if (au <= c_umax[a]) {
+#pragma unroll
+            for (int a = 0; a <= kHalfPatch; a++) {
+                if (a >= half && au <= c_umax[a]) {
                     const int v = half ? -a : a;
-                    const int val = center[(long long)v * g.pyrStride + u];
+                    const int val = center[v * kRawStride + u];
                     m10 += u * val;
                     m01 += v * val;
                 }
@@ -142,18 +185,18 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.0);   // (float)(CV_PI/180.f)
     float a, b;
     sincosGlibc(__fmul_rn(angle, factorPI), &b, &a);
-    const uint8_t* bc = blur + g.blurOff + (long long)f * g.blurFrameBytes + (long long)ky * g.blurStride + kx;
+    const uint8_t* bc = blurT + kBriefReach * kBlurStride + blurMis + kBriefReach;
     unsigned long long word[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = lane + 64 * j;   // test pair index; bit (p & 7) of descriptor byte (p >> 3)
-        const float x0 = (float)c_pattern[4 * p], y0 = (float)c_pattern[4 * p + 1];
-        const float x1 = (float)c_pattern[4 * p + 2], y1 = (float)c_pattern[4 * p + 3];
+        const char4 pt = ((const char4*)c_pattern)[p];
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[(long long)r0 * g.blurStride + q0], t1 = bc[(long long)r1 * g.blurStride + q1];
+        const int t0 = bc[r0 * kBlurStride + q0], t1 = bc[r1 * kBlurStride + q1];
         word[j] = __ballot(t0 < t1);
     }
 
