@@ -102,21 +102,37 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
     }
     __syncthreads();
     unsigned out[kPyrRows];
+    if (staged) {
+        // column parts of the LDS addresses and the two 11-bit weights of each of the 4 pixels, fixed for all rows
+        // (two independent byte offsets on purpose: a merged 16-bit LDS read at an odd address is slow)
+        int co[4], c1[4], a0[4], a1[4];
 #pragma unroll
-    for (int r = 0; r < kPyrRows; r++) {
-        unsigned o = 0;
-        if (staged) {
-            const uint8_t* r0 = tile + (cy[r].sx0 - fy0) * ldsStride - fx0;
-            const uint8_t* r1 = tile + (cy[r].sx1 - fy0) * ldsStride - fx0;
+        for (int j = 0; j < 4; j++) { co[j] = cx[j].sx0 - fx0; c1[j] = cx[j].sx1 - fx0; a0[j] = cx[j].a0; a1[j] = cx[j].a1; }
 #pragma unroll
-            for (int j = 0; j < 4; j++) o |= bilinear(r0, r1, cx[j], cy[r].a0, cy[r].a1) << (8 * j);
-        } else {
+        for (int r = 0; r < kPyrRows; r++) {
+            const uint8_t* r0 = tile + (cy[r].sx0 - fy0) * ldsStride;
+            const uint8_t* r1 = tile + (cy[r].sx1 - fy0) * ldsStride;
+            const int b0 = cy[r].a0, b1 = cy[r].a1;
+            unsigned o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int h0 = __mul24(r0[co[j]], a0[j]) + __mul24(r0[c1[j]], a1[j]);
+                const int h1 = __mul24(r1[co[j]], a0[j]) + __mul24(r1[c1[j]], a1[j]);
+                const int v = ((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2;
+                o |= (unsigned)v << (8 * j);
+            }
+            out[r] = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kPyrRows; r++) {
             const uint8_t* r0 = sp + (long long)cy[r].sx0 * sv.stride;
             const uint8_t* r1 = sp + (long long)cy[r].sx1 * sv.stride;
+            unsigned o = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) o |= bilinear(r0, r1, cx[j], cy[r].a0, cy[r].a1) << (8 * j);
+            out[r] = o;
         }
-        out[r] = o;
     }
     if (valid) {
 #pragma unroll
