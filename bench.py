@@ -24,14 +24,14 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
-    "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=64, variant="noise",
+    "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=256, variant="noise",
                     desc="640x480 mono stream, 8 levels, 1000 features, synthetic noise frames"),
     # configs[2]
-    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=16, variant="noise",
+    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=32, variant="noise",
                    desc="1920x1080 mono stream, 8 levels, 2000 features, synthetic noise frames"),
     # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
-    "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=64, variant="noise",
-                      desc="stereo 640x480 L+R pairs (32 pairs per step), 8 levels, 1200 features per eye"),
+    "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="noise",
+                      desc="stereo 640x480 L+R pairs (128 pairs per step), 8 levels, 1200 features per eye"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="mono640", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: per workload)")
