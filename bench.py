@@ -62,9 +62,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
-    if world != N and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (N, world))
-    distributed = world > 1
+    if world != N:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (N, world))
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run (any world size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
     torch.cuda.set_device(local_rank)
