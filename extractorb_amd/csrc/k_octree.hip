@@ -34,9 +34,39 @@ constexpr int kOctThreads = 1024;
 constexpr int kOctWaves = kOctThreads / 64;
 constexpr int kOctUnroll = 4;   // keys per thread per sweep iteration (memory-level parallelism)
 
+// Dense phase.  DivideNode's boxes depend only on the root box, and the x and y split decisions are independent
+// of each other, so a key's quadrant path of length kD0 below its root is two table look-ups: xcode[x] (root and
+// 5 left/right decisions) and ycode[y] (5 up/down decisions), both built once per workgroup in LDS.  The first
+// sweep stores the leaf cell (root, ypath, xpath) per key and histograms the 4^kD0 leaf cells of every root;
+// summing 4:1 gives the key count of every possible node down to depth kD0.
+// While every node that may split is shallower than kD0, a refinement pass needs NO sweep over the keys: its
+// child counts are table look-ups.  The keys are visited again only to take the final arg-max (node found through
+// a leaf-cell -> node table), or — when a node at depth kD0 must split — once to materialise their node ids,
+// after which the passes continue with one rename+count sweep each.
+constexpr int kD0 = 5;
+constexpr int kLeaves = 1 << (2 * kD0);                       // 1024 leaf cells per root
+constexpr int kHistPerRoot = (4 * kLeaves - 4) / 3;           // 4 + 16 + ... + 4^kD0 = 1364 counters per root
+__device__ __forceinline__ int histOff(int depth) { return ((1 << (2 * depth)) - 4) / 3; }   // depth 1..kD0
+// node descriptor in the dense phase: root << 24 | depth << 20 | ypath << 10 | xpath  (paths hold `depth` bits)
+__device__ __forceinline__ unsigned nodeKey(int root, int depth, int yp, int xp) {
+    return ((unsigned)root << 24) | ((unsigned)depth << 20) | ((unsigned)yp << 10) | (unsigned)xp;
+}
+// left/right (or up/down) decisions of DivideNode along one axis for coordinate v in the box [b0, b1)
+__device__ __forceinline__ int axisPath(int v, int b0, int b1) {
+    int path = 0;
+#pragma unroll
+    for (int d = 0; d < kD0; d++) {
+        const int c = b0 + ((b1 - b0 + 1) >> 1);    // UL + ceil(extent/2)  (:488-489)
+        const int bit = v < c ? 0 : 1;               // kp.pt.x < n1.UR.x  (:520)
+        path = 2 * path + bit;
+        if (bit) b0 = c; else b1 = c;
+    }
+    return path;
+}
+
 struct OctShared {
     unsigned scanTmp[kOctWaves];
-    int size, prevSize, phase2, nToExpand, done, nChildren, breakRank;
+    int size, prevSize, phase2, nToExpand, done, nChildren, breakRank, deep;
 };
 
 // exclusive prefix sum of data[0..n) in place, returns the total; every thread of the workgroup calls it
@@ -100,23 +130,10 @@ __device__ __forceinline__ void countQuadrant(int* childCnt, bool active, int no
     }
 }
 
+// Per-node arg-max: a 64-bit LDS atomic per key (lanes of a wave spread over only a few nodes, but a wave-level
+// pre-reduction costs more instructions than the serialised same-address atomics it would save).
 __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active, int node, unsigned long long v) {
-    const unsigned long long act = __ballot(active);
-    if (act == 0) return;
-    const int leader = __ffsll((long long)act) - 1;
-    const int n0 = __shfl(node, leader);
-    if (__all(!active || node == n0)) {
-        unsigned long long m = active ? v : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)m, o), hi = __shfl_xor((unsigned)(m >> 32), o);
-            const unsigned long long t = ((unsigned long long)hi << 32) | lo;
-            m = t > m ? t : m;
-        }
-        if ((threadIdx.x & 63) == leader) atomicMax(&best[n0], m);
-    } else if (active) {
-        atomicMax(&best[node], v);
-    }
+    if (active) atomicMax(&best[node], v);
 }
 
 __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restrict__ lv, int nlevels,
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
                                                          unsigned short* __restrict__ nodeOf,
                                                          uint2* __restrict__ sel, int selPerFrame,
                                                          int* __restrict__ levelCount, int* __restrict__ levelLap,
-                                                         const int* __restrict__ lapArea, int M, int P) {
+                                                         const int* __restrict__ lapArea, int M, int P, int R, int XT) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ OctShared sh;
     // blockIdx.x = frame: consecutive workgroups are dealt round-robin to the 8 XCDs, so the heavy level-0
@@ -148,6 +165,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
     int* fwd = (int*)(mapKeep + M);                   // [M]    creation offset of a split node's first child
     int* keepIdx = fwd + M;                           // [M]
     unsigned long long* sortKey = (unsigned long long*)(keepIdx + M);   // [P]
+    unsigned* ncode[2];                                // [M] x2 dense-phase node descriptors
+    ncode[0] = (unsigned*)(sortKey + P);  ncode[1] = ncode[0] + M;
+    int* hist = (int*)(ncode[1] + M);                 // [R][kHistPerRoot] key counts of every node down to depth kD0
+    unsigned short* cell = (unsigned short*)(hist + R * kHistPerRoot);   // [R][kLeaves] leaf cell -> node position
+    uint8_t* xcode = (uint8_t*)(cell + R * kLeaves);  // [XT] root << kD0 | x path of every x of the rectangle
+    uint8_t* ycode = xcode + XT;                      // [XT] y path of every y
 
     int nC = (int)candCount[f * nlevels + level];
     nC = nC > g.candCap ? g.candCap : nC;
@@ -167,7 +190,19 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
         box[0][tid] = b;
         cnt[0][tid] = 0;
     }
+    bool dense = g.nIni <= R && g.rectW <= XT && g.rectH <= XT;    // workgroup-uniform
+    if (tid < g.nIni) ncode[0][tid] = nodeKey(tid, 0, 0, 0);
+    if (dense) {
+        for (int x = tid; x < g.rectW; x += kOctThreads) {
+            int r = (int)__fdiv_rn((float)x, g.hX);                // vpIniNodes[kp.pt.x/hX] (:574)
+            r = r > g.nIni - 1 ? g.nIni - 1 : r;
+            xcode[x] = (uint8_t)((r << kD0) | axisPath(x, (int)(g.hX * (float)r), (int)(g.hX * (float)(r + 1))));
+        }
+        for (int y = tid; y < g.rectH; y += kOctThreads) ycode[y] = (uint8_t)axisPath(y, 0, g.rectH);
+    }
     for (int i = tid; i < 4 * g.nIni; i += kOctThreads) childCnt[i] = 0;
+    if (dense)
+        for (int i = tid; i < g.nIni * kHistPerRoot; i += kOctThreads) hist[i] = 0;
     __syncthreads();
     for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
         unsigned w[kOctUnroll];
@@ -183,17 +218,40 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
             int r = 0, q = 0;
             if (active) {
                 const int x = w[u] & 0xfff, y = (w[u] >> 12) & 0xfff;
-                r = (int)__fdiv_rn((float)x, g.hX);            // vpIniNodes[kp.pt.x/hX] (:574)
-                r = r > g.nIni - 1 ? g.nIni - 1 : r;
-                nof[k] = (unsigned short)r;
-                q = quadrantOf(x, y, box[0][r]);
+                if (dense) {
+                    const int xc = xcode[min(x, g.rectW - 1)], yc = ycode[min(y, g.rectH - 1)];
+                    const int leaf = (yc << kD0) | (xc & ((1 << kD0) - 1));      // row-major leaf cell of the root
+                    r = xc >> kD0;
+                    nof[k] = (unsigned short)(r * kLeaves + leaf);
+                    atomicAdd(&hist[r * kHistPerRoot + histOff(kD0) + leaf], 1);
+                } else {
+                    r = (int)__fdiv_rn((float)x, g.hX);            // vpIniNodes[kp.pt.x/hX] (:574)
+                    r = r > g.nIni - 1 ? g.nIni - 1 : r;
+                    nof[k] = (unsigned short)r;
+                    q = quadrantOf(x, y, box[0][r]);
+                }
             }
-            countQuadrant(childCnt, active, r, q);
+            if (!dense) countQuadrant(childCnt, active, r, q);
         }
     }
     __syncthreads();
-    if (tid < g.nIni)
+    if (dense) {
+        for (int d = kD0 - 1; d >= 1; d--) {      // 4:1 sums: counts of every node at depth d
+            const int nd = 1 << (2 * d);
+            for (int i = tid; i < g.nIni * nd; i += kOctThreads) {
+                const int r = i >> (2 * d), c = i & (nd - 1), yp = c >> d, xp = c & ((1 << d) - 1);
+                const int* ch = hist + r * kHistPerRoot + histOff(d + 1) + ((2 * yp) << (d + 1)) + 2 * xp;   // 2x2 block below
+                hist[r * kHistPerRoot + histOff(d) + c] = ch[0] + ch[1] + ch[1 << (d + 1)] + ch[(1 << (d + 1)) + 1];
+            }
+            __syncthreads();
+        }
+        if (tid < g.nIni) {
+            const int* h1 = hist + tid * kHistPerRoot;
+            cnt[0][tid] = h1[0] + h1[1] + h1[2] + h1[3];
+        }
+    } else if (tid < g.nIni) {
         cnt[0][tid] = childCnt[4 * tid] + childCnt[4 * tid + 1] + childCnt[4 * tid + 2] + childCnt[4 * tid + 3];
+    }
     if (tid == 0) { sh.size = nC > 0 ? g.nIni : 0; sh.phase2 = 0; sh.done = 0; }
     __syncthreads();
     if (tid == 0) {
@@ -211,7 +269,66 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
         const int size = sh.size, phase2 = sh.phase2, prevSize = sh.prevSize;
         short4* bx = box[cur];
         int* cn = cnt[cur];
-        if (tid == 0) { sh.nToExpand = 0; sh.breakRank = 0x7fffffff; }
+        if (tid == 0) { sh.nToExpand = 0; sh.breakRank = 0x7fffffff; sh.deep = 0; }
+        if (dense) {
+            const unsigned* cd = ncode[cur];
+            __syncthreads();
+            for (int n = tid; n < size; n += kOctThreads)
+                if (cn[n] > 1 && ((cd[n] >> 20) & 15) >= (unsigned)kD0) sh.deep = 1;
+            __syncthreads();
+            if (!sh.deep) {
+                // child counts of every node that may split: look-ups in the count pyramid
+                for (int i = tid; i < 4 * size; i += kOctThreads) {
+                    const int n = i >> 2, q = i & 3;
+                    const unsigned c = cd[n];
+                    const int root = c >> 24, depth = (c >> 20) & 15, yp = (c >> 10) & 1023, xp = c & 1023;
+                    const int cy = 2 * yp + (q >> 1), cx = 2 * xp + (q & 1);      // child q of DivideNode
+                    childCnt[i] = cn[n] > 1 ? hist[root * kHistPerRoot + histOff(depth + 1) + (cy << (depth + 1)) + cx] : 0;
+                }
+                __syncthreads();
+            } else {
+                // a node at depth kD0 has to split: give every key its node id once, counting the next split;
+                // from here on the passes sweep the keys
+                for (int n = tid; n < size; n += kOctThreads) {
+                    const unsigned c = cd[n];
+                    const int root = c >> 24, depth = (c >> 20) & 15, yp = (c >> 10) & 1023, xp = c & 1023;
+                    if (cn[n] > 0 && depth <= kD0) {
+                        const int span = 1 << (kD0 - depth);      // leaf cells per side under this node
+                        unsigned short* dst = cell + root * kLeaves + ((yp * span) << kD0) + xp * span;
+                        for (int jy = 0; jy < span; jy++)
+                            for (int jx = 0; jx < span; jx++) dst[(jy << kD0) + jx] = (unsigned short)n;
+                    }
+                }
+                for (int i = tid; i < 4 * size; i += kOctThreads) childCnt[i] = 0;
+                __syncthreads();
+                for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
+                    unsigned w[kOctUnroll];
+                    int nd[kOctUnroll];
+#pragma unroll
+                    for (int u = 0; u < kOctUnroll; u++) {
+                        const int k = k0 + u * kOctThreads + tid;
+                        w[u] = k < nC ? pos[k] : 0u;
+                        nd[u] = k < nC ? (int)nof[k] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kOctUnroll; u++) {
+                        const int k = k0 + u * kOctThreads + tid;
+                        const bool active = k < nC;
+                        int nn = 0, q = 0;
+                        bool counts = false;
+                        if (active) {
+                            nn = cell[nd[u]];
+                            nof[k] = (unsigned short)nn;
+                            counts = cn[nn] > 1;
+                            if (counts) q = quadrantOf(w[u] & 0xfff, (w[u] >> 12) & 0xfff, bx[nn]);
+                        }
+                        countQuadrant(childCnt, counts, nn, q);
+                    }
+                }
+                dense = false;
+                __syncthreads();
+            }
+        }
         auto nch = [&](int n) {   // non-empty children of node n
             return (childCnt[4 * n] > 0) + (childCnt[4 * n + 1] > 0) + (childCnt[4 * n + 2] > 0) + (childCnt[4 * n + 3] > 0);
         };
@@ -284,11 +401,14 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
         // a node splits iff it has several keys (phase 1) / iff it was reached before the break (phase 2)
         short4* nbx = box[cur ^ 1];
         int* ncn = cnt[cur ^ 1];
+        const unsigned* ocd = ncode[cur];
+        unsigned* ncd = ncode[cur ^ 1];
         for (int n = tid; n < size; n += kOctThreads) {
             const int c0 = cn[n];
             const bool split = phase2 ? fwd[n] >= 0 : c0 > 1;
             if (split) {
                 int j = fwd[n], expand = 0;
+                const unsigned cdn = ocd[n];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int c = childCnt[4 * n + q];
@@ -296,6 +416,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
                         const int p = C - 1 - j;   // pushed to the front in creation order
                         nbx[p] = childBox(bx[n], q);
                         ncn[p] = c;
+                        if (dense) ncd[p] = nodeKey(cdn >> 24, ((cdn >> 20) & 15) + 1, 2 * ((cdn >> 10) & 1023) + (q >> 1), 2 * (cdn & 1023) + (q & 1));
                         mapChild[4 * n + q] = (unsigned short)p;
                         expand += c > 1;
                         j++;
@@ -306,6 +427,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
                 const int p = C + keepIdx[n];
                 nbx[p] = bx[n];
                 ncn[p] = c0;
+                if (dense) ncd[p] = ocd[n];
                 mapKeep[n] = (unsigned short)p;
             }
         }
@@ -316,11 +438,48 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
             else if (!phase2 && newSize + 3 * sh.nToExpand > N) sh.phase2 = 1;  // :678
             sh.prevSize = newSize;
         }
-        // the child counters are consumed; clear them for the new list (or the arg-max slots if this was the last pass)
-        for (int i = tid; i < 4 * newSize; i += kOctThreads) childCnt[i] = 0;
         __syncthreads();
         const bool last = sh.done != 0;
         STAMP(4);
+        if (dense) {
+            // no sweep between dense passes; after the last one the keys find their node through the leaf-cell table
+            if (last) {
+                for (int n = tid; n < newSize; n += kOctThreads) {
+                    const unsigned c = ncd[n];
+                    const int root = c >> 24, depth = (c >> 20) & 15, yp = (c >> 10) & 1023, xp = c & 1023;
+                    const int span = 1 << (kD0 - depth);
+                    unsigned short* dst = cell + root * kLeaves + ((yp * span) << kD0) + xp * span;
+                    for (int jy = 0; jy < span; jy++)
+                        for (int jx = 0; jx < span; jx++) dst[(jy << kD0) + jx] = (unsigned short)n;
+                    best[n] = 0;
+                }
+                __syncthreads();
+                for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
+                    unsigned w[kOctUnroll], od[kOctUnroll];
+                    int nd[kOctUnroll];
+#pragma unroll
+                    for (int u = 0; u < kOctUnroll; u++) {
+                        const int k = k0 + u * kOctThreads + tid;
+                        const bool active = k < nC;
+                        w[u] = active ? pos[k] : 0u;
+                        nd[u] = active ? (int)nof[k] : 0;
+                        od[u] = active ? ord[k] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kOctUnroll; u++) {
+                        const int k = k0 + u * kOctThreads + tid;
+                        const bool active = k < nC;
+                        const int nn = active ? (int)cell[nd[u]] : 0;
+                        const unsigned long long v = ((unsigned long long)(w[u] >> 24) << 56) | ((unsigned long long)(~od[u]) << 24) |
+                                                     (unsigned long long)(w[u] & 0xffffff);
+                        maxPerNode(best, active, nn, v);
+                    }
+                }
+            }
+        } else {
+        // the child counters are consumed; clear them for the new list (or the arg-max slots if this was the last pass)
+        for (int i = tid; i < 4 * newSize; i += kOctThreads) childCnt[i] = 0;
+        __syncthreads();
         // ---- the sweep: rename every key's node; count it for the next pass, or take the arg-max ----
         for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
             unsigned w[kOctUnroll], od[kOctUnroll];
@@ -358,6 +517,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restr
                 if (last) maxPerNode(best, active, nn, v);
                 else countQuadrant(childCnt, counts, nn, q);
             }
+        }
         }
         cur ^= 1;
         __syncthreads();
@@ -406,7 +566,7 @@ extern "C" int orbx_debug_oct_stamps(unsigned long long* out128) {
 }
 #endif
 
-size_t octreeLdsBytes(int M, int P) {
+size_t octreeLdsBytes(int M, int P, int R, int XT) {
     size_t b = 0;
     b += 2 * (size_t)M * sizeof(short4);            // box
     b += 2 * (size_t)M * sizeof(int);               // cnt
@@ -416,13 +576,17 @@ size_t octreeLdsBytes(int M, int P) {
     b += (size_t)M * sizeof(int);                   // fwd
     b += (size_t)M * sizeof(int);                   // keepIdx
     b += (size_t)P * sizeof(unsigned long long);    // sortKey
+    b += 2 * (size_t)M * sizeof(unsigned);          // ncode
+    b += (size_t)R * kHistPerRoot * sizeof(int);    // hist
+    b += (size_t)R * kLeaves * sizeof(unsigned short);   // cell
+    b += 2 * (size_t)XT;                            // xcode, ycode
     return b + 64;
 }
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const unsigned* candPos, const unsigned* candOrd,
                   const unsigned* candCount, unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount,
-                  int* levelLap, const int* lapArea, int M, int P, int B) {
-    hipLaunchKernelGGL(k_octree, dim3(B, nlevels), dim3(kOctThreads), octreeLdsBytes(M, P), st, lv, nlevels, candPos,
-                       candOrd, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P);
+                  int* levelLap, const int* lapArea, int M, int P, int R, int XT, int B) {
+    hipLaunchKernelGGL(k_octree, dim3(B, nlevels), dim3(kOctThreads), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, candPos,
+                       candOrd, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT);
 }
 
 }  // namespace orbx

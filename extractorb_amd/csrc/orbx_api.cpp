@@ -20,9 +20,9 @@ void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 unsigned*, int, int, int);
-size_t octreeLdsBytes(int M, int P);
+size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const unsigned*, const unsigned*, const unsigned*, unsigned short*,
-                  uint2*, int, int*, int*, const int*, int, int, int);
+                  uint2*, int, int*, int*, const int*, int, int, int, int, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
@@ -68,7 +68,7 @@ struct orbx_handle {
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel
     int nBlurLanes = 0;
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
-    int octM = 0, octP = 0;
+    int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
     // outputs of the host path
     int outCap = 0;
     Keypoint *d_outK = nullptr, *d_outLevelK = nullptr;
@@ -229,7 +229,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     {
         Prof p(h, S_OCTREE);
         launchOctree(st, h->d_lv, g.nlevels, h->d_candPos, h->d_candOrd, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, B);
+                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, B);
     }
     {
         Prof p(h, S_DESCRIBE);
@@ -346,7 +346,13 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
     M = (M + 7) / 8 * 8;
     h->octM = M; h->octP = nextPow2(M);
-    if (octreeLdsBytes(h->octM, h->octP) > 150 * 1024) {
+    // dense phase of the quad-tree: count pyramids for the roots of the widest level and coordinate tables for the
+    // largest rectangle; dropped (the kernel then sweeps the keys every pass) when LDS is short
+    h->octR = 1;
+    for (int l = 0; l < nlevels; l++) h->octR = mg.lv[l].nIni > h->octR ? mg.lv[l].nIni : h->octR;
+    h->octXT = ((mg.lv[0].rectW > mg.lv[0].rectH ? mg.lv[0].rectW : mg.lv[0].rectH) + 15) / 16 * 16;
+    if (h->octR > 7 || octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) { h->octR = 0; h->octXT = 0; }
+    if (octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) {
         h->err = "orbx_create: per-level feature quota too large for the LDS-resident quad-tree (nfeatures <= ~9000)";
         return bail(ORBX_ERR_UNSUPPORTED);
     }
