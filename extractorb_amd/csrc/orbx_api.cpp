@@ -14,9 +14,10 @@
 
 namespace orbx {
 // launch wrappers, defined in the k_*.hip files
-void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, const ResizeX*,
-                    const ResizeX*, uint8_t*, int);
-void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, const ResizeX*, const ResizeX*, uint8_t*, int);
+void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
+                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, int);
+void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
+                  uint8_t*, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 unsigned*, int, int, int);
@@ -65,6 +66,8 @@ struct orbx_handle {
     LevelGeom* d_lv = nullptr;
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
+    TileFoot* d_foot = nullptr;
+    size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel
     int nBlurLanes = 0;
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
@@ -108,7 +111,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candOrd, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_tiles, h->d_outK,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
@@ -140,6 +143,13 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
         xo += g.rx[l].size(); yo += g.ry[l].size();
+    }
+    size_t fo = 0;
+    for (int l = 1; l < g.nlevels; l++) {
+        h->footOff[l] = fo;
+        if (fo + g.foot[l].size() > h->footCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "tile footprint table does not fit");
+        HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
+        fo += g.foot[l].size();
     }
     std::vector<BlurItem> tiles;
     int lanes = 0;
@@ -213,12 +223,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     }
     {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
         Prof p(h, S_LEVEL0);
-        launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, h->d_rx + h->rxOff[1],
-                       h->d_ry + h->ryOff[1], h->d_pyr, B);
+        launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
+                       g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
+                       g.tileLdsStride, g.tileLdsRows, B);
     }
     for (int l = 2; l < g.nlevels; l++) {
         Prof p(h, S_RESIZE);
-        launchResize(st, g.lv[l - 1], g.lv[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l], h->d_pyr, B);
+        launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
+                     h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, B);
     }
     { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     {
@@ -376,6 +388,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_rx, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurItem) * h->tileCap));
+    h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
+    CREATE_TRY(hipMalloc(&h->d_foot, sizeof(TileFoot) * h->footCap));
     const size_t oc = (size_t)h->outCap * max_batch;
     CREATE_TRY(hipMalloc(&h->d_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipMalloc(&h->d_outLevelK, oc * sizeof(Keypoint)));

@@ -103,6 +103,9 @@ struct FrameGeom {
     std::vector<CellDesc> cells;             // all levels, level 0 first, raster order inside a level
     std::vector<ResizeX> rx[kMaxLevels];     // level l from level l-1 (l >= 1)
     std::vector<ResizeX> ry[kMaxLevels];
+    std::vector<TileFoot> foot[kMaxLevels];  // per 256x32 tile of bordered level l (l >= 1), row-major over tiles
+    int tilesX[kMaxLevels] = {}, tilesY[kMaxLevels] = {};
+    int tileLdsStride = 16, tileLdsRows = 1; // LDS tile able to hold the largest footprint
     long long pyrBytesPerFrame = 0, blurBytesPerFrame = 0;
     long long candPerFrame = 0;              // sum of candCap
     int selPerFrame = 0;                     // sum of selCap
@@ -180,6 +183,39 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         if (l > 0) {
             resizeAxis(g.lv[l - 1].w, L.w, true, g.rx[l]);
             resizeAxis(g.lv[l - 1].h, L.h, false, g.ry[l]);
+        }
+        // tiles of the bordered level: 64 dword columns x 32 rows; their source footprints
+        {
+            const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
+            g.tilesX[l] = (nd + 63) / 64;
+            g.tilesY[l] = (L.pyrRows + 31) / 32;
+            auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
+            if (l > 0) {
+                for (int ty = 0; ty < g.tilesY[l]; ty++)
+                    for (int tx = 0; tx < g.tilesX[l]; tx++) {
+                        int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
+                        for (int dw = tx * 64; dw < tx * 64 + 64; dw++) {
+                            const int bc0 = 4 * (dw < nd ? dw : nd - 1);
+                            for (int j = 0; j < 4; j++) {
+                                int bx = bc0 + j - (kPadL - kEdge);
+                                bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                                const ResizeX& c = g.rx[l][refl(bx - kEdge, L.w)];
+                                sx0 = c.sx0 < sx0 ? c.sx0 : sx0; sx1 = c.sx1 > sx1 ? c.sx1 : sx1;
+                            }
+                        }
+                        for (int by = ty * 32; by < ty * 32 + 32; by++) {
+                            const int b = by < L.pyrRows ? by : L.pyrRows - 1;
+                            const ResizeX& c = g.ry[l][refl(b - kEdge, L.h)];
+                            sy0 = c.sx0 < sy0 ? c.sx0 : sy0; sy1 = c.sx1 > sy1 ? c.sx1 : sy1;
+                        }
+                        TileFoot t;
+                        t.fx0 = (short)(sx0 & ~3); t.nDw = (short)((sx1 - t.fx0 + 4) >> 2);
+                        t.fy0 = (short)sy0; t.nRows = (short)(sy1 - sy0 + 1);
+                        g.foot[l].push_back(t);
+                        if (t.nDw * 4 > g.tileLdsStride) g.tileLdsStride = (t.nDw * 4 + 15) / 16 * 16;
+                        if (t.nRows > g.tileLdsRows) g.tileLdsRows = t.nRows;
+                    }
+            }
         }
     }
     return std::string();
