@@ -136,7 +136,7 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
     if (active) atomicMax(&best[node], v);
 }
 
-__global__ __launch_bounds__(kOctThreads) void k_octree(const LevelGeom* __restrict__ lv, int nlevels,
+__global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __restrict__ lv, int nlevels,
                                                          const unsigned* __restrict__ candPos,
                                                          const unsigned* __restrict__ candOrd,
                                                          const unsigned* __restrict__ candCount,
