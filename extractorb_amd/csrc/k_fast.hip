@@ -139,59 +139,53 @@ __global__ __launch_bounds__(256) void k_fast(const CellDesc* __restrict__ cells
     }
     waveLdsSync();
 
-    // ---- pass 2: strict local maxima; lane i keeps the ballots of sweep i ----
-    unsigned long long myIni = 0, myMin = 0;
+    // ---- pass 2: strict local maxima (all 9 loads unconditional, 3-input max); survivors at minThFAST are
+    //      appended in raster order to a list that reuses the pixel tile (no longer needed) ----
+    unsigned* list = (unsigned*)tile;                   // entry: x | y << 6 | S << 12
     int nIni = 0, nMin = 0;
     {
-        int x = x00, y = y00, it = 0;
-        for (int base = 0; base < npix; base += 64, it++) {
-            bool lm = false;
-            int s = 0;
+        int x = x00, y = y00;
+        for (int base = 0; base < npix; base += 64) {
+            int s = 0, m = 255;
             if (base + lane < npix) {
                 const uint8_t* q = score + (y + 1) * TS + x + 1;
                 s = q[0];
-                lm = s > q[-1] && s > q[1] && s > q[-TS - 1] && s > q[-TS] && s > q[-TS + 1] && s > q[TS - 1] &&
-                     s > q[TS] && s > q[TS + 1];
+                const unsigned a = vmax3(q[-TS - 1], q[-TS], q[-TS + 1]), b = vmax3(q[-1], q[1], q[TS - 1]);
+                m = (int)vmax3(a, b, max((unsigned)q[TS], (unsigned)q[TS + 1]));
             }
-            const unsigned long long bIni = __ballot(lm && s > iniTh);
-            const unsigned long long bMin = __ballot(lm && s > minTh);
-            if (lane == it) { myIni = bIni; myMin = bMin; }
-            nIni += __popcll(bIni);
+            const bool keepMin = s > m && s > minTh;
+            const unsigned long long bMin = __ballot(keepMin);
+            if (keepMin) list[nMin + __popcll(bMin & ((1ull << lane) - 1))] = (unsigned)x | ((unsigned)y << 6) | ((unsigned)s << 12);
             nMin += __popcll(bMin);
+            nIni += __popcll(__ballot(keepMin && s > iniTh));
             x += qx; y += qy;
             if (x >= cw) { x -= cw; y++; }
         }
     }
     // the reference retries the cell at minThFAST only when the first call returned nothing (:835-838)
     const bool useIni = nIni > 0;
-    const unsigned long long mine = useIni ? myIni : myMin;
     const int total = useIni ? nIni : nMin;
     if (total == 0) return;
+    waveLdsSync();
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(&candCount[f * nlevels + c.level], (unsigned)total);
     base = __builtin_amdgcn_readfirstlane(base);
     unsigned* outPos = candPos + g.candOff + (long long)f * g.candCap;
     unsigned* outOrd = candOrd + g.candOff + (long long)f * g.candCap;
-    {
-        int x = x00, y = y00, it = 0;
-        for (int b0 = 0; b0 < npix; b0 += 64, it++) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)mine, it);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), it);
-            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-            if ((m >> lane) & 1) {
-                const int s = score[(y + 1) * TS + x + 1];
-                const unsigned before = __popcll(m & ((1ull << lane) - 1));
-                const unsigned px = (unsigned)(c.shiftX + x + 3), py = (unsigned)(c.shiftY + y + 3);
-                const unsigned at = base + before;
-                if (at < (unsigned)g.candCap) {
-                    outPos[at] = px | (py << 12) | ((unsigned)(s - 1) << 24);                       // response = S - 1
-                    outOrd[at] = ((unsigned)c.cellId << 12) | ((unsigned)y << 6) | (unsigned)x;    // reference list order
-                }
+    const int th = useIni ? iniTh : minTh;
+    for (int i0 = 0; i0 < nMin; i0 += 64) {
+        const unsigned e = i0 + lane < nMin ? list[i0 + lane] : 0u;
+        const int s = (int)(e >> 12), x = (int)(e & 63), y = (int)((e >> 6) & 63);
+        const bool keep = s > th;                       // entries hold S > minTh; 0 marks "past the end"
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const unsigned at = base + __popcll(m & ((1ull << lane) - 1));
+            if (at < (unsigned)g.candCap) {
+                outPos[at] = (unsigned)(c.shiftX + x + 3) | ((unsigned)(c.shiftY + y + 3) << 12) | ((unsigned)(s - 1) << 24);   // response = S - 1
+                outOrd[at] = ((unsigned)c.cellId << 12) | ((unsigned)y << 6) | (unsigned)x;    // reference list order
             }
-            base += __popcll(m);
-            x += qx; y += qy;
-            if (x >= cw) { x -= cw; y++; }
         }
+        base += __popcll(m);
     }
 }
 
