@@ -77,14 +77,19 @@ __device__ __forceinline__ void sincosGlibc(float y, float* s_out, float* c_out)
     }
 }
 
-constexpr int kDescWaves = 4;
+constexpr int kDescWaves = 4;                         // waves per workgroup; each half-wave (32 lanes) owns one keypoint
 constexpr int kBriefReach = 18;                       // |rounded rotated pattern coordinate| <= 18 (max radius 18.385)
 constexpr int kRawRows = 2 * kHalfPatch + 1;          // 31
 constexpr int kRawStride = 36;                        // 3 + 31 bytes -> 9 dwords
 constexpr int kBlurRows = 2 * kBriefReach + 1;        // 37
 constexpr int kBlurStride = 40;                       // 3 + 37 bytes -> 10 dwords
-constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per wave (dword multiple)
+constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per keypoint (dword multiple)
 
+// One half-wave (32 lanes) per kept keypoint:
+//   * both patches are staged in LDS with aligned dword loads that are all in flight at once;
+//   * IC_Angle: lane = patch row; the row's 31 pixels are byte-aligned with v_alignbyte and reduced with
+//     v_dot4_u32_u8 against per-row weight words (u+16 inside the disc, 0 outside) — sum(u*I) = dot(I, u+16) - 16*dot(I, 1);
+//   * rBRIEF: lane = 8 of the 256 test pairs; a ballot per group of 32 pairs packs 4 descriptor bytes of each keypoint.
 __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels,
                                                    const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                    const uint2* __restrict__ sel, int selPerFrame,
@@ -92,11 +97,23 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                    Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
                                                    int* __restrict__ nOut, int* __restrict__ monoOut,
                                                    Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts) {
-    __shared__ __align__(16) uint8_t smem[kDescWaves * kPatchLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * kDescWaves + wave, f = blockIdx.y;
-    if (slot >= selPerFrame) return;
-    // totals of this frame
+    __shared__ __align__(16) uint8_t smem[2 * kDescWaves * kPatchLds];
+    __shared__ __align__(16) unsigned wtab[2][16][8];   // [m10 weights | disc mask][|v|][dword of the aligned row]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
+    const int f = blockIdx.y;
+    {   // weight words of row |v| = a, bytes k = 0..31 <-> u = k - 15
+        const int which = tid >> 7, a = (tid >> 3) & 15, j = tid & 7;
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int u = 4 * j + b - kHalfPatch, au = u < 0 ? -u : u;
+            if (au <= c_umax[a]) w |= (unsigned)(which ? 1 : u + 16) << (8 * b);
+        }
+        wtab[which][a][j] = w;
+    }
+    __syncthreads();
+    const int slot = (blockIdx.x * kDescWaves + wave) * 2 + half;
+    // totals of this frame and the level this slot belongs to (per half-wave)
     int total = 0, totalLap = 0, level = 0, seqBase = 0, lapBase = 0;
     for (int l = 0; l < nlevels; l++) {
         const int c = levelCount[f * nlevels + l], lp = levelLap[f * nlevels + l];
@@ -104,50 +121,55 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         total += c;
         totalLap += lp;
     }
-    if (slot == 0 && lane == 0) {
+    if (slot == 0 && hl == 0) {
         nOut[f] = total;
         monoOut[f] = total - totalLap;   // monoIndex after the loop (:1161)
     }
-    if (slot == 0 && outLevelCounts && lane < nlevels) outLevelCounts[f * nlevels + lane] = levelCount[f * nlevels + lane];
-    const LevelGeom g = lv[level];
-    const int i = slot - g.selOff;
-    if (i >= levelCount[f * nlevels + level]) return;
-    const uint2 e = sel[(long long)f * selPerFrame + slot];
+    if (slot == 0 && outLevelCounts && hl < nlevels) outLevelCounts[f * nlevels + hl] = levelCount[f * nlevels + hl];
+    const int selOff = lv[level].selOff;
+    const int i = slot - selOff;
+    const bool active = slot < selPerFrame && i < levelCount[f * nlevels + level];
+    if (__ballot(active) == 0) return;
+    // per-half geometry (the two halves of a wave may sit in different levels)
+    const int gw = lv[level].w, gh = lv[level].h, pyrStride = lv[level].pyrStride, blurStride = lv[level].blurStride;
+    const long long pyrBase = lv[level].pyrOff + (long long)f * lv[level].pyrFrameBytes;
+    const long long blurBase = lv[level].blurOff + (long long)f * lv[level].blurFrameBytes;
+    const uint2 e = active ? sel[(long long)f * selPerFrame + slot] : make_uint2(0u, 0u);
     int kx = e.x & 0xfff, ky = (e.x >> 12) & 0xfff;
     const float response = (float)(e.x >> 24);
-    // the quad-tree only emits points of the FAST rectangle; clamp anyway so a corrupted entry can never
-    // turn into an out-of-bounds gather
-    kx = min(max(kx, kEdge), g.w - kEdge - 1);
-    ky = min(max(ky, kEdge), g.h - kEdge - 1);
+    // the quad-tree only emits points of the FAST rectangle; clamp anyway so a corrupted entry (or an idle half)
+    // can never turn into an out-of-bounds gather
+    kx = min(max(kx, kEdge), gw - kEdge - 1);
+    ky = min(max(ky, kEdge), gh - kEdge - 1);
 
-    // ---- stage both patches in LDS: every global load of the wave is an aligned dword and in flight at once ----
-    // raw level, rows/cols +-15 (IC_Angle); blurred level, rows/cols +-18 (the rotated pattern reaches radius 18.4)
-    uint8_t* rawT = smem + wave * kPatchLds;
+    // ---- stage both patches: raw level rows/cols +-15 (IC_Angle), blurred level rows/cols +-18 (rBRIEF) ----
+    uint8_t* rawT = smem + (wave * 2 + half) * kPatchLds;
     uint8_t* blurT = rawT + kRawRows * kRawStride;
     const int rawCol0 = kPadL + kx - kHalfPatch, rawMis = rawCol0 & 3;
     const int blurCol0 = kx - kBriefReach, blurMis = blurCol0 & 3;
     {
-        const uint8_t* rp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + ky - kHalfPatch) * g.pyrStride + (rawCol0 - rawMis);
-        const uint8_t* bp = blur + g.blurOff + (long long)f * g.blurFrameBytes + (long long)(ky - kBriefReach) * g.blurStride + (blurCol0 - blurMis);
+        const uint8_t* rp = pyr + pyrBase + (long long)(kEdge + ky - kHalfPatch) * pyrStride + (rawCol0 - rawMis);
+        const uint8_t* bp = blur + blurBase + (long long)(ky - kBriefReach) * blurStride + (blurCol0 - blurMis);
         constexpr int nRaw = kRawRows * (kRawStride / 4), nBlur = kBlurRows * (kBlurStride / 4);
-        constexpr int steps = (nRaw + nBlur + 63) / 64;
+        constexpr int steps = (nRaw + nBlur + 31) / 32;
         unsigned w[steps];
 #pragma unroll
         for (int s = 0; s < steps; s++) {
-            const int i = lane + 64 * s;
-            if (i < nRaw) {
-                const int r = i / (kRawStride / 4), c = i - r * (kRawStride / 4);
-                w[s] = *(const unsigned*)(rp + (long long)r * g.pyrStride + 4 * c);
-            } else if (i < nRaw + nBlur) {
-                const int k = i - nRaw, r = k / (kBlurStride / 4), c = k - r * (kBlurStride / 4);
+            const int idx = hl + 32 * s;
+            w[s] = 0u;
+            if (idx < nRaw) {
+                const int r = idx / (kRawStride / 4), c = idx - r * (kRawStride / 4);
+                w[s] = *(const unsigned*)(rp + r * pyrStride + 4 * c);
+            } else if (idx < nRaw + nBlur) {
+                const int k = idx - nRaw, r = k / (kBlurStride / 4), c = k - r * (kBlurStride / 4);
                 // the last dword of a row can start past the blurred row's padded end when the patch touches the right edge
-                w[s] = (blurCol0 - blurMis + 4 * c) < g.blurStride ? *(const unsigned*)(bp + (long long)r * g.blurStride + 4 * c) : 0u;
+                if (blurCol0 - blurMis + 4 * c < blurStride) w[s] = *(const unsigned*)(bp + r * blurStride + 4 * c);
             }
         }
 #pragma unroll
         for (int s = 0; s < steps; s++) {
-            const int i = lane + 64 * s;
-            if (i < nRaw + nBlur) *(unsigned*)(rawT + 4 * i) = w[s];   // the two tiles are adjacent and dword-granular
+            const int idx = hl + 32 * s;
+            if (idx < nRaw + nBlur) *(unsigned*)(rawT + 4 * idx) = w[s];   // the two tiles are adjacent and dword-granular
         }
     }
     asm volatile("" ::: "memory");
@@ -156,26 +178,28 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     asm volatile("" ::: "memory");
 
     // ---- IC_Angle (:75-102): integer moments over the radius-15 disc of the unblurred level ----
-    const uint8_t* center = rawT + kHalfPatch * kRawStride + rawMis + kHalfPatch;
     int m10 = 0, m01 = 0;
-    {
-        const int col = lane & 31, u = col - kHalfPatch, half = lane >> 5;
-        if (col <= 2 * kHalfPatch) {
-            const int au = u < 0 ? -u : u;
-            // half 0: rows v = 0..15, half 1: rows v = -1..-15
+    if (hl < kRawRows) {
+        const int v = hl - kHalfPatch, a = v < 0 ? -v : v;
+        const unsigned* row = (const unsigned*)(rawT + hl * kRawStride);
+        unsigned d[9];
 #pragma unroll
-            for (int a = 0; a <= kHalfPatch; a++) {
-                if (a >= half && au <= c_umax[a]) {
-                    const int v = half ? -a : a;
-                    const int val = center[v * kRawStride + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+        for (int j = 0; j < 9; j++) d[j] = row[j];
+        unsigned s1 = 0, s0 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // bytes u = 4j-15 .. 4j-12 of the row: shift the dword pair by the patch's misalignment
+            const unsigned px = rawMis == 0 ? d[j] : (rawMis == 1 ? __builtin_amdgcn_alignbyte(d[j + 1], d[j], 1)
+                                                  : (rawMis == 2 ? __builtin_amdgcn_alignbyte(d[j + 1], d[j], 2)
+                                                                 : __builtin_amdgcn_alignbyte(d[j + 1], d[j], 3)));
+            s1 = __builtin_amdgcn_udot4(px, wtab[0][a][j], s1, false);
+            s0 = __builtin_amdgcn_udot4(px, wtab[1][a][j], s0, false);
         }
+        m10 = (int)s1 - 16 * (int)s0;     // sum u*I
+        m01 = v * (int)s0;                // v * sum I
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {    // reduce inside the half-wave
         m10 += __shfl_xor(m10, o);
         m01 += __shfl_xor(m01, o);
     }
@@ -186,10 +210,10 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     float a, b;
     sincosGlibc(__fmul_rn(angle, factorPI), &b, &a);
     const uint8_t* bc = blurT + kBriefReach * kBlurStride + blurMis + kBriefReach;
-    unsigned long long word[4];
+    unsigned myWord = 0;                   // lane hl < 8 ends up holding descriptor bytes 4*hl .. 4*hl+3 of its keypoint
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int p = lane + 64 * j;   // test pair index; bit (p & 7) of descriptor byte (p >> 3)
+    for (int j = 0; j < 8; j++) {
+        const int p = hl + 32 * j;        // test pair index; bit (p & 7) of descriptor byte (p >> 3)
         const char4 pt = ((const char4*)c_pattern)[p];
         const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
@@ -197,8 +221,11 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
         const int t0 = bc[r0 * kBlurStride + q0], t1 = bc[r1 * kBlurStride + q1];
-        word[j] = __ballot(t0 < t1);
+        const unsigned long long m = __ballot(t0 < t1);
+        const unsigned mine = half ? (unsigned)(m >> 32) : (unsigned)m;
+        myWord = hl == j ? mine : myWord;
     }
+    if (!active) return;
 
     // ---- placement (:1137-1158): non-lapping keys fill from the front, lapping keys from the back ----
     const int lapRank = (int)(e.y & 0x7fffffff), isLap = (int)(e.y >> 31);
@@ -206,25 +233,21 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const int monoBefore = (seqBase - lapBase) + (i - lapRank);
     const int at = isLap ? total - 1 - lapBefore : monoBefore;
     float ox = (float)kx, oy = (float)ky;
-    if (level != 0) { ox = __fmul_rn(ox, g.scale); oy = __fmul_rn(oy, g.scale); }
+    const float scale = lv[level].scale;
+    if (level != 0) { ox = __fmul_rn(ox, scale); oy = __fmul_rn(oy, scale); }
+    const float patchSize = (float)lv[level].patchSize;
     if (at < capacity) {
-        if (lane == 0) {
+        if (hl == 0) {
             Keypoint k;
-            k.x = ox; k.y = oy; k.size = (float)g.patchSize; k.angle = angle; k.response = response;
+            k.x = ox; k.y = oy; k.size = patchSize; k.angle = angle; k.response = response;
             k.octave = level; k.class_id = -1;
             outK[(long long)f * capacity + at] = k;
         }
-        if (lane < 4) {
-            unsigned long long w = word[0];
-            w = lane == 1 ? word[1] : w;
-            w = lane == 2 ? word[2] : w;
-            w = lane == 3 ? word[3] : w;
-            ((unsigned long long*)(outD + ((long long)f * capacity + at) * 32))[lane] = w;
-        }
+        if (hl < 8) ((unsigned*)(outD + ((long long)f * capacity + at) * 32))[hl] = myWord;
     }
-    if (outLevelK && lane == 0 && seqBase + i < capacity) {
+    if (outLevelK && hl == 0 && seqBase + i < capacity) {
         Keypoint k;
-        k.x = (float)kx; k.y = (float)ky; k.size = (float)g.patchSize; k.angle = angle; k.response = response;
+        k.x = (float)kx; k.y = (float)ky; k.size = patchSize; k.angle = angle; k.response = response;
         k.octave = level; k.class_id = -1;
         outLevelK[(long long)f * capacity + seqBase + i] = k;
     }
@@ -234,7 +257,8 @@ void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint
                     const uint2* sel, int selPerFrame, const int* levelCount, const int* levelLap, Keypoint* outK,
                     uint8_t* outD, int capacity, int* nOut, int* monoOut, Keypoint* outLevelK, int* outLevelCounts,
                     int B) {
-    hipLaunchKernelGGL(k_describe, dim3((selPerFrame + kDescWaves - 1) / kDescWaves, B), dim3(256), 0, st, lv, nlevels,
+    const int perBlock = 2 * kDescWaves;
+    hipLaunchKernelGGL(k_describe, dim3((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
                        pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
                        outLevelCounts);
 }
