@@ -78,7 +78,7 @@ __device__ __forceinline__ void waveLdsSync() {
 
 // TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.
 template <int TS, int ROWS>
-__global__ __launch_bounds__(256) void k_fast(const CellDesc* __restrict__ cells, int nCells,
+__global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                unsigned* __restrict__ candPos, unsigned* __restrict__ candOrd,
