@@ -179,3 +179,44 @@ def test_device_resident_path_with_torch_tensors():
     for f in range(B):
         k = kraw[f, :n[f]].copy().view(X.KEYPOINT_DTYPE).reshape(-1)
         assert_same_result((int(m[f]), k, d_d[f, :n[f]].cpu().numpy()), oracle_run(frames[f])[1], "device frame %d" % f)
+
+
+def test_quadtree_paths_wide_and_clustered():
+    # (a) 10 quad-tree roots: too many for the LDS count pyramids -> the kernel sweeps the keys every pass
+    wide = synth.frames("noise", 3, 1, 260, 2400)[0]
+    o, want = oracle_run(wide, 1500, (0, 1000), nlevels=3)
+    ex = X.ORBextractor(1500, 1.2, 3, 20, 7, max_width=2400, max_height=260)
+    mono, k, d, lvl = ex(wide)
+    check_stages(ex, o, lvl, 3)
+    assert_same_result((mono, k, d), want, "wide")
+    # (b) tight clusters: nodes deeper than the dense phase's 5 levels must be materialised and swept
+    rng = np.random.default_rng(4)
+    img = np.full((480, 640), 90, np.uint8)
+    for cy, cx in [(100, 120), (300, 500), (240, 320), (400, 90)]:
+        ys = np.clip(cy + rng.integers(-24, 24, 900), 20, 459); xs = np.clip(cx + rng.integers(-24, 24, 900), 20, 619)
+        img[ys, xs] = rng.integers(150, 255, 900)
+    o, want = oracle_run(img, 3000)
+    ex = X.ORBextractor(3000)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, "clustered")
+
+
+def test_randomised_sizes_and_parameters():
+    rng = np.random.default_rng(2026)
+    for t in range(10):
+        rows, cols = int(rng.integers(230, 700)), int(rng.integers(230, 900))
+        if rows > 2 * cols - 40:
+            continue
+        nf = int(rng.integers(50, 2500))
+        variant = ["noise", "textured", "sparse"][t % 3]
+        lap = (int(rng.integers(-10, 400)), int(rng.integers(100, 1200)))
+        img = synth.frames(variant, 1000 + t, 1, rows, cols)[0]
+        try:
+            o, want = oracle_run(img, nf, lap)
+            ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows)
+        except X.OrbxError:
+            continue          # geometry the library rejects (a level smaller than one cell)
+        mono, k, d, lvl = ex(img, None, lap)
+        check_stages(ex, o, lvl)
+        assert_same_result((mono, k, d), want, "random case %d: %dx%d nf=%d %s lap=%s" % (t, cols, rows, nf, variant, lap))
