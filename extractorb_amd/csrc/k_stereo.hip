@@ -1,0 +1,249 @@
+// k_stereo.hip — "next" row SURVEY.md §8f-1: Frame::ComputeStereoMatches (reference src/Frame.cc:813-991)
+// on the device-resident outputs of one batched extraction (frame 2p = left eye, frame 2p+1 = right eye).
+//
+//   k_stereo_rows    per pair: the reference's vRowIndices — for every image row the right keypoints whose
+//                    band [floor(y - 2s), ceil(y + 2s)] (s = scale of the keypoint's octave) covers it  (:826-840)
+//   k_stereo_match   one wave per left keypoint: 256-bit Hamming search over the row's candidates
+//                    (ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2349-2365; octave within +-1, u inside
+//                    [uL - bf/b, uL]), then the 11-shift SAD of an 11x11 window on the LEFT/RIGHT PYRAMIDS — which
+//                    never leave HBM — and the parabola sub-pixel fit  (:849-978)
+//   k_stereo_filter  per pair: median of the SAD distances, matches at >= 1.5*1.4*median dropped  (:981-996)
+//
+// Ties: the reference keeps the first minimum while walking candidates in increasing right index, so the search
+// minimises the pair (distance, right index).  All float steps use explicit single roundings.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbx_device.hpp"
+
+namespace orbx {
+
+struct StereoParams {
+    float scale[kMaxLevels], invScale[kMaxLevels];
+    float bf, b;
+    int nlevels, capacity, rowCap;   // rowCap: entries of one pair's row-list arena
+};
+
+constexpr int kThHigh = 100, kThLow = 50;   // ORBmatcher.cc:36-37
+
+// ---- row tables -----------------------------------------------------------------------------------------
+// grid: n_pairs; 1024 threads.  rowOff: [pair][rows+1]; rowList: [pair][rowCap] right indices.
+__global__ __launch_bounds__(1024) void k_stereo_rows(const Keypoint* __restrict__ kps, const int* __restrict__ nOut,
+                                                       StereoParams sp, int rows, int* __restrict__ rowOff,
+                                                       unsigned short* __restrict__ rowList) {
+    extern __shared__ int cnt[];   // [rows + 1] counts, then cursors
+    __shared__ int wsum[16];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Keypoint* kr = kps + (long long)(2 * pair + 1) * sp.capacity;
+    const int Nr = min(nOut[2 * pair + 1], sp.capacity);
+    for (int i = tid; i <= rows; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int iR = tid; iR < Nr; iR += 1024) {
+        const float kpY = kr[iR].y, r = __fmul_rn(2.0f, sp.scale[min(max(kr[iR].octave, 0), sp.nlevels - 1)]);
+        const int maxr = min((int)ceilf(__fadd_rn(kpY, r)), rows - 1), minr = max((int)floorf(__fsub_rn(kpY, r)), 0);
+        for (int y = minr; y <= maxr; y++) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..rows) by 1024 threads
+    const int per = (rows + 1023) / 1024, b0 = tid * per, e0 = min(b0 + per, rows);
+    int sum = 0;
+    for (int i = b0; i < e0; i++) sum += cnt[i];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    int run = off + incl - sum;
+    int* ro = rowOff + (long long)pair * (rows + 1);
+    for (int i = b0; i < e0; i++) { const int c = cnt[i]; ro[i] = run; cnt[i] = run; run += c; }   // cnt becomes the fill cursor
+    if (tid == 1023) ro[rows] = run;
+    __syncthreads();
+    unsigned short* rl = rowList + (long long)pair * sp.rowCap;
+    for (int iR = tid; iR < Nr; iR += 1024) {
+        const float kpY = kr[iR].y, r = __fmul_rn(2.0f, sp.scale[min(max(kr[iR].octave, 0), sp.nlevels - 1)]);
+        const int maxr = min((int)ceilf(__fadd_rn(kpY, r)), rows - 1), minr = max((int)floorf(__fsub_rn(kpY, r)), 0);
+        for (int y = minr; y <= maxr; y++) {
+            const int at = atomicAdd(&cnt[y], 1);
+            if (at < sp.rowCap) rl[at] = (unsigned short)iR;
+        }
+    }
+}
+
+// ---- matching ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int waveSumI(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid (ceil(capacity/4), n_pairs), 256 threads: one wave per left keypoint.
+__global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ lv, const uint8_t* __restrict__ pyr,
+                                                       const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                       const int* __restrict__ nOut, StereoParams sp, int rows,
+                                                       const int* __restrict__ rowOff, const unsigned short* __restrict__ rowList,
+                                                       float* __restrict__ uRight, float* __restrict__ depth,
+                                                       int* __restrict__ sadDist) {
+    const int lane = threadIdx.x & 63, iL = blockIdx.x * 4 + (threadIdx.x >> 6), pair = blockIdx.y;
+    const int fL = 2 * pair, fR = 2 * pair + 1;
+    const int N = min(nOut[fL], sp.capacity), Nr = min(nOut[fR], sp.capacity);
+    if (iL >= N) return;
+    const long long outIdx = (long long)pair * sp.capacity + iL;
+    if (lane == 0) { uRight[outIdx] = -1.0f; depth[outIdx] = -1.0f; sadDist[outIdx] = -1; }
+    const Keypoint* kl = kps + (long long)fL * sp.capacity;
+    const Keypoint* kr = kps + (long long)fR * sp.capacity;
+    const float uL = kl[iL].x, vL = kl[iL].y;
+    const int levelL = min(max(kl[iL].octave, 0), sp.nlevels - 1);
+    const int row = (int)vL;
+    if (row < 0 || row >= rows) return;
+    const int* ro = rowOff + (long long)pair * (rows + 1);
+    const int c0 = ro[row], c1 = min(ro[row + 1], sp.rowCap);
+    if (c1 <= c0) return;                                              // vCandidates.empty()  (:857-858)
+    const float minZ = sp.b, minD = 0.f, maxD = __fdiv_rn(sp.bf, minZ);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    if (maxU < 0) return;
+    // ---- descriptor search (:867-893) ----
+    const unsigned* dl = (const unsigned*)(desc + ((long long)fL * sp.capacity + iL) * 32);
+    unsigned dL[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) dL[k] = dl[k];
+    const unsigned short* rl = rowList + (long long)pair * sp.rowCap;
+    unsigned best = ((unsigned)kThHigh << 16);                         // (distance << 16 | right index): lexicographic minimum
+    for (int c = c0 + lane; c < c1; c += 64) {
+        const int iR = rl[c];
+        if (iR >= Nr) continue;
+        const int oR = kr[iR].octave;
+        const float uR = kr[iR].x;
+        if (oR < levelL - 1 || oR > levelL + 1) continue;
+        if (!(uR >= minU && uR <= maxU)) continue;
+        const unsigned* dr = (const unsigned*)(desc + ((long long)fR * sp.capacity + iR) * 32);
+        int dist = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dist += __popc(dL[k] ^ dr[k]);
+        const unsigned key = ((unsigned)dist << 16) | (unsigned)iR;
+        best = dist < kThHigh && key < best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    const int bestDist = (int)(best >> 16);
+    if (bestDist >= (kThHigh + kThLow) / 2) return;                    // thOrbDist  (:896)
+    const int bestIdxR = (int)(best & 0xffff);
+    // ---- sub-pixel refinement by correlation on the pyramids (:898-978) ----
+    const float uR0 = kr[bestIdxR].x;
+    const float scaleFactor = sp.invScale[levelL];
+    const float scaleduL = roundf(__fmul_rn(uL, scaleFactor)), scaledvL = roundf(__fmul_rn(vL, scaleFactor));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+    const int w = 5, L = 5;
+    const LevelGeom g = lv[levelL];
+    const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w), endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.f);
+    if (iniu < 0 || endu >= (float)g.w) return;
+    const int y0 = (int)__fsub_rn(scaledvL, (float)w), xl0 = (int)__fsub_rn(scaleduL, (float)w);
+    // guard the gathers: the reference's windows stay inside the bordered level for every keypoint it can produce
+    if (y0 < -kEdge || y0 + 10 >= g.h + kEdge || xl0 < -kEdge || xl0 + 10 >= g.w + kEdge) return;
+    const uint8_t* pl = pyr + g.pyrOff + (long long)fL * g.pyrFrameBytes + (long long)kEdge * g.pyrStride + kPadL;
+    const uint8_t* pr = pyr + g.pyrOff + (long long)fR * g.pyrFrameBytes + (long long)kEdge * g.pyrStride + kPadL;
+    // lane owns window pixels p = lane and lane + 64 (121 in all)
+    int il[2], oy[2], ox[2];
+    bool in[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int p = lane + 64 * t;
+        in[t] = p < 121;
+        oy[t] = in[t] ? p / 11 : 0;
+        ox[t] = in[t] ? p - oy[t] * 11 : 0;
+        il[t] = pl[(long long)(y0 + oy[t]) * g.pyrStride + xl0 + ox[t]];
+    }
+    const int cL = pl[(long long)(y0 + w) * g.pyrStride + xl0 + w];
+    il[0] -= cL; il[1] -= cL;
+    float vDists[11];
+    int bestS = 2147483647, bestincR = 0;
+#pragma unroll
+    for (int incR = -5; incR <= 5; incR++) {
+        const int xr0 = (int)__fsub_rn(__fadd_rn(scaleduR0, (float)incR), (float)w);
+        int part = 0;
+        if (xr0 >= -kEdge && xr0 + 10 < g.w + kEdge) {
+            const int cR = pr[(long long)(y0 + w) * g.pyrStride + xr0 + w];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                if (in[t]) part += abs(il[t] - ((int)pr[(long long)(y0 + oy[t]) * g.pyrStride + xr0 + ox[t]] - cR));
+        }
+        const float dist = (float)waveSumI(part);
+        if (dist < (float)bestS) { bestS = (int)dist; bestincR = incR; }
+        vDists[incR + 5] = dist;
+    }
+    if (bestincR == -L || bestincR == L) return;
+    float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+    for (int k = 1; k < 10; k++)
+        if (k == bestincR + 5) { dist1 = vDists[k - 1]; dist2 = vDists[k]; dist3 = vDists[k + 1]; }
+    const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                   __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = __fmul_rn(sp.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+        if (lane == 0) {
+            depth[outIdx] = __fdiv_rn(sp.bf, disparity);
+            uRight[outIdx] = bestuR;
+            sadDist[outIdx] = bestS;
+        }
+    }
+}
+
+// ---- outlier removal (:981-996) ---------------------------------------------------------------------------
+// grid n_pairs, 1024 threads.  median = the (cnt/2)-th element of the (distance, left index)-sorted matches.
+__global__ __launch_bounds__(1024) void k_stereo_filter(const int* __restrict__ nOut, StereoParams sp, float* __restrict__ uRight,
+                                                         float* __restrict__ depth, const int* __restrict__ sadDist,
+                                                         int* __restrict__ nMatched) {
+    extern __shared__ int d[];   // [capacity] SAD distances, -1 = unmatched
+    __shared__ int sCnt, sMedian, sKept;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int N = min(nOut[2 * pair], sp.capacity);
+    const long long base = (long long)pair * sp.capacity;
+    if (tid == 0) { sCnt = 0; sMedian = 0; sKept = 0; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < N; i += 1024) { d[i] = sadDist[base + i]; mine += d[i] >= 0; }
+    if (mine) atomicAdd(&sCnt, mine);
+    __syncthreads();
+    const int cnt = sCnt;
+    if (cnt == 0) { if (tid == 0) nMatched[pair] = 0; return; }       // the reference reads vDistIdx[0] here (undefined)
+    const int kth = cnt / 2;
+    for (int i = tid; i < N; i += 1024) {
+        const int di = d[i];
+        if (di < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < N; j++) {
+            const int dj = d[j];
+            rank += dj >= 0 && (dj < di || (dj == di && j < i));
+        }
+        if (rank == kth) sMedian = di;
+    }
+    __syncthreads();
+    const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)sMedian);
+    int kept = 0;
+    for (int i = tid; i < N; i += 1024) {
+        const int di = d[i];
+        if (di < 0) continue;
+        if ((float)di < thDist) kept++;
+        else { uRight[base + i] = -1.0f; depth[base + i] = -1.0f; }
+    }
+    if (kept) atomicAdd(&sKept, kept);
+    __syncthreads();
+    if (tid == 0) nMatched[pair] = sKept;
+}
+
+void launchStereo(hipStream_t st, const LevelGeom* lv, const uint8_t* pyr, const Keypoint* kps, const uint8_t* desc,
+                  const int* nOut, const StereoParams& sp, int rows, int* rowOff, unsigned short* rowList, float* uRight,
+                  float* depth, int* sadDist, int* nMatched, int nPairs) {
+    hipLaunchKernelGGL(k_stereo_rows, dim3(nPairs), dim3(1024), (size_t)(rows + 1) * sizeof(int), st, kps, nOut, sp, rows,
+                       rowOff, rowList);
+    hipLaunchKernelGGL(k_stereo_match, dim3((sp.capacity + 3) / 4, nPairs), dim3(256), 0, st, lv, pyr, kps, desc, nOut, sp,
+                       rows, rowOff, rowList, uRight, depth, sadDist);
+    hipLaunchKernelGGL(k_stereo_filter, dim3(nPairs), dim3(1024), (size_t)sp.capacity * sizeof(int), st, nOut, sp, uRight,
+                       depth, sadDist, nMatched);
+}
+
+}  // namespace orbx

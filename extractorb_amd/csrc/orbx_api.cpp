@@ -4,6 +4,7 @@
 // ORBX_ERR_NO_DEVICE, and nothing here includes, links or calls anything under oracle/.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -27,6 +28,13 @@ void launchOctree(hipStream_t, const LevelGeom*, int, const unsigned*, const uns
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
+struct StereoParams {
+    float scale[kMaxLevels], invScale[kMaxLevels];
+    float bf, b;
+    int nlevels, capacity, rowCap;
+};
+void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const StereoParams&,
+                  int, int*, unsigned short*, float*, float*, int*, int*, int);
 void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
 }  // namespace orbx
 
@@ -84,6 +92,11 @@ struct orbx_handle {
     uint8_t* h_outD = nullptr;
     int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
     int lastB = 0;
+    // stereo matching (allocated on first use)
+    int stereoPairs = 0, stereoCap = 0, stereoRows = 0;
+    int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
+    unsigned short* d_rowList = nullptr;
+    float *d_uRight = nullptr, *d_depth = nullptr;
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -112,7 +125,8 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candOrd, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_outK,
-                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts};
+                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_rowOff, h->d_sadDist,
+                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -577,6 +591,80 @@ int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, p
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy2D(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
                            L.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+namespace {
+// rows covered by one right keypoint's band [floor(y - 2s), ceil(y + 2s)], s = the coarsest level's scale
+int bandRows(const orbx_handle* h) { return 2 * (int)std::ceil(2.0 * h->tabs.scale[h->nlevels - 1]) + 2; }
+
+int stereoEnsure(orbx_handle* h, int nPairs, int capacity, int rows) {
+    if (nPairs <= h->stereoPairs && capacity <= h->stereoCap && rows <= h->stereoRows) return ORBX_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    void* old[] = {h->d_rowOff, h->d_sadDist, h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->d_rowOff = h->d_sadDist = h->d_nMatched = nullptr; h->d_rowList = nullptr; h->d_uRight = h->d_depth = nullptr;
+    h->stereoPairs = nPairs > h->stereoPairs ? nPairs : h->stereoPairs;
+    h->stereoCap = capacity > h->stereoCap ? capacity : h->stereoCap;
+    h->stereoRows = rows > h->stereoRows ? rows : h->stereoRows;
+    const size_t P = h->stereoPairs, C = h->stereoCap;
+    HIP_TRY(h, hipMalloc(&h->d_rowOff, P * (h->stereoRows + 1) * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->d_rowList, P * C * bandRows(h) * sizeof(unsigned short)));
+    HIP_TRY(h, hipMalloc(&h->d_sadDist, P * C * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->d_nMatched, P * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->d_uRight, P * C * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->d_depth, P * C * sizeof(float)));
+    return ORBX_OK;
+}
+
+int stereoEnqueue(orbx_handle* h, int n_pairs, const Keypoint* d_kps, const uint8_t* d_desc, const int* d_n, int capacity,
+                  float bf, float b, float* d_u, float* d_d, int* d_nm) {
+    if (h->geom.nlevels == 0 || 2 * n_pairs > h->lastB || n_pairs < 1)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "stereo matching needs the 2*n_pairs frames of the last extract batch on this handle");
+    if (!(b > 0.f) || !(bf > 0.f)) return fail(h, ORBX_ERR_BAD_ARGUMENT, "bf and b must be positive");
+    if (capacity > 65535) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 65535 keypoints per eye");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rows = h->geom.rows;
+    int rc = stereoEnsure(h, n_pairs, capacity, rows);
+    if (rc != ORBX_OK) return rc;
+    StereoParams sp;
+    for (int l = 0; l < kMaxLevels; l++) { sp.scale[l] = l < h->nlevels ? h->tabs.scale[l] : 1.f; sp.invScale[l] = l < h->nlevels ? h->tabs.invScale[l] : 1.f; }
+    sp.bf = bf; sp.b = b; sp.nlevels = h->nlevels; sp.capacity = capacity; sp.rowCap = h->stereoCap * bandRows(h);
+    launchStereo(h->stream, h->d_lv, h->d_pyr, d_kps, d_desc, d_n, sp, rows, h->d_rowOff, h->d_rowList, d_u, d_d, h->d_sadDist,
+                 d_nm, n_pairs);
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+}  // namespace
+
+int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out,
+                             int capacity, float bf, float b, float* d_u_right, float* d_depth, int* d_n_matched) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_kps || !d_desc || !d_n_out || !d_u_right || !d_depth || !d_n_matched || capacity < 1)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer or capacity < 1");
+    return stereoEnqueue(h, n_pairs, (const Keypoint*)d_kps, d_desc, d_n_out, capacity, bf, b, d_u_right, d_depth, d_n_matched);
+}
+
+int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
+                           int* n_matched) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!u_right || !depth || !n_matched || capacity < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer or capacity < 1");
+    const int cap = h->outCap;
+    int rc = stereoEnsure(h, n_pairs, cap, h->geom.rows > 0 ? h->geom.rows : 1);
+    if (rc != ORBX_OK) return rc;
+    rc = stereoEnqueue(h, n_pairs, h->d_outK, h->d_outD, h->d_nOut, cap, bf, b, h->d_uRight, h->d_depth, h->d_nMatched);
+    if (rc != ORBX_OK) return rc;
+    std::vector<float> hu((size_t)n_pairs * cap), hd((size_t)n_pairs * cap);
+    HIP_TRY(h, hipMemcpyAsync(hu.data(), h->d_uRight, hu.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(hd.data(), h->d_depth, hd.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(n_matched, h->d_nMatched, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int p = 0; p < n_pairs; p++) {
+        const int n = h->h_nOut[2 * p];      // left keypoints of this pair, from the last orbx_extract_batch
+        if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity smaller than the left keypoint count");
+        std::memcpy(u_right + (size_t)p * capacity, hu.data() + (size_t)p * cap, sizeof(float) * n);
+        std::memcpy(depth + (size_t)p * capacity, hd.data() + (size_t)p * cap, sizeof(float) * n);
+    }
     return ORBX_OK;
 }
 

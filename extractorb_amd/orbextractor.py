@@ -85,6 +85,8 @@ def load_library():
     L.orbx_extract_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp,
                                             C.c_int, vp, vp, vp, vp]
     L.orbx_get_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, ip, ip]
+    L.orbx_stereo_match_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+    L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_set_stream.argtypes = [vp, vp]
     L.orbx_get_stream.restype = vp
     L.orbx_get_stream.argtypes = [vp]
@@ -242,6 +244,22 @@ class ORBextractor:
         self._check(self._L.orbx_extract_batch_device(self._h, n_frames, dp(d_images), rows, cols, stride, frame_stride,
                                                       _ptr(lap), dp(d_kps), dp(d_desc), capacity, dp(d_n), dp(d_mono),
                                                       dp(d_level_kps), dp(d_level_counts)))
+
+    # ---- Frame::ComputeStereoMatches (reference src/Frame.cc:813-991) on the last batch ----
+    def stereo_match_last(self, n_pairs, bf, b):
+        """Frames 2p / 2p+1 of the last extract_batch call are the left / right eye of pair p.
+        Returns a list of (uRight[nL], depth[nL], n_matched) per pair."""
+        cap = self.capacity
+        u = np.zeros((n_pairs, cap), np.float32); d = np.zeros((n_pairs, cap), np.float32)
+        nm = np.zeros(n_pairs, np.int32)
+        self._check(self._L.orbx_stereo_match_last(self._h, n_pairs, bf, b, _ptr(u), _ptr(d), cap, _ptr(nm)))
+        return u, d, nm
+
+    def stereo_match_device(self, n_pairs, d_kps, d_desc, d_n, capacity, bf, b, d_u_right, d_depth, d_n_matched):
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self._L.orbx_stereo_match_device(self._h, n_pairs, dp(d_kps), dp(d_desc), dp(d_n), capacity, bf, b,
+                                                     dp(d_u_right), dp(d_depth), dp(d_n_matched)))
 
     def set_stream(self, stream_ptr):
         self._check(self._L.orbx_set_stream(self._h, C.c_void_p(int(stream_ptr))))

@@ -127,6 +127,23 @@ int orbx_extract_batch_device(orbx_handle* h, int n_frames, const uint8_t* d_img
 int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride,
                    int* width, int* height);
 
+/* ---- next row beyond the extractor ------------------------------------------------------
+ * Replaces Frame::ComputeStereoMatches() (reference src/Frame.cc:813-991) for stereo pairs extracted by ONE
+ * batched call on this handle: frame 2p is the left eye, frame 2p+1 the right eye (n_frames = 2*n_pairs).
+ * It consumes that call's keypoints/descriptors and the two eyes' image pyramids, which are still in HBM (the
+ * reference reads mpORBextractorLeft/Right->mvImagePyramid for the 11x11 SAD refinement, Frame.cc:910,929).
+ *   bf, b : Frame::mbf and Frame::mb (baseline*fx and baseline; minZ = b, maxD = bf/b, Frame.cc:843-845)
+ *   u_right[p*capacity + i], depth[p*capacity + i] : mvuRight / mvDepth of left keypoint i (-1 = no match)
+ *   n_matched[p] : matches that survive the median filter
+ * orbx_stereo_match_device takes the device buffers an orbx_extract_batch_device call filled (and is asynchronous
+ * on the handle's stream); orbx_stereo_match_last uses the results of the last orbx_extract_batch call, which the
+ * handle keeps in HBM, and returns host arrays. */
+int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d_kps, const uint8_t* d_desc,
+                             const int* d_n_out, int capacity, float bf, float b, float* d_u_right, float* d_depth,
+                             int* d_n_matched);
+int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
+                           int* n_matched);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

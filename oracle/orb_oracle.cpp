@@ -745,6 +745,135 @@ void oracle_describe(const uint8_t* blurredImg, int step, float x, float y, floa
     Oracle::computeOrbDescriptor(kp, blurredImg, step, desc32);
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Next" row: Frame::ComputeStereoMatches, reference src/Frame.cc:813-991, restated on the
+// two oracle extractors that produced the left and right features.  Same test-infrastructure status as the rest.
+// ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2349-2365) is the 256-bit Hamming distance.
+// ---------------------------------------------------------------------------------------------
+static int descriptorDistance(const uint8_t* a, const uint8_t* b) {
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        std::memcpy(&pa, a + 4 * i, 4); std::memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// Returns the number of left keypoints that kept a stereo match.
+int oracle_stereo_match(void* hL, void* hR, const void* kpsL_, const uint8_t* descL, int N, const void* kpsR_,
+                        const uint8_t* descR, int Nr, float mbf, float mb, float* mvuRight, float* mvDepth) {
+    const Oracle* oL = (const Oracle*)hL;
+    const Oracle* oR = (const Oracle*)hR;
+    const KeyPoint* mvKeys = (const KeyPoint*)kpsL_;
+    const KeyPoint* mvKeysRight = (const KeyPoint*)kpsR_;
+    const std::vector<float>& mvScaleFactors = oL->mvScaleFactor;
+    const std::vector<float>& mvInvScaleFactors = oL->mvInvScaleFactor;
+    for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+    const int TH_HIGH = 100, TH_LOW = 50;                      // ORBmatcher.cc:36-37
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = oL->pyr[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const KeyPoint& kp = mvKeysRight[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * mvScaleFactors[kp.octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // (the reference does not guard; keypoints stay >= 17*scale inside)
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    auto levelAt = [](const Oracle* o, int level, int y, int x) -> int {
+        const Level& L = o->pyr[level];
+        return L.interior()[(ptrdiff_t)y * L.stride() + x];     // the Mats are views into the bordered buffers
+    };
+    for (int iL = 0; iL < N; iL++) {
+        const KeyPoint& kpL = mvKeys[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        if ((int)vL < 0 || (int)vL >= nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KeyPoint& kpR = mvKeysRight[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = descriptorDistance(dL, descR + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = mvKeysRight[bestIdxR].x;
+            const float scaleFactor = mvInvScaleFactors[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            int IL[11][11];
+            {
+                const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
+                for (int a = 0; a < 11; a++)
+                    for (int b2 = 0; b2 < 11; b2++) IL[a][b2] = levelAt(oL, kpL.octave, y0 + a, x0 + b2);
+                const int c = IL[w][w];
+                for (int a = 0; a < 11; a++) for (int b2 = 0; b2 < 11; b2++) IL[a][b2] -= c;
+            }
+            int bestDistS = 2147483647, bestincR = 0;
+            std::vector<float> vDists(2 * L + 1);
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= oR->pyr[kpL.octave].w) continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduR0 + incR - w);
+                int IR[11][11];
+                for (int a = 0; a < 11; a++)
+                    for (int b2 = 0; b2 < 11; b2++) IR[a][b2] = levelAt(oR, kpL.octave, y0 + a, x0 + b2);
+                const int c = IR[w][w];
+                double norm = 0;
+                for (int a = 0; a < 11; a++) for (int b2 = 0; b2 < 11; b2++) norm += std::abs(IL[a][b2] - (IR[a][b2] - c));
+                const float dist = (float)norm;
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;       // the reference indexes vDistIdx[0] here (undefined for an empty vector)
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1;
+        mvDepth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
+}
+int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptorDistance(a, b); }
+
 // ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,
 // the reference's own execution model per Frame.cc:109-112); returns wall seconds. ------------
 double oracle_time_frames(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,

@@ -64,6 +64,10 @@ def lib():
         L.oracle_sincos_check.restype = C.c_long
         L.oracle_sincos_check.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_long)]
         L.oracle_describe.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, vp]
+        L.oracle_stereo_match.restype = C.c_int
+        L.oracle_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp]
+        L.oracle_descriptor_distance.restype = C.c_int
+        L.oracle_descriptor_distance.argtypes = [vp, vp]
         L.oracle_time_frames.restype = C.c_double
         L.oracle_time_frames.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -144,6 +148,22 @@ class Oracle:
         if n:
             self.L.oracle_get_level_keys(self.h, level, _ptr(out))
         return out
+
+
+def stereo_match(o_left, o_right, kps_l, desc_l, kps_r, desc_r, bf, b):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:813-991) on two Oracle instances that just extracted
+    the left / right image.  Returns (uRight[N], depth[N], matches_kept)."""
+    kps_l = np.ascontiguousarray(kps_l, KEYPOINT_DTYPE); kps_r = np.ascontiguousarray(kps_r, KEYPOINT_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8); desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    u = np.zeros(len(kps_l), np.float32); d = np.zeros(len(kps_l), np.float32)
+    kept = lib().oracle_stereo_match(o_left.h, o_right.h, _ptr(kps_l), _ptr(desc_l), len(kps_l), _ptr(kps_r), _ptr(desc_r),
+                                     len(kps_r), float(bf), float(b), _ptr(u), _ptr(d))
+    return u, d, kept
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_descriptor_distance(_ptr(a), _ptr(b))
 
 
 def resize_linear(src, dw, dh):
