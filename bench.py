@@ -32,6 +32,10 @@ WORKLOADS = {
     # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
     "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="noise",
                       desc="stereo 640x480 L+R pairs (128 pairs per step), 8 levels, 1200 features per eye"),
+    # configs[3] + the reference's next step on a stereo frame, Frame::ComputeStereoMatches, fed from HBM
+    "stereo640_match": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="stereo", match=True,
+                            desc="stereo 640x480 L+R pairs (128 pairs per step, right eye = left shifted by 6..40 px), 8 levels, "
+                                 "1200 features per eye, extraction + ComputeStereoMatches"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -73,7 +77,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- inputs: this rank's B frames of the stream, generated on the host, parked in HBM ----
-    frames = synth.frames(variant, rank * B, B, rows, cols)
+    if variant == "stereo":      # L/R pairs cut from one wider textured frame: a true disparity for the matcher to find
+        pairs = []
+        for p in range(B // 2):
+            big = synth.textured_frame(rank * B + p, rows, cols + 80)
+            disp = 6 + (p * 7) % 35
+            pairs += [big[:, 40:40 + cols], big[:, 40 + disp:40 + disp + cols]]
+        frames = np.ascontiguousarray(np.stack(pairs))
+    else:
+        frames = synth.frames(variant, rank * B, B, rows, cols)
     d_img = torch.from_numpy(frames).cuda()
     ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank)
     stream = torch.cuda.current_stream()
@@ -84,6 +96,10 @@ def main():
     off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
     slab = torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda")
     base = slab.data_ptr()
+    match = bool(wl.get("match"))
+    if match:
+        d_u = torch.zeros((B // 2, cap), dtype=torch.float32, device="cuda"); d_z = torch.zeros_like(d_u)
+        d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
     gathered = None
     if distributed and not args.no_gather and rank == 0:
         gathered = [torch.empty_like(slab) for _ in range(world)]
@@ -91,6 +107,8 @@ def main():
     def step():
         ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
                                 lapping=wl["lapping"])
+        if match:
+            ex.stereo_match_device(B // 2, base + off_k, base + off_d, base + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
         if distributed and not args.no_gather:
             dist.gather(slab, gathered, dst=0)
 
@@ -123,6 +141,8 @@ def main():
         for _ in range(psteps):
             ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
                                     lapping=wl["lapping"])
+            if match:
+                ex.stereo_match_device(B // 2, base + off_k, base + off_d, base + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
         prof = ex.profile_read()
         ex.profile(False)
         kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
@@ -166,6 +186,7 @@ def main():
                        "global_frames_per_step": N * B, "nfeatures": nf, "nlevels": 8, "scale_factor": 1.2,
                        "fast_thresholds": [20, 7], "lapping": list(wl["lapping"]),
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
+                       **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0" if (distributed and not args.no_gather) else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }

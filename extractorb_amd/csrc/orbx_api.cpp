@@ -43,9 +43,10 @@ using namespace orbx;
 static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
 
 namespace {
-enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL };
+enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_SPARE };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
-                                            "k_octree", "k_describe", "memset+copies", "batch_total"};
+                                            "k_octree", "k_describe", "memset+copies", "batch_total",
+                                            "k_stereo_rows+match+filter", "spare"};
 thread_local std::string g_createError;
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -630,8 +631,11 @@ int stereoEnqueue(orbx_handle* h, int n_pairs, const Keypoint* d_kps, const uint
     StereoParams sp;
     for (int l = 0; l < kMaxLevels; l++) { sp.scale[l] = l < h->nlevels ? h->tabs.scale[l] : 1.f; sp.invScale[l] = l < h->nlevels ? h->tabs.invScale[l] : 1.f; }
     sp.bf = bf; sp.b = b; sp.nlevels = h->nlevels; sp.capacity = capacity; sp.rowCap = h->stereoCap * bandRows(h);
-    launchStereo(h->stream, h->d_lv, h->d_pyr, d_kps, d_desc, d_n, sp, rows, h->d_rowOff, h->d_rowList, d_u, d_d, h->d_sadDist,
-                 d_nm, n_pairs);
+    {
+        Prof p(h, S_STEREO);
+        launchStereo(h->stream, h->d_lv, h->d_pyr, d_kps, d_desc, d_n, sp, rows, h->d_rowOff, h->d_rowList, d_u, d_d, h->d_sadDist,
+                     d_nm, n_pairs);
+    }
     HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
 }

@@ -22,7 +22,7 @@ assert KEYPOINT_DTYPE.itemsize == 28
 
 ORBX_OK = 0
 ORBX_ERR_EMPTY_IMAGE = -1
-ORBX_NUM_KERNELS = 8
+ORBX_NUM_KERNELS = 10
 
 
 class OrbxError(RuntimeError):

@@ -163,7 +163,7 @@ int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, p
 
 /* Per-kernel timing with HIP events on the handle's stream.  enable=1 brackets every kernel launch of
  * subsequent extract calls with events (adds launch overhead: use for attribution, not for fps). */
-#define ORBX_NUM_KERNELS 8
+#define ORBX_NUM_KERNELS 10
 int orbx_profile_enable(orbx_handle* h, int enable);
 int orbx_profile_reset(orbx_handle* h);
 /* Resolves pending events; fills total milliseconds and launch counts per kernel slot. */
