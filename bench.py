@@ -94,25 +94,36 @@ def main():
     # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
     lay = sharding.slab_layout(B, cap)
     off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
-    slab = torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda")
-    base = slab.data_ptr()
+    # two slabs: while step k's results travel to rank 0, step k+1 already computes into the other one
+    slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+    slab = slabs[0]
     match = bool(wl.get("match"))
     if match:
         d_u = torch.zeros((B // 2, cap), dtype=torch.float32, device="cuda"); d_z = torch.zeros_like(d_u)
         d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
     gathered = None
-    if distributed and not args.no_gather and rank == 0:
-        gathered = [torch.empty_like(slab) for _ in range(world)]
+    gather = distributed and not args.no_gather
+    if gather and rank == 0:
+        gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(2)]
+    pending = [None]
+    counter = [0]
 
     def step():
-        ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
-                                lapping=wl["lapping"])
+        k = counter[0] & 1
+        counter[0] += 1
+        b = slabs[k].data_ptr()
+        ex.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
         if match:
-            ex.stereo_match_device(B // 2, base + off_k, base + off_d, base + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
-        if distributed and not args.no_gather:
-            dist.gather(slab, gathered, dst=0)
+            ex.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
+        if gather:
+            if pending[0] is not None:
+                pending[0].wait()          # the previous step's slab has arrived; its buffer may be overwritten next step
+            pending[0] = dist.gather(slabs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
 
     def fence():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -130,7 +141,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_host = slab[off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
+    base = slabs[0].data_ptr()
+    n_host = slabs[0][off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
     fps = N * B * args.steps / elapsed
 
     result = None
@@ -187,7 +199,7 @@ def main():
                        "fast_thresholds": [20, 7], "lapping": list(wl["lapping"]),
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
-                       "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0" if (distributed and not args.no_gather) else "")},
+                       "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
