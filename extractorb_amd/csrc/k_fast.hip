@@ -81,8 +81,7 @@ template <int TS, int ROWS>
 __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                               unsigned* __restrict__ candPos, unsigned* __restrict__ candOrd,
-                                               unsigned* __restrict__ candCount) {
+                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
     constexpr int DW = TS / 4;                        // dwords per tile row
@@ -165,13 +164,15 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
     // the reference retries the cell at minThFAST only when the first call returned nothing (:835-838)
     const bool useIni = nIni > 0;
     const int total = useIni ? nIni : nMin;
+    // every cell owns a fixed, exactly sized segment of the level's candidate arena (no two 8-adjacent NMS survivors
+    // => at most ceil(cw/2)*ceil(ch/2) of them), so the emit needs no atomic; the quad-tree kernel compacts the
+    // segments in cell order, which is the reference's vToDistributeKeys order (cell row, cell column, y, x)
+    if (lane == 0) cellCount[(long long)f * nCells + ci] = (unsigned)total;
     if (total == 0) return;
     waveLdsSync();
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&candCount[f * nlevels + c.level], (unsigned)total);
-    base = __builtin_amdgcn_readfirstlane(base);
-    unsigned* outPos = candPos + g.candOff + (long long)f * g.candCap;
-    unsigned* outOrd = candOrd + g.candOff + (long long)f * g.candCap;
+    unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
+    const unsigned segCap = (unsigned)(((cw + 1) >> 1) * ((ch + 1) >> 1));
     const int th = useIni ? iniTh : minTh;
     for (int i0 = 0; i0 < nMin; i0 += 64) {
         const unsigned e = i0 + lane < nMin ? list[i0 + lane] : 0u;
@@ -180,24 +181,22 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const unsigned at = base + __popcll(m & ((1ull << lane) - 1));
-            if (at < (unsigned)g.candCap) {
+            if (at < segCap)
                 outPos[at] = (unsigned)(c.shiftX + x + 3) | ((unsigned)(c.shiftY + y + 3) << 12) | ((unsigned)(s - 1) << 24);   // response = S - 1
-                outOrd[at] = ((unsigned)c.cellId << 12) | ((unsigned)y << 6) | (unsigned)x;    // reference list order
-            }
         }
         base += __popcll(m);
     }
 }
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
-                const uint8_t* pyr, int iniTh, int minTh, unsigned* candPos, unsigned* candOrd, unsigned* candCount,
-                int maxRoiW, int maxRoiH, int B) {
+                const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
+                int B) {
     const dim3 grid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
     if (maxRoiW <= 45 && maxRoiH <= 45)
-        hipLaunchKernelGGL((k_fast<48, 45>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candPos, candOrd, candCount);
+        hipLaunchKernelGGL((k_fast<48, 45>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
     else   // cells up to 63 px (the geometry code rejects larger ones)
-        hipLaunchKernelGGL((k_fast<72, 69>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candPos, candOrd, candCount);
+        hipLaunchKernelGGL((k_fast<72, 69>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
 }
 
 // unpack one level's candidates into reference KeyPoints (introspection for tests)

@@ -137,9 +137,11 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 }
 
 __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __restrict__ lv, int nlevels,
-                                                         const unsigned* __restrict__ candPos,
-                                                         const unsigned* __restrict__ candOrd,
-                                                         const unsigned* __restrict__ candCount,
+                                                         const CellDesc* __restrict__ cells, int nCellsTotal,
+                                                         const unsigned* __restrict__ candSeg,
+                                                         const unsigned* __restrict__ cellCount,
+                                                         int* __restrict__ cellOff, unsigned* __restrict__ candPos,
+                                                         unsigned* __restrict__ candCount,
                                                          unsigned short* __restrict__ nodeOf,
                                                          uint2* __restrict__ sel, int selPerFrame,
                                                          int* __restrict__ levelCount, int* __restrict__ levelLap,
@@ -172,14 +174,37 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
     uint8_t* xcode = (uint8_t*)(cell + R * kLeaves);  // [XT] root << kD0 | x path of every x of the rectangle
     uint8_t* ycode = xcode + XT;                      // [XT] y path of every y
 
-    int nC = (int)candCount[f * nlevels + level];
-    nC = nC > g.candCap ? g.candCap : nC;
+    // ---- compaction plan: exclusive scan of this level's per-cell candidate counts (cells are in the reference's
+    //      loop order, so the compacted array IS vToDistributeKeys, :786-864) ----
     const long long base = g.candOff + (long long)f * g.candCap;
-    const unsigned* pos = candPos + base;
-    const unsigned* ord = candOrd + base;
+    const unsigned* seg = candSeg + base;             // per-cell segments written by k_fast
+    unsigned* pos = candPos + base;                   // compacted (x | y << 12 | response << 24), written below
     unsigned short* nof = nodeOf + base;
     uint2* selOut = sel + (long long)f * selPerFrame + g.selOff;
     const int N = g.quota;
+    const int cN = g.cellCount;
+    const CellDesc* cd0 = cells + g.cellFirst;
+    const unsigned* cc = cellCount + (long long)f * nCellsTotal + g.cellFirst;
+    int* co = cellOff + (long long)f * nCellsTotal + g.cellFirst;
+    int nC;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int per = (cN + kOctThreads - 1) / kOctThreads, b = tid * per, e = min(b + per, cN);
+        int sum = 0;
+        for (int i = b; i < e; i++) sum += (int)cc[i];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) sh.scanTmp[wave] = (unsigned)incl;
+        __syncthreads();
+        int waveOff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kOctWaves; w++) { const int t = (int)sh.scanTmp[w]; if (w < wave) waveOff += t; total += t; }
+        int run = waveOff + incl - sum;
+        for (int i = b; i < e; i++) { co[i] = run; run += (int)cc[i]; }
+        nC = total > g.candCap ? 0 : total;           // the segments are exactly sized: total <= candCap always
+        if (tid == 0) candCount[f * nlevels + level] = (unsigned)nC;
+    }
 
     // ---- roots (:548-575); empty roots are dropped by the first pass (:577-590) ----
     if (tid < g.nIni) {
@@ -204,20 +229,35 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
     if (dense)
         for (int i = tid; i < g.nIni * kHistPerRoot; i += kOctThreads) hist[i] = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
-        unsigned w[kOctUnroll];
+    // ---- first sweep: a wave per cell gathers the cell's segment into the compacted array and, in the same visit,
+    //      assigns the key to its root / dense-phase leaf cell ----
+    constexpr int kCellsPerTrip = 8;   // small enough that 16 waves share even a 100-cell level evenly
+    for (int c0 = (tid >> 6) * kCellsPerTrip; c0 < cN && nC > 0; c0 += kOctWaves * kCellsPerTrip) {
+        // The wave takes 8 consecutive cells.  Their keys are consecutive in the compacted array, so lanes walk the
+        // concatenation of the 8 segments at full width; which segment a key sits in is 7 compares against
+        // wave-uniform prefix counts held in scalar registers.
+        const int lane = tid & 63, cj = c0 + (lane & (kCellsPerTrip - 1));
+        const int nj = cj < cN ? (int)cc[cj] : 0, sj = cj < cN ? cd0[cj].segOff : 0, oj = cj < cN ? co[cj] : 0;
+        int pre[kCellsPerTrip + 1], D[kCellsPerTrip];
+        pre[0] = 0;
 #pragma unroll
-        for (int u = 0; u < kOctUnroll; u++) {
-            const int k = k0 + u * kOctThreads + tid;
-            w[u] = k < nC ? pos[k] : 0u;
+        for (int j = 0; j < kCellsPerTrip; j++) {
+            pre[j + 1] = pre[j] + __builtin_amdgcn_readlane(nj, j);
+            D[j] = __builtin_amdgcn_readlane(sj, j) - pre[j];       // source slot = D[j] + (index inside the 8 cells)
         }
-#pragma unroll
-        for (int u = 0; u < kOctUnroll; u++) {
-            const int k = k0 + u * kOctThreads + tid;
-            const bool active = k < nC;
+        const int k0 = __builtin_amdgcn_readlane(oj, 0), T8 = pre[kCellsPerTrip];
+        for (int i0 = 0; i0 < T8; i0 += 64) {
+            const int i = i0 + lane;
+            const bool active = i < T8;
             int r = 0, q = 0;
             if (active) {
-                const int x = w[u] & 0xfff, y = (w[u] >> 12) & 0xfff;
+                int src = i + D[0];
+#pragma unroll
+                for (int j = 1; j < kCellsPerTrip; j++) src = i >= pre[j] ? i + D[j] : src;
+                const unsigned w = seg[src];
+                const int k = k0 + i;
+                pos[k] = w;
+                const int x = w & 0xfff, y = (w >> 12) & 0xfff;
                 if (dense) {
                     const int xc = xcode[min(x, g.rectW - 1)], yc = ycode[min(y, g.rectH - 1)];
                     const int leaf = (yc << kD0) | (xc & ((1 << kD0) - 1));      // row-major leaf cell of the root
@@ -455,7 +495,7 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
                 }
                 __syncthreads();
                 for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
-                    unsigned w[kOctUnroll], od[kOctUnroll];
+                    unsigned w[kOctUnroll];
                     int nd[kOctUnroll];
 #pragma unroll
                     for (int u = 0; u < kOctUnroll; u++) {
@@ -463,14 +503,14 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
                         const bool active = k < nC;
                         w[u] = active ? pos[k] : 0u;
                         nd[u] = active ? (int)nof[k] : 0;
-                        od[u] = active ? ord[k] : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < kOctUnroll; u++) {
                         const int k = k0 + u * kOctThreads + tid;
                         const bool active = k < nC;
                         const int nn = active ? (int)cell[nd[u]] : 0;
-                        const unsigned long long v = ((unsigned long long)(w[u] >> 24) << 56) | ((unsigned long long)(~od[u]) << 24) |
+                        // max response, then smallest candidate index (= first in the reference's vector)
+                        const unsigned long long v = ((unsigned long long)(w[u] >> 24) << 56) | ((unsigned long long)(~(unsigned)k) << 24) |
                                                      (unsigned long long)(w[u] & 0xffffff);
                         maxPerNode(best, active, nn, v);
                     }
@@ -482,7 +522,7 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
         __syncthreads();
         // ---- the sweep: rename every key's node; count it for the next pass, or take the arg-max ----
         for (int k0 = 0; k0 < nC; k0 += kOctUnroll * kOctThreads) {
-            unsigned w[kOctUnroll], od[kOctUnroll];
+            unsigned w[kOctUnroll];
             int nd[kOctUnroll];
 #pragma unroll
             for (int u = 0; u < kOctUnroll; u++) {   // all loads of the iteration in flight together
@@ -490,7 +530,6 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
                 const bool active = k < nC;
                 w[u] = active ? pos[k] : 0u;
                 nd[u] = active ? (int)nof[k] : 0;
-                od[u] = (active && last) ? ord[k] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < kOctUnroll; u++) {
@@ -505,8 +544,8 @@ __global__ __launch_bounds__(kOctThreads, 8) void k_octree(const LevelGeom* __re
                     const bool split = phase2 ? fwd[n] >= 0 : cn[n] > 1;
                     nn = split ? mapChild[4 * n + quadrantOf(x, y, bx[n])] : mapKeep[n];
                     if (last) {
-                        // max response, then smallest candidate order word (= first in the reference's vector)
-                        v = ((unsigned long long)(w[u] >> 24) << 56) | ((unsigned long long)(~od[u]) << 24) |
+                        // max response, then smallest candidate index (= first in the reference's vector)
+                        v = ((unsigned long long)(w[u] >> 24) << 56) | ((unsigned long long)(~(unsigned)k) << 24) |
                             (unsigned long long)(w[u] & 0xffffff);
                     } else {
                         nof[k] = (unsigned short)nn;
@@ -582,11 +621,12 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
     b += 2 * (size_t)XT;                            // xcode, ycode
     return b + 64;
 }
-void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const unsigned* candPos, const unsigned* candOrd,
-                  const unsigned* candCount, unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount,
-                  int* levelLap, const int* lapArea, int M, int P, int R, int XT, int B) {
-    hipLaunchKernelGGL(k_octree, dim3(B, nlevels), dim3(kOctThreads), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, candPos,
-                       candOrd, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT);
+void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
+                  const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
+                  unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
+                  int M, int P, int R, int XT, int B) {
+    hipLaunchKernelGGL(k_octree, dim3(B, nlevels), dim3(kOctThreads), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, cells,
+                       nCellsTotal, candSeg, cellCount, cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT);
 }
 
 }  // namespace orbx

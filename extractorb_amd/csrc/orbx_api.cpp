@@ -21,10 +21,10 @@ void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, con
                   uint8_t*, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                unsigned*, int, int, int);
+                int, int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
-void launchOctree(hipStream_t, const LevelGeom*, int, const unsigned*, const unsigned*, const unsigned*, unsigned short*,
-                  uint2*, int, int*, int*, const int*, int, int, int, int, int);
+void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
@@ -67,7 +67,9 @@ struct orbx_handle {
     // arenas (sized once)
     size_t pyrBytes = 0, blurBytes = 0, candEntries = 0, selEntries = 0, cellCap = 0, rxCap = 0, tileCap = 0;
     uint8_t *d_input = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
-    unsigned *d_candPos = nullptr, *d_candOrd = nullptr;   // packed (x,y,response) / reference list-order word
+    unsigned *d_candPos = nullptr, *d_candSeg = nullptr;   // packed (x,y,response): compacted / per-cell segments
+    unsigned* d_cellCount = nullptr;                      // [frame][cell] candidates emitted by k_fast
+    int* d_cellOff = nullptr;                             // [frame][cell] offset of the cell in the compacted array
     unsigned short* d_nodeOf = nullptr;
     unsigned* d_candCount = nullptr;
     uint2* d_sel = nullptr;
@@ -124,7 +126,7 @@ int fail(orbx_handle* h, int code, const std::string& msg) {
 int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
-    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candOrd, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
+    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
@@ -232,10 +234,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             h->lapCached = want;
         }
     }
-    {
-        Prof p(h, S_MISC);
-        HIP_TRY(h, hipMemsetAsync(h->d_candCount, 0, sizeof(unsigned) * B * g.nlevels, st));
-    }
     {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
         Prof p(h, S_LEVEL0);
         launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
@@ -250,12 +248,13 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     {
         Prof p(h, S_FAST);
-        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candPos,
-                   h->d_candOrd, h->d_candCount, g.maxRoiW, g.maxRoiH, B);
+        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
+                   h->d_cellCount, g.maxRoiW, g.maxRoiH, B);
     }
     {
         Prof p(h, S_OCTREE);
-        launchOctree(st, h->d_lv, g.nlevels, h->d_candPos, h->d_candOrd, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
+        launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
+                     h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                      h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, B);
     }
     {
@@ -391,7 +390,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_pyr, h->pyrBytes));
     CREATE_TRY(hipMalloc(&h->d_blur, h->blurBytes));
     CREATE_TRY(hipMalloc(&h->d_candPos, h->candEntries * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc(&h->d_candOrd, h->candEntries * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc(&h->d_candSeg, h->candEntries * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc(&h->d_cellCount, sizeof(unsigned) * h->cellCap * max_batch));
+    CREATE_TRY(hipMalloc(&h->d_cellOff, sizeof(int) * h->cellCap * max_batch));
     CREATE_TRY(hipMalloc(&h->d_nodeOf, h->candEntries * sizeof(unsigned short)));
     CREATE_TRY(hipMalloc(&h->d_candCount, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_sel, h->selEntries * sizeof(uint2)));

@@ -53,8 +53,9 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
     short shiftX, shiftY;     // j*wCell, i*hCell (ORBextractor.cc:857-858)
     short pad;
     int cellId;               // i*nCols + j: raster rank of the cell inside its level
+    int segOff;               // first slot of this cell's candidate segment inside the level's per-frame arena
 };
-static_assert(sizeof(CellDesc) == 20, "CellDesc layout");
+static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
 
 // Source footprint of one 256 x 32 destination tile of the resize kernel (host-computed from the coefficient tables)
 struct TileFoot { short fx0, nDw, fy0, nRows; };   // first source column (multiple of 4), dwords per row, first row, rows

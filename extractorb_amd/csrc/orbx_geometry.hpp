@@ -163,6 +163,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                 c.shiftX = (short)(j * L.wCell); c.shiftY = (short)(i * L.hCell);
                 c.pad = 0;
                 c.cellId = i * L.nCols + j;
+                c.segOff = (int)cap;     // cells own consecutive, exactly sized segments in the reference's loop order
                 if (c.roiW < 7 || c.roiH < 7) continue;   // cv::FAST tests nothing on such an ROI
                 g.cells.push_back(c);
                 if (c.roiW > g.maxRoiW) g.maxRoiW = c.roiW;
