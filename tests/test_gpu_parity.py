@@ -220,3 +220,42 @@ def test_randomised_sizes_and_parameters():
         mono, k, d, lvl = ex(img, None, lap)
         check_stages(ex, o, lvl)
         assert_same_result((mono, k, d), want, "random case %d: %dx%d nf=%d %s lap=%s" % (t, cols, rows, nf, variant, lap))
+
+
+def test_device_path_with_padded_rows_and_frames():
+    import torch
+    B, rows, cols, stride, fstride = 3, 300, 400, 448, 448 * 310
+    frames = synth.frames("textured", 7, B, rows, cols)
+    buf = np.zeros((B, fstride), np.uint8)
+    for f in range(B):
+        buf[f, :rows * stride].reshape(rows, stride)[:, :cols] = frames[f]
+    ex = X.ORBextractor(600, max_width=cols, max_height=rows, max_batch=B)
+    cap = ex.capacity
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_img = torch.from_numpy(buf).cuda()
+    d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_m = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_lk = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); d_lc = torch.zeros((B, 8), dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img, B, rows, cols, d_k, d_d, d_n, d_m, cap, stride=stride, frame_stride=fstride,
+                            lapping=(50, 250), d_level_kps=d_lk, d_level_counts=d_lc)
+    ex.synchronize()
+    n = d_n.cpu().numpy()
+    for f in range(B):
+        o, want = oracle_run(frames[f], 600, (50, 250))
+        k = d_k[f, :n[f]].cpu().numpy().view(np.uint8).reshape(-1, 28).copy().view(X.KEYPOINT_DTYPE).reshape(-1)
+        assert_same_result((int(d_m[f]), k, d_d[f, :n[f]].cpu().numpy()), want, "padded frame %d" % f)
+        assert d_lc[f].cpu().numpy().tolist() == [len(o.level_keypoints(l)) for l in range(8)]
+
+
+def test_profile_api_and_algorithmic_bytes():
+    ex = X.ORBextractor(1000, max_batch=4)
+    fr = synth.frames("noise", 0, 4, 480, 640)
+    ex.profile(True)
+    ex.extract_batch(fr)
+    ex.extract_batch(fr)
+    p = ex.profile_read()
+    assert p["k_fast"][1] == 2 and p["k_resize"][1] == 12 and p["k_octree"][1] == 2 and p["k_fast"][0] > 0
+    assert p["batch_total"][0] >= p["k_fast"][0]
+    ex.profile(False)
+    assert ex.algorithmic_bytes(480, 640, 1000) == 307200 + 2 * 950532 + 60000
+    assert ex.algorithmic_bytes(1080, 1920, 2000) == 2073600 + 2 * 6419321 + 120000

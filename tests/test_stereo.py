@@ -93,3 +93,18 @@ def test_gpu_stereo_batch_of_pairs_device_path():
         assert int(d_nm[p]) == kept_o
         assert d_u[p, :n].cpu().numpy().tobytes() == u_o.tobytes()
         assert d_z[p, :n].cpu().numpy().tobytes() == d_o.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_stereo_argument_errors():
+    left, right = stereo_pair(10)
+    ex = X.ORBextractor(1200, max_batch=2)
+    with pytest.raises(X.OrbxError):
+        ex.stereo_match_last(1, 40.0, 0.1)                 # nothing extracted yet
+    ex.extract_batch(np.stack([left, right]), lapping=(0, 0))
+    with pytest.raises(X.OrbxError):
+        ex.stereo_match_last(2, 40.0, 0.1)                 # only one pair in the last batch
+    with pytest.raises(X.OrbxError):
+        ex.stereo_match_last(1, 40.0, 0.0)                 # b must be positive (maxD = bf/b)
+    u, d, nm = ex.stereo_match_last(1, 40.0, 0.1)
+    assert nm[0] > 100
