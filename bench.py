@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: per workload)")
     ap.add_argument("--variant", default="", help="noise|textured|sparse (default: per workload)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave results on their GPUs")
+    ap.add_argument("--handles", type=int, default=1, help="extractor handles per GPU used round-robin, each on its own "
+                    "HIP stream (two cameras / ping-pong batches: small kernels of one overlap big kernels of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -87,15 +89,19 @@ def main():
     else:
         frames = synth.frames(variant, rank * B, B, rows, cols)
     d_img = torch.from_numpy(frames).cuda()
-    ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank)
+    nH = max(1, args.handles)
+    exs = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank) for _ in range(nH)]
+    ex = exs[0]
     stream = torch.cuda.current_stream()
-    ex.set_stream(stream.cuda_stream)
+    streams = [stream] + [torch.cuda.Stream() for _ in range(nH - 1)]
+    for e, st_ in zip(exs, streams):
+        e.set_stream(st_.cuda_stream)
     cap = ex.capacity
     # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
     lay = sharding.slab_layout(B, cap)
     off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
     # two slabs: while step k's results travel to rank 0, step k+1 already computes into the other one
-    slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+    slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda") for _ in range(max(2, nH))]
     slab = slabs[0]
     match = bool(wl.get("match"))
     if match:
@@ -109,13 +115,16 @@ def main():
     counter = [0]
 
     def step():
-        k = counter[0] & 1
+        k = counter[0] % len(slabs)
+        e_ = exs[counter[0] % nH]
         counter[0] += 1
         b = slabs[k].data_ptr()
-        ex.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
+        e_.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
         if match:
-            ex.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
+            e_.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
         if gather:
+            if nH > 1:
+                stream.wait_stream(streams[(counter[0] - 1) % nH])   # the collective is ordered after the CURRENT stream
             if pending[0] is not None:
                 pending[0].wait()          # the previous step's slab has arrived; its buffer may be overwritten next step
             pending[0] = dist.gather(slabs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
@@ -199,6 +208,7 @@ def main():
                        "fast_thresholds": [20, 7], "lapping": list(wl["lapping"]),
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
+                       "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
