@@ -64,3 +64,18 @@ def O_level(img, l):
     o = O.Oracle(1000)
     o.extract(img)
     return o.level(l)
+
+
+def test_parity_over_a_longer_stream():
+    # 96 frames (3 variants x 32) against the oracle: catches rare-path differences (rounding ties in the rotated
+    # pattern, response ties in the quad-tree, empty-cell retries) that a handful of frames may never reach
+    ex = X.ORBextractor(1000, max_batch=32)
+    total_kp = 0
+    for variant in ("noise", "textured", "sparse"):
+        fr = synth.frames(variant, 500, 32, 480, 640)
+        out = ex.extract_batch(fr)
+        o = O.Oracle(1000)
+        for f in range(32):
+            assert_same_result(out[f][:3], o.extract(fr[f]), "%s frame %d" % (variant, f))
+            total_kp += len(out[f][1])
+    assert total_kp > 70000
