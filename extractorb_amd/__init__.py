@@ -8,8 +8,9 @@ There is no CPU fallback: importing works anywhere (so the C ABI can be inspecte
 extractor without the built library or without a HIP device raises.
 """
 from .orbextractor import (KEYPOINT_DTYPE, ORBextractor, OrbxError, build_library, library_path, load_library,
-                           compute_tables, compute_level_sizes, compute_cell_grid, header_symbols)
+                           compute_tables, compute_level_sizes, compute_cell_grid, header_symbols, camera,
+                           compute_image_bounds)
 
 __all__ = ["KEYPOINT_DTYPE", "ORBextractor", "OrbxError", "build_library", "library_path", "load_library",
-           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols"]
+           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols", "camera", "compute_image_bounds"]
 __version__ = "0.1.0"

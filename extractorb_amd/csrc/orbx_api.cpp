@@ -33,6 +33,9 @@ struct StereoParams {
     float bf, b;
     int nlevels, capacity, rowCap;
 };
+struct CameraParams { float fx, fy, cx, cy, k1, k2, p1, p2, k3; };
+struct FrameFinishParams { CameraParams cam; float minX, minY, wInv, hInv; int capacity; };
+void launchFrameFinish(hipStream_t, const Keypoint*, const int*, const FrameFinishParams&, Keypoint*, int*, int*, int*, int);
 void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const StereoParams&,
                   int, int*, unsigned short*, float*, float*, int*, int*, int);
 void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
@@ -670,6 +673,63 @@ int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float
         std::memcpy(u_right + (size_t)p * capacity, hu.data() + (size_t)p * cap, sizeof(float) * n);
         std::memcpy(depth + (size_t)p * capacity, hd.data() + (size_t)p * cap, sizeof(float) * n);
     }
+    return ORBX_OK;
+}
+
+namespace {
+// cv::undistortPoints for one point, host twin of the device routine in k_frame.hip (same operation order, doubles;
+// this file is compiled with -ffp-contract=off)
+void undistortHost(const orbx_camera& c, float xin, float yin, float* xo, float* yo) {
+    const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy, ifx = 1. / fx, ify = 1. / fy;
+    const double k[12] = {c.k1, c.k2, c.p1, c.p2, c.k3, 0, 0, 0, 0, 0, 0, 0};
+    double x = xin, y = yin;
+    const double u = x, v = y;
+    x = (x - cx) * ifx; y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+    *xo = (float)(xx * ww); *yo = (float)(yy * ww);
+}
+}  // namespace
+
+int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float* b) {
+    if (!cam || !b || cols < 1 || rows < 1 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return ORBX_ERR_BAD_ARGUMENT;
+    if (cam->k1 != 0.0f) {
+        float m[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+        for (int i = 0; i < 4; i++) undistortHost(*cam, m[i][0], m[i][1], &m[i][0], &m[i][1]);
+        b[0] = m[0][0] < m[2][0] ? m[0][0] : m[2][0]; b[1] = m[1][0] > m[3][0] ? m[1][0] : m[3][0];
+        b[2] = m[0][1] < m[1][1] ? m[0][1] : m[1][1]; b[3] = m[2][1] > m[3][1] ? m[2][1] : m[3][1];
+    } else {
+        b[0] = 0.0f; b[1] = (float)cols; b[2] = 0.0f; b[3] = (float)rows;
+    }
+    return ORBX_OK;
+}
+
+int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
+                             const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
+                             int* d_grid_idx, int* d_n_inside) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_kps || !d_n_out || !cam || !bounds4 || !d_kps_un || !d_grid_off || !d_grid_idx || !d_n_inside || capacity < 1 ||
+        n_frames < 1 || !(cam->fx > 0.f) || !(cam->fy > 0.f) || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames < 1, non-positive focal length or empty bounds");
+    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
+    HIP_TRY(h, hipSetDevice(h->device));
+    FrameFinishParams p;
+    p.cam = CameraParams{cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+    p.minX = bounds4[0]; p.minY = bounds4[2];
+    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
+    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
+    p.capacity = capacity;
+    launchFrameFinish(h->stream, (const Keypoint*)d_kps, d_n_out, p, (Keypoint*)d_kps_un, d_grid_off, d_grid_idx, d_n_inside, n_frames);
+    HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
 }
 

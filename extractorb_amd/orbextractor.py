@@ -87,6 +87,8 @@ def load_library():
     L.orbx_get_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, ip, ip]
     L.orbx_stereo_match_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
+    L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_set_stream.argtypes = [vp, vp]
     L.orbx_get_stream.restype = vp
     L.orbx_get_stream.argtypes = [vp]
@@ -138,6 +140,21 @@ def compute_cell_grid(rows, cols, level, scale_factor=1.2, nlevels=8):
         raise OrbxError(rc, "orbx_compute_cell_grid")
     keys = ["n_cols", "n_rows", "w_cell", "h_cell", "n_cells", "n_ini", "cand_cap"]
     return dict(zip(keys, [x.value for x in v]))
+
+
+def camera(fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+    """orbx_camera: Frame::mK and Frame::mDistCoef as nine floats."""
+    return np.array([fx, fy, cx, cy, k1, k2, p1, p2, k3], np.float32)
+
+
+def compute_image_bounds(cam, cols, rows):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:784-811): (mnMinX, mnMaxX, mnMinY, mnMaxY).  Host only."""
+    L = load_library()
+    b = np.zeros(4, np.float32)
+    rc = L.orbx_compute_image_bounds(_ptr(np.ascontiguousarray(cam, np.float32)), cols, rows, _ptr(b))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_compute_image_bounds")
+    return b
 
 
 class ORBextractor:
@@ -260,6 +277,14 @@ class ORBextractor:
             return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
         self._check(self._L.orbx_stereo_match_device(self._h, n_pairs, dp(d_kps), dp(d_desc), dp(d_n), capacity, bf, b,
                                                      dp(d_u_right), dp(d_depth), dp(d_n_matched)))
+
+    def frame_finish_device(self, n_frames, d_kps, d_n, capacity, cam, bounds, d_kps_un, d_grid_off, d_grid_idx, d_n_inside):
+        """UndistortKeyPoints + AssignFeaturesToGrid (reference src/Frame.cc:748-782, 383-417) on device buffers."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        cam = np.ascontiguousarray(cam, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
+        self._check(self._L.orbx_frame_finish_device(self._h, n_frames, dp(d_kps), dp(d_n), capacity, _ptr(cam), _ptr(bounds),
+                                                     dp(d_kps_un), dp(d_grid_off), dp(d_grid_idx), dp(d_n_inside)))
 
     def set_stream(self, stream_ptr):
         self._check(self._L.orbx_set_stream(self._h, C.c_void_p(int(stream_ptr))))

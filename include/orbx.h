@@ -144,6 +144,27 @@ int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d
 int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
                            int* n_matched);
 
+/* ---- next row: the rest of the Frame constructor ------------------------------------------
+ * Frame::mK and Frame::mDistCoef as plain floats (fx, fy, cx, cy: src/Frame.cc:342-345; k1, k2, p1, p2[, k3]). */
+typedef struct orbx_camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;
+#define ORBX_GRID_COLS 64 /* FRAME_GRID_COLS, inc/Frame.h:40 */
+#define ORBX_GRID_ROWS 48 /* FRAME_GRID_ROWS, inc/Frame.h:39 */
+
+/* Replaces Frame::ComputeImageBounds (src/Frame.cc:784-811): bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY of a
+ * cols x rows image (the four corners undistorted when k1 != 0).  Host-only, no GPU touched. */
+int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float* bounds4);
+
+/* Replaces Frame::UndistortKeyPoints (src/Frame.cc:748-782) and Frame::AssignFeaturesToGrid (:383-417, the
+ * Nleft == -1 case) + PosInGrid (:726-736) for n_frames frames of device-resident extraction results:
+ *   d_kps_un[f*capacity + i]            : mvKeysUn
+ *   d_grid_off[f*(64*48+1) + x*48 + y]  : first slot of mGrid[x][y]; [.. + 64*48] = keypoints inside the grid
+ *   d_grid_idx[f*capacity + slot]       : keypoint indices, increasing inside a cell (push_back order)
+ *   d_n_inside[f]
+ * bounds4 as returned by orbx_compute_image_bounds.  Asynchronous on the handle's stream. */
+int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
+                             const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
+                             int* d_grid_idx, int* d_n_inside);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

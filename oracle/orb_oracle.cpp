@@ -874,6 +874,79 @@ int oracle_stereo_match(void* hL, void* hR, const void* kpsL_, const uint8_t* de
 }
 int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptorDistance(a, b); }
 
+// ---------------------------------------------------------------------------------------------
+// "Next" row: what the Frame constructor does with the extracted keypoints —
+// Frame::UndistortKeyPoints (src/Frame.cc:748-782), ComputeImageBounds (:784-811), AssignFeaturesToGrid (:383-417)
+// with PosInGrid (:726-736).  cv::undistortPoints is OpenCV again (not vendored): restated here as the 3.4.x
+// cvUndistortPointsInternal path for a 4/5-coefficient model, no rectification, P = K: five fixed-point iterations
+// in double, then re-projection.
+// ---------------------------------------------------------------------------------------------
+struct Camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; };
+
+static void undistortPoint(const Camera& c, float xin, float yin, float* xo, float* yo) {
+    const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy, ifx = 1. / fx, ify = 1. / fy;
+    double k[12] = {c.k1, c.k2, c.p1, c.p2, c.k3, 0, 0, 0, 0, 0, 0, 0};
+    double x = xin, y = yin;
+    const double u = x, v = y;
+    x = (x - cx) * ifx; y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+    *xo = (float)(xx * ww); *yo = (float)(yy * ww);
+}
+
+// bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY
+void oracle_image_bounds(const void* cam_, int cols, int rows, float* bounds) {
+    const Camera& c = *(const Camera*)cam_;
+    if (c.k1 != 0.0) {
+        float m[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+        for (int i = 0; i < 4; i++) undistortPoint(c, m[i][0], m[i][1], &m[i][0], &m[i][1]);
+        bounds[0] = std::min(m[0][0], m[2][0]); bounds[1] = std::max(m[1][0], m[3][0]);
+        bounds[2] = std::min(m[0][1], m[1][1]); bounds[3] = std::max(m[2][1], m[3][1]);
+    } else {
+        bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+    }
+}
+
+// mvKeysUn, and mGrid as CSR over cells x*48+y (x < 64, y < 48): gridOff[3073], gridIdx[N] (keypoint indices in
+// increasing order inside a cell, as push_back leaves them).  Returns the number of keypoints inside the grid.
+int oracle_frame_finish(const void* cam_, const void* kps_, int N, const float* bounds, void* kpsUn_, int* gridOff, int* gridIdx) {
+    const Camera& c = *(const Camera*)cam_;
+    const KeyPoint* mvKeys = (const KeyPoint*)kps_;
+    KeyPoint* mvKeysUn = (KeyPoint*)kpsUn_;
+    for (int i = 0; i < N; i++) {
+        mvKeysUn[i] = mvKeys[i];
+        if (c.k1 != 0.0) undistortPoint(c, mvKeys[i].x, mvKeys[i].y, &mvKeysUn[i].x, &mvKeysUn[i].y);
+    }
+    const int COLS = 64, ROWS = 48;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / static_cast<float>(mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / static_cast<float>(mnMaxY - mnMinY);
+    std::vector<std::vector<int>> grid(COLS * ROWS);
+    int inside = 0;
+    for (int i = 0; i < N; i++) {
+        const int posX = (int)std::round((mvKeysUn[i].x - mnMinX) * wInv), posY = (int)std::round((mvKeysUn[i].y - mnMinY) * hInv);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[posX * ROWS + posY].push_back(i);
+        inside++;
+    }
+    int o = 0;
+    for (int cell = 0; cell < COLS * ROWS; cell++) {
+        gridOff[cell] = o;
+        for (int i : grid[cell]) gridIdx[o++] = i;
+    }
+    gridOff[COLS * ROWS] = o;
+    return inside;
+}
+
 // ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,
 // the reference's own execution model per Frame.cc:109-112); returns wall seconds. ------------
 double oracle_time_frames(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,

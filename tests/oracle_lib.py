@@ -68,6 +68,9 @@ def lib():
         L.oracle_stereo_match.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp]
         L.oracle_descriptor_distance.restype = C.c_int
         L.oracle_descriptor_distance.argtypes = [vp, vp]
+        L.oracle_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.oracle_frame_finish.restype = C.c_int
+        L.oracle_frame_finish.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
         L.oracle_time_frames.restype = C.c_double
         L.oracle_time_frames.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -159,6 +162,27 @@ def stereo_match(o_left, o_right, kps_l, desc_l, kps_r, desc_r, bf, b):
     kept = lib().oracle_stereo_match(o_left.h, o_right.h, _ptr(kps_l), _ptr(desc_l), len(kps_l), _ptr(kps_r), _ptr(desc_r),
                                      len(kps_r), float(bf), float(b), _ptr(u), _ptr(d))
     return u, d, kept
+
+
+def camera(fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+    """Frame::mK / mDistCoef as the 9-float struct both the oracle and liborbx take."""
+    return np.array([fx, fy, cx, cy, k1, k2, p1, p2, k3], np.float32)
+
+
+def image_bounds(cam, cols, rows):
+    b = np.zeros(4, np.float32)
+    lib().oracle_image_bounds(_ptr(np.ascontiguousarray(cam, np.float32)), cols, rows, _ptr(b))
+    return b
+
+
+def frame_finish(cam, kps, bounds):
+    """UndistortKeyPoints + AssignFeaturesToGrid (reference src/Frame.cc:748-782, 383-417).
+    Returns (mvKeysUn, grid_offsets[3073], grid_indices[n_inside])."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    un = np.zeros(len(kps), KEYPOINT_DTYPE); off = np.zeros(64 * 48 + 1, np.int32); idx = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().oracle_frame_finish(_ptr(np.ascontiguousarray(cam, np.float32)), _ptr(kps), len(kps),
+                                  _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(un), _ptr(off), _ptr(idx))
+    return un, off, idx[:n].copy()
 
 
 def descriptor_distance(a, b):
