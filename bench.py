@@ -27,7 +27,7 @@ WORKLOADS = {
     "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=256, variant="noise",
                     desc="640x480 mono stream, 8 levels, 1000 features, synthetic noise frames"),
     # configs[2]
-    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=32, variant="noise",
+    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=64, variant="noise",
                    desc="1920x1080 mono stream, 8 levels, 2000 features, synthetic noise frames"),
     # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
     "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="noise",

@@ -153,6 +153,8 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         (size_t)g.selPerFrame * h->maxB > h->selEntries || g.cells.size() > h->cellCap || g.maxNodes > h->octM)
         return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "image geometry does not fit the arenas sized at orbx_create");
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // tables may still be in use by queued work
+    h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
+    h->lastB = 0;
     HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
     size_t xo = 0, yo = 0;
