@@ -16,6 +16,7 @@
 // offsets and the 8 NMS neighbours are instruction immediates.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "orbx_device.hpp"
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ void waveLdsSync() {
 }
 
 // TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.
-template <int TS, int ROWS>
+template <int TS, int ROWS, bool PREFILTER>
 __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
@@ -88,13 +89,15 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
     constexpr int LPR = DW <= 16 ? 16 : 32;           // lanes per row while staging
     constexpr int RPI = 64 / LPR;                     // rows per staging step
     constexpr int STEPS = (ROWS + RPI - 1) / RPI;
-    __shared__ __align__(16) uint8_t smem[kFastWaves * (kTileBytes + kScoreBytes)];
+    constexpr int kMaxPix = (ROWS - 6) * (ROWS - 6);  // interior pixels of the largest cell
+    constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
+    __shared__ __align__(16) uint8_t smem[kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ci = blockIdx.x * kFastWaves + wave, f = blockIdx.y;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
-    uint8_t* tile = smem + wave * (kTileBytes + kScoreBytes);
+    uint8_t* tile = smem + wave * (kTileBytes + kScoreBytes + kPassBytes);
     uint8_t* score = tile + kTileBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
 
@@ -127,7 +130,43 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
     const int qx = 64 % cw, qy = 64 / cw;               // how (x, y) advance when the pixel index advances by 64
     const int x00 = lane % cw, y00 = lane / cw;
     // ---- pass 1: scores ----
-    {
+    if (PREFILTER) {
+        // 1a. cheap exact rejection: a 9-arc contains one pixel of every opposite ring pair, so a bright (dark) corner
+        //     at threshold t needs min over the 8 pairs of max(r_k, r_k+8) > v + t (max over pairs of min < v - t).
+        //     Pixels failing both have S <= minThFAST: they are neither keypoints nor able to suppress one, so their
+        //     score stays 0.  Survivors are compacted so the full score runs at full lane occupancy.
+        unsigned short* pass = (unsigned short*)(score + kScoreBytes);
+        int nPass = 0;
+        int x = x00, y = y00;
+        for (int base = 0; base < npix; base += 64) {
+            bool may = false;
+            if (base + lane < npix) {
+                const uint8_t* c0 = tile + (y + 3) * TS + mis + x + 3;
+                const unsigned v = c0[0];
+                const unsigned a0 = c0[3 * TS], a8 = c0[-3 * TS], a1 = c0[3 * TS + 1], a9 = c0[-3 * TS - 1];
+                const unsigned a2 = c0[2 * TS + 2], a10 = c0[-2 * TS - 2], a3 = c0[TS + 3], a11 = c0[-TS - 3];
+                const unsigned a4 = c0[3], a12 = c0[-3], a5 = c0[-TS + 3], a13 = c0[TS - 3];
+                const unsigned a6 = c0[-2 * TS + 2], a14 = c0[2 * TS - 2], a7 = c0[-3 * TS + 1], a15 = c0[3 * TS - 1];
+                const unsigned minOfMax = vmin3(vmin3(max(a0, a8), max(a1, a9), max(a2, a10)), vmin3(max(a3, a11), max(a4, a12), max(a5, a13)),
+                                                min(max(a6, a14), max(a7, a15)));
+                const unsigned maxOfMin = vmax3(vmax3(min(a0, a8), min(a1, a9), min(a2, a10)), vmax3(min(a3, a11), min(a4, a12), min(a5, a13)),
+                                                max(min(a6, a14), min(a7, a15)));
+                may = minOfMax > v + (unsigned)minTh || maxOfMin + (unsigned)minTh < v;
+            }
+            const unsigned long long b = __ballot(may);
+            if (may) pass[nPass + __popcll(b & ((1ull << lane) - 1))] = (unsigned short)(x | (y << 6));
+            nPass += __popcll(b);
+            x += qx; y += qy;
+            if (x >= cw) { x -= cw; y++; }
+        }
+        waveLdsSync();
+        // 1b. full score of the survivors
+        for (int i = lane; i < nPass; i += 64) {
+            const int e = pass[i], px = e & 63, py = e >> 6;
+            const int s = fastScore<TS>(tile + (py + 3) * TS + mis + px + 3);
+            score[(py + 1) * TS + px + 1] = (uint8_t)s;
+        }
+    } else {
         int x = x00, y = y00;
         for (int p = lane; p < npix; p += 64) {
             const int s = fastScore<TS>(tile + (y + 3) * TS + mis + x + 3);
@@ -190,13 +229,16 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
-                int B) {
+                bool prefilter, int B) {
     const dim3 grid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
-    if (maxRoiW <= 45 && maxRoiH <= 45)
-        hipLaunchKernelGGL((k_fast<48, 45>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
-    else   // cells up to 63 px (the geometry code rejects larger ones)
-        hipLaunchKernelGGL((k_fast<72, 69>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
+    if (maxRoiW <= 45 && maxRoiH <= 45) {
+        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
+        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
+    } else {   // cells up to 63 px (the geometry code rejects larger ones)
+        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
+        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount);
+    }
 }
 
 // unpack one level's candidates into reference KeyPoints (introspection for tests)

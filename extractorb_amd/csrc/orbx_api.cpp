@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,7 +22,7 @@ void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, con
                   uint8_t*, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, int);
+                int, int, bool, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
                   unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, int);
@@ -46,6 +47,7 @@ using namespace orbx;
 static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
 
 namespace {
+constexpr float kPrefilterDensity = 0.02f;   // candidates per pixel below which the prefilter variant of k_fast is faster
 enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_SPARE };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
@@ -98,6 +100,16 @@ struct orbx_handle {
     uint8_t* h_outD = nullptr;
     int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
     int lastB = 0;
+    // FAST kernel choice.  Both variants give identical results; the one that first rejects pixels with a cheap exact
+    // test and scores only the survivors wins when few pixels can be corners (natural images: 2-18 %), the direct one
+    // when most can (noise: 55 %).  Chosen from the candidate density of the previous batch of the stream, read back
+    // asynchronously (never waited for); ORBX_FAST_PREFILTER=0/1 forces a variant.
+    int fastMode = -1;              // -1 auto, 0 direct, 1 prefilter
+    float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
+    unsigned* h_candStat = nullptr; // pinned copy of d_candCount
+    hipEvent_t statEvent = nullptr;
+    bool statPending = false;
+    int statB = 0;
     // stereo matching (allocated on first use)
     int stereoPairs = 0, stereoCap = 0, stereoRows = 0;
     int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
@@ -134,7 +146,8 @@ void freeAll(orbx_handle* h) {
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
+    if (h->statEvent) (void)hipEventDestroy(h->statEvent);
+    void* host[] = {h->h_candStat, h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -251,16 +264,29 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                      h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, B);
     }
     { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
+    if (h->statPending && hipEventQuery(h->statEvent) == hipSuccess) {
+        long long total = 0;
+        for (int i = 0; i < h->statB * g.nlevels; i++) total += h->h_candStat[i];
+        h->candDensity = (float)((double)total / ((double)h->statB * (double)g.sumPixels));
+        h->statPending = false;
+    }
+    const bool prefilter = h->fastMode == 1 || (h->fastMode < 0 && h->candDensity >= 0.f && h->candDensity < kPrefilterDensity);
     {
         Prof p(h, S_FAST);
         launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
-                   h->d_cellCount, g.maxRoiW, g.maxRoiH, B);
+                   h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, B);
     }
     {
         Prof p(h, S_OCTREE);
         launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                      h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                      h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, B);
+    }
+    if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
+        HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipEventRecord(h->statEvent, st));
+        h->statPending = true;
+        h->statB = B;
     }
     {
         Prof p(h, S_DESCRIBE);
@@ -419,6 +445,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_monoOut, sizeof(int) * max_batch));
     CREATE_TRY(hipMalloc(&h->d_outLevelCounts, sizeof(int) * max_batch * nlevels));
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
+    CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
+    CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
+    if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));

@@ -62,3 +62,19 @@ def frames(variant, first, count, rows, cols, seed=SEED):
     """uint8 [count, rows, cols]: frames first .. first+count-1 of the stream."""
     gen = VARIANTS[variant]
     return np.stack([gen(first + i, rows, cols, seed) for i in range(count)])
+
+
+def fixture_frame(f, rows, cols, seed=SEED):
+    """A natural image for bench/tests: the reference's own 640x480 demo frame (tests/golden/robot_865_gray.png),
+    cropped/tiled to the requested size and shifted by f pixels so consecutive frames differ."""
+    import os
+    from PIL import Image
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "robot_865_gray.png")
+    img = np.array(Image.open(path))
+    reps = (-(-rows // img.shape[0]), -(-(cols + 64) // img.shape[1]))
+    big = np.tile(img, reps)
+    s = int(f) % 64
+    return np.ascontiguousarray(big[:rows, s:s + cols])
+
+
+VARIANTS["natural"] = fixture_frame

@@ -259,3 +259,22 @@ def test_profile_api_and_algorithmic_bytes():
     ex.profile(False)
     assert ex.algorithmic_bytes(480, 640, 1000) == 307200 + 2 * 950532 + 60000
     assert ex.algorithmic_bytes(1080, 1920, 2000) == 2073600 + 2 * 6419321 + 120000
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "auto"])
+def test_fast_kernel_variants_agree(mode, monkeypatch):
+    # k_fast has a direct and a prefilter+compaction variant (chosen per stream from the previous batch's candidate
+    # density); both must give the reference result on dense and on natural content
+    if mode == "auto":
+        monkeypatch.delenv("ORBX_FAST_PREFILTER", raising=False)
+    else:
+        monkeypatch.setenv("ORBX_FAST_PREFILTER", mode)
+    ex = X.ORBextractor(1000, max_batch=4)
+    for variant in ("natural", "noise", "sparse", "natural"):
+        fr = synth.frames(variant, 3, 4, 480, 640)
+        for rep in range(2):          # the second call of a stream may switch variant in auto mode
+            out = ex.extract_batch(fr)
+            ex.synchronize()
+        for f in (0, 3):
+            o, want = oracle_run(fr[f])
+            assert_same_result(out[f][:3], want, "%s mode %s frame %d" % (variant, mode, f))
