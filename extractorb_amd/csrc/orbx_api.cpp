@@ -100,6 +100,8 @@ struct orbx_handle {
     uint8_t* h_outD = nullptr;
     int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
     int lastB = 0;
+    int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
+    bool pendingLevels = false;
     // FAST kernel choice.  Both variants give identical results; the one that first rejects pixels with a cheap exact
     // test and scores only the survivors wins when few pixels can be corners (natural images: 2-18 %), the direct one
     // when most can (noise: 55 %).  Chosen from the candidate density of the previous batch of the stream, read back
@@ -511,19 +513,18 @@ int orbx_extract_batch_device(orbx_handle* h, int n_frames, const uint8_t* d_img
                         (Keypoint*)d_kps, d_desc, capacity, d_n_out, d_mono_out, (Keypoint*)d_level_kps, d_level_counts);
 }
 
-int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
-                       ptrdiff_t frame_stride, const int* lap, orbx_keypoint* kps, uint8_t* desc, int capacity,
-                       int* n_out, int* mono_out, orbx_keypoint* level_kps, int* level_counts) {
+int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
+                             ptrdiff_t frame_stride, const int* lap, int want_levels) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "a batch is already in flight on this handle: call orbx_extract_batch_end first");
     if (!imgs || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
-    if (!kps || !desc || !n_out || !mono_out || capacity < 1 || stride < cols)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer, capacity < 1 or stride < cols");
+    if (stride < cols) return fail(h, ORBX_ERR_BAD_ARGUMENT, "stride < cols");
     int rc = checkFrameArgs(h, n_frames, rows, cols);
     if (rc != ORBX_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const int B = n_frames;
-    // H2D into a tight cols x rows x B slab
+    // H2D into a tight cols x rows x B slab (truly asynchronous when `imgs` is pinned: orbx_host_alloc)
     if (stride == cols && frame_stride == (ptrdiff_t)rows * cols) {
         HIP_TRY(h, hipMemcpyAsync(h->d_input, imgs, (size_t)rows * cols * B, hipMemcpyHostToDevice, st));
     } else {
@@ -540,10 +541,26 @@ int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int ro
     HIP_TRY(h, hipMemcpyAsync(h->h_monoOut, h->d_monoOut, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(h->h_outK, h->d_outK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpyAsync(h->h_outD, h->d_outD, oc * 32, hipMemcpyDeviceToHost, st));
-    if (level_kps) HIP_TRY(h, hipMemcpyAsync(h->h_outLevelK, h->d_outLevelK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
-    if (level_counts)
+    if (want_levels) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_outLevelK, h->d_outLevelK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipMemcpyAsync(h->h_outLevelCounts, h->d_outLevelCounts, sizeof(int) * B * h->nlevels, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    h->pendingB = B;
+    h->pendingLevels = want_levels != 0;
+    return ORBX_OK;
+}
+
+int orbx_extract_batch_end(orbx_handle* h, orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out,
+                           orbx_keypoint* level_kps, int* level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "no batch in flight: call orbx_extract_batch_begin first");
+    const int B = h->pendingB, cap = h->outCap;
+    h->pendingB = 0;
+    if (!kps || !desc || !n_out || !mono_out || capacity < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer or capacity < 1");
+    if ((level_kps || level_counts) && !h->pendingLevels)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "per-level outputs requested but the batch was begun with want_levels = 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     int status = ORBX_OK;
     for (int f = 0; f < B; f++) {
         const int n = h->h_nOut[f];
@@ -560,6 +577,37 @@ int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int ro
     }
     return status;
 }
+
+int orbx_extract_batch_end_view(orbx_handle* h, const orbx_keypoint** kps, const uint8_t** desc, int* capacity,
+                                const int** n_out, const int** mono_out) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "no batch in flight: call orbx_extract_batch_begin first");
+    h->pendingB = 0;
+    if (!kps || !desc || !capacity || !n_out || !mono_out) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *kps = (const orbx_keypoint*)h->h_outK; *desc = h->h_outD; *capacity = h->outCap;
+    *n_out = h->h_nOut; *mono_out = h->h_monoOut;
+    return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
+                       ptrdiff_t frame_stride, const int* lap, orbx_keypoint* kps, uint8_t* desc, int capacity,
+                       int* n_out, int* mono_out, orbx_keypoint* level_kps, int* level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!imgs || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
+    if (!kps || !desc || !n_out || !mono_out || capacity < 1 || stride < cols)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer, capacity < 1 or stride < cols");
+    int rc = orbx_extract_batch_begin(h, n_frames, imgs, rows, cols, stride, frame_stride, lap, level_kps || level_counts);
+    if (rc != ORBX_OK) return rc;
+    return orbx_extract_batch_end(h, kps, desc, capacity, n_out, mono_out, level_kps, level_counts);
+}
+
+void* orbx_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+}
+void orbx_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out, orbx_keypoint* level_kps,

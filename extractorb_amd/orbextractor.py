@@ -82,6 +82,12 @@ def load_library():
     L.orbx_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp, C.c_int, ip, ip, vp, vp]
     L.orbx_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, C.c_int,
                                      vp, vp, vp, vp]
+    L.orbx_extract_batch_begin.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int]
+    L.orbx_extract_batch_end.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.orbx_extract_batch_end_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), C.POINTER(vp)]
+    L.orbx_host_alloc.restype = vp
+    L.orbx_host_alloc.argtypes = [C.c_size_t]
+    L.orbx_host_free.argtypes = [vp]
     L.orbx_extract_batch_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp,
                                             C.c_int, vp, vp, vp, vp]
     L.orbx_get_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, ip, ip]
@@ -140,6 +146,22 @@ def compute_cell_grid(rows, cols, level, scale_factor=1.2, nlevels=8):
         raise OrbxError(rc, "orbx_compute_cell_grid")
     keys = ["n_cols", "n_rows", "w_cell", "h_cell", "n_cells", "n_ini", "cand_cap"]
     return dict(zip(keys, [x.value for x in v]))
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array backed by pinned host memory (orbx_host_alloc): H2D copies from it overlap with kernels."""
+    L = load_library()
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    p = L.orbx_host_alloc(nbytes)
+    if not p:
+        raise OrbxError(-6, "orbx_host_alloc failed")
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)   # free with pinned_free(arr); it must not be used afterwards
+
+
+def pinned_free(arr):
+    load_library().orbx_host_free(C.c_void_p(arr.ctypes.data))
 
 
 def camera(fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
@@ -247,6 +269,27 @@ class ORBextractor:
                 per_level.append(lvl[f, o:o + c].copy()); o += c
             out.append((int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), per_level))
         return out
+
+    def extract_batch_begin(self, images, lapping=None, want_levels=False):
+        """Asynchronous host-buffer form: enqueue H2D + path + D2H and return (one batch in flight per handle)."""
+        assert images.dtype == np.uint8 and images.ndim == 3 and images.flags["C_CONTIGUOUS"]
+        B, rows, cols = images.shape
+        lap = None
+        if lapping is not None:
+            lap = np.ascontiguousarray(np.broadcast_to(np.asarray(lapping, np.int32).reshape(-1, 2), (B, 2)))
+        self._check(self._L.orbx_extract_batch_begin(self._h, B, _ptr(images), rows, cols, cols, rows * cols, _ptr(lap), int(want_levels)))
+        self._pending = (B, images, lap)     # keep the buffers alive until the batch ends
+
+    def extract_batch_end(self):
+        if getattr(self, "_pending", None) is None:
+            raise OrbxError(-2, "no batch in flight: call extract_batch_begin first")
+        B = self._pending[0]
+        cap = self.capacity
+        kps = np.zeros((B, cap), KEYPOINT_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
+        self._check(self._L.orbx_extract_batch_end(self._h, _ptr(kps), _ptr(desc), cap, _ptr(n), _ptr(mono), None, None))
+        self._pending = None
+        return [(int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(B)]
 
     def extract_batch_device(self, d_images, n_frames, rows, cols, d_kps, d_desc, d_n, d_mono, capacity,
                              stride=None, frame_stride=None, lapping=None, d_level_kps=0, d_level_counts=0):

@@ -112,6 +112,23 @@ int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int ro
                        uint8_t* desc, int capacity, int* n_out, int* mono_out, orbx_keypoint* level_kps,
                        int* level_counts);
 
+/* Asynchronous host-buffer form.  _begin enqueues the H2D copy of the frames, the whole path and the D2H copy of
+ * the results (into pinned staging owned by the handle) and returns without waiting; _end waits for that batch and
+ * copies the results into the caller's arrays (same layout as orbx_extract_batch).  One batch in flight per handle:
+ * two handles used alternately overlap the transfers of one batch with the kernels of the other.  The H2D copy is
+ * only truly asynchronous from pinned memory (orbx_host_alloc).  want_levels != 0 also brings back the per-level
+ * arrays.  orbx_extract_batch == _begin + _end. */
+int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
+                             ptrdiff_t frame_stride, const int* lap, int want_levels);
+int orbx_extract_batch_end(orbx_handle* h, orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out,
+                           orbx_keypoint* level_kps, int* level_counts);
+/* Zero-copy variant of _end: waits, then hands out pointers into the handle's pinned result staging
+ * (kps[f*capacity + i], desc[(f*capacity + i)*32], n_out[f], mono_out[f]); valid until the next _begin on this handle. */
+int orbx_extract_batch_end_view(orbx_handle* h, const orbx_keypoint** kps, const uint8_t** desc, int* capacity,
+                                const int** n_out, const int** mono_out);
+void* orbx_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
+void orbx_host_free(void* p);
+
 /* Device-resident batched form: d_imgs and the outputs are device pointers; the work is enqueued on the
  * handle's stream and NOT synchronised (call orbx_synchronize or sync the stream yourself).  Same output
  * layout as orbx_extract_batch; d_level_kps/d_level_counts may be NULL.  lap is a HOST pointer (or NULL). */

@@ -278,3 +278,22 @@ def test_fast_kernel_variants_agree(mode, monkeypatch):
         for f in (0, 3):
             o, want = oracle_run(fr[f])
             assert_same_result(out[f][:3], want, "%s mode %s frame %d" % (variant, mode, f))
+
+
+def test_async_host_api_with_two_handles_and_pinned_input():
+    B = 3
+    fa, fb = synth.frames("textured", 200, B, 480, 640), synth.frames("noise", 300, B, 480, 640)
+    pa, pb = X.pinned_empty(fa.shape), X.pinned_empty(fb.shape)
+    pa[...] = fa; pb[...] = fb
+    a, b = X.ORBextractor(1000, max_batch=B), X.ORBextractor(1000, max_batch=B)
+    a.extract_batch_begin(pa)
+    b.extract_batch_begin(pb)                    # both batches in flight
+    with pytest.raises(X.OrbxError):
+        a.extract_batch_begin(pa)                # one batch per handle
+    ra, rb = a.extract_batch_end(), b.extract_batch_end()
+    with pytest.raises(X.OrbxError):
+        a.extract_batch_end()                    # nothing in flight any more
+    for f in range(B):
+        assert_same_result(ra[f], oracle_run(fa[f])[1], "handle a frame %d" % f)
+        assert_same_result(rb[f], oracle_run(fb[f])[1], "handle b frame %d" % f)
+    X.pinned_free(pa); X.pinned_free(pb)

@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the host-buffer entry point (orbx_extract_batch: H2D + path + D2H + sync per call).
-Reported in DESIGN.md next to bench.py's device-resident `value`; never used as `value`."""
-import os, sys, time
+"""PCIe-inclusive rates of the host-buffer entry points (never used as bench.py's `value`):
+  sync      orbx_extract_batch on pageable numpy buffers: H2D + path + D2H + wait per call
+  pipelined orbx_extract_batch_begin/_end on pinned buffers (orbx_host_alloc), two handles used alternately so the
+            transfers of one batch overlap the kernels of the other"""
+import ctypes as C
+import os
+import sys
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import extractorb_amd as X
 from extractorb_amd import synth
 
+
 def main():
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
     for B in (1, 8, 64, 256):
         fr = synth.frames("noise", 0, min(B, 64), 480, 640)
         fr = np.concatenate([fr] * ((B + len(fr) - 1) // len(fr)))[:B]
@@ -17,8 +26,6 @@ def main():
         cap = ex.capacity
         kps = np.zeros((B, cap), X.KEYPOINT_DTYPE); desc = np.zeros((B, cap, 32), np.uint8)
         n = np.zeros(B, np.int32); mono = np.zeros(B, np.int32)
-        import ctypes as C
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
         call = lambda: L.orbx_extract_batch(h, B, p(fr), 480, 640, 640, 480 * 640, None, p(kps), p(desc), cap, p(n), p(mono), None, None)
         for _ in range(3):
             assert call() == 0
@@ -27,7 +34,31 @@ def main():
         for _ in range(reps):
             call()
         dt = (time.perf_counter() - t) / reps
-        print("B=%4d  %8.3f ms/call  %9.1f frames/s (pageable host buffers, synchronous)" % (B, dt * 1e3, B / dt))
+        # pipelined: two handles, pinned input
+        exs = [ex, X.ORBextractor(1000, max_batch=B)]
+        pin = [X.pinned_empty(fr.shape), X.pinned_empty(fr.shape)]
+        for a in pin:
+            a[...] = fr
+        outs = [(np.zeros((B, cap), X.KEYPOINT_DTYPE), np.zeros((B, cap, 32), np.uint8), np.zeros(B, np.int32), np.zeros(B, np.int32)) for _ in range(2)]
+        begin = lambda i: exs[i]._L.orbx_extract_batch_begin(exs[i]._h, B, p(pin[i]), 480, 640, 640, 480 * 640, None, 0)
+        endc = lambda i: exs[i]._L.orbx_extract_batch_end(exs[i]._h, p(outs[i][0]), p(outs[i][1]), cap, p(outs[i][2]), p(outs[i][3]), None, None)
+        assert begin(0) == 0 and begin(1) == 0 and endc(0) == 0 and endc(1) == 0
+        assert outs[0][2].tolist() == n.tolist() and np.array_equal(outs[1][1], desc)
+        vk, vd, vn, vm, vc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        end = lambda i: exs[i]._L.orbx_extract_batch_end_view(exs[i]._h, C.byref(vk), C.byref(vd), C.byref(vc), C.byref(vn), C.byref(vm))   # zero-copy
+        reps2 = max(4, 512 // B)
+        t = time.perf_counter()
+        assert begin(0) == 0
+        for k in range(1, reps2):
+            assert begin(k & 1) == 0            # next batch enqueued before the previous one is collected
+            assert end((k - 1) & 1) == 0
+        assert end((reps2 - 1) & 1) == 0
+        dt2 = (time.perf_counter() - t) / reps2
+        print("B=%4d  sync/pageable %8.3f ms/call %9.1f frames/s   pipelined/pinned/zero-copy (2 handles) %8.3f ms/batch %9.1f frames/s"
+              % (B, dt * 1e3, B / dt, dt2 * 1e3, B / dt2))
+        for a in pin:
+            X.pinned_free(a)
+
 
 if __name__ == "__main__":
     main()
