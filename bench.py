@@ -36,6 +36,11 @@ WORKLOADS = {
     "stereo640_match": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="stereo", match=True,
                             desc="stereo 640x480 L+R pairs (128 pairs per step, right eye = left shifted by 6..40 px), 8 levels, "
                                  "1200 features per eye, extraction + ComputeStereoMatches"),
+    # configs[1] + the rest of the Frame constructor + monocular initialisation matching of consecutive
+    # frames (§8f-2), all fed from HBM
+    "mono640_init": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=256, variant="pan", init_match=True,
+                         desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
+                              "AssignFeaturesToGrid + SearchForInitialization(frame i, frame i+1)"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -86,6 +91,9 @@ def main():
             disp = 6 + (p * 7) % 35
             pairs += [big[:, 40:40 + cols], big[:, 40 + disp:40 + disp + cols]]
         frames = np.ascontiguousarray(np.stack(pairs))
+    elif variant == "pan":     # one textured scene per rank seen by a camera panning 1 px per frame: consecutive frames match
+        big = synth.textured_frame(rank, rows, cols + B)
+        frames = np.ascontiguousarray(np.stack([big[:, i:i + cols] for i in range(B)]))
     else:
         frames = synth.frames(variant, rank * B, B, rows, cols)
     d_img = torch.from_numpy(frames).cuda()
@@ -107,6 +115,22 @@ def main():
     if match:
         d_u = torch.zeros((B // 2, cap), dtype=torch.float32, device="cuda"); d_z = torch.zeros_like(d_u)
         d_nm = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
+    init_match = bool(wl.get("init_match"))
+    if init_match:
+        cam = X.camera(fx=458.654, fy=457.296, cx=367.215, cy=248.375, k1=-0.28340811, k2=0.07395907, p1=0.00019359, p2=1.76187114e-05)
+        bounds = X.compute_image_bounds(cam, cols, rows)
+        d_un = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_goff = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda"); d_gidx = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+        d_nin = torch.zeros(B, dtype=torch.int32, device="cuda")
+        d_prev = torch.zeros((B - 1, cap, 2), dtype=torch.float32, device="cuda")
+        d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda"); d_nm12 = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+
+    def finish_and_match(e_, b):
+        e_.frame_finish_device(B, b + off_k, b + off_n, cap, cam, bounds, d_un, d_goff, d_gidx, d_nin)
+        d_prev.copy_(d_un[:B - 1, :, :2])               # Tracking.cc:2029-2031: vbPrevMatched = F1.mvKeysUn[i].pt
+        e_.search_for_initialization_device(B - 1, (0, 1), (1, 1), d_un, b + off_d, b + off_n, cap, d_goff, d_gidx, bounds, d_prev,
+                                            d_m12, d_nm12, 100, 0.9, True)
+
     gathered = None
     gather = distributed and not args.no_gather
     if gather and rank == 0:
@@ -122,6 +146,8 @@ def main():
         e_.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
         if match:
             e_.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
+        if init_match:
+            finish_and_match(e_, b)
         if gather:
             if nH > 1:
                 stream.wait_stream(streams[(counter[0] - 1) % nH])   # the collective is ordered after the CURRENT stream
@@ -164,6 +190,8 @@ def main():
                                     lapping=wl["lapping"])
             if match:
                 ex.stereo_match_device(B // 2, base + off_k, base + off_d, base + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
+            if init_match:
+                finish_and_match(ex, base)
         prof = ex.profile_read()
         ex.profile(False)
         kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
@@ -208,6 +236,7 @@ def main():
                        "fast_thresholds": [20, 7], "lapping": list(wl["lapping"]),
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
+                       **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -39,6 +39,13 @@ struct FrameFinishParams { CameraParams cam; float minX, minY, wInv, hInv; int c
 void launchFrameFinish(hipStream_t, const Keypoint*, const int*, const FrameFinishParams&, Keypoint*, int*, int*, int*, int);
 void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const StereoParams&,
                   int, int*, unsigned short*, float*, float*, int*, int*, int);
+struct InitMatchParams {
+    float minX, minY, wInv, hInv, r, nnRatio;
+    int checkOrientation, capacity, f1First, f1Step, f2First, f2Step;
+};
+size_t initMatchLdsBytes(int capacity);
+void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
+                      float*, int*, int*, int);
 void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
 }  // namespace orbx
 
@@ -48,10 +55,10 @@ static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout")
 
 namespace {
 constexpr float kPrefilterDensity = 0.02f;   // candidates per pixel below which the prefilter variant of k_fast is faster
-enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_SPARE };
+enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_FRAME };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
-                                            "k_stereo_rows+match+filter", "spare"};
+                                            "k_stereo_rows+match+filter", "k_frame_finish+k_search_init"};
 thread_local std::string g_createError;
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -807,7 +814,39 @@ int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* 
     p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
     p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
     p.capacity = capacity;
-    launchFrameFinish(h->stream, (const Keypoint*)d_kps, d_n_out, p, (Keypoint*)d_kps_un, d_grid_off, d_grid_idx, d_n_inside, n_frames);
+    {
+        Prof pr(h, S_FRAME);
+        launchFrameFinish(h->stream, (const Keypoint*)d_kps, d_n_out, p, (Keypoint*)d_kps_un, d_grid_off, d_grid_idx, d_n_inside, n_frames);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame1_first, int frame1_step, int frame2_first,
+                                          int frame2_step, const orbx_keypoint* d_kps_un, const uint8_t* d_desc,
+                                          const int* d_n_out, int capacity, const int* d_grid_off, const int* d_grid_idx,
+                                          const float* bounds4, float* d_prev_matched, int window_size, float nn_ratio,
+                                          int check_orientation, int* d_matches12, int* d_n_matches) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_kps_un || !d_desc || !d_n_out || !d_grid_off || !d_grid_idx || !bounds4 || !d_prev_matched || !d_matches12 ||
+        !d_n_matches || capacity < 1 || n_pairs < 1 || frame1_first < 0 || frame2_first < 0 || frame1_step < 0 || frame2_step < 0 ||
+        window_size < 0 || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1, negative frame index/step/window or empty bounds");
+    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
+    if (initMatchLdsBytes(capacity) > 160 * 1024 - 512)
+        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (56 bytes per keypoint, 160 KB per CU)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    InitMatchParams p;
+    p.minX = bounds4[0]; p.minY = bounds4[2];
+    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
+    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
+    p.r = (float)window_size; p.nnRatio = nn_ratio; p.checkOrientation = check_orientation != 0; p.capacity = capacity;
+    p.f1First = frame1_first; p.f1Step = frame1_step; p.f2First = frame2_first; p.f2Step = frame2_step;
+    {
+        Prof pr(h, S_FRAME);
+        launchSearchInit(h->stream, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off, d_grid_idx, p, d_prev_matched, d_matches12,
+                         d_n_matches, n_pairs);
+    }
     HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
 }

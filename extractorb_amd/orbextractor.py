@@ -95,6 +95,8 @@ def load_library():
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.orbx_search_for_initialization_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp,
+                                                        vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbx_set_stream.argtypes = [vp, vp]
     L.orbx_get_stream.restype = vp
     L.orbx_get_stream.argtypes = [vp]
@@ -328,6 +330,19 @@ class ORBextractor:
         cam = np.ascontiguousarray(cam, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
         self._check(self._L.orbx_frame_finish_device(self._h, n_frames, dp(d_kps), dp(d_n), capacity, _ptr(cam), _ptr(bounds),
                                                      dp(d_kps_un), dp(d_grid_off), dp(d_grid_idx), dp(d_n_inside)))
+
+    def search_for_initialization_device(self, n_pairs, frames1, frames2, d_kps_un, d_desc, d_n, capacity, d_grid_off, d_grid_idx,
+                                         bounds, d_prev_matched, d_matches12, d_n_matches, window=100, nnratio=0.9,
+                                         check_orientation=True):
+        """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:706-821) for n_pairs pairs of device-resident
+        frames; frames1 / frames2 = (first, step) of the F1 / F2 frame index of pair p."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        bounds = np.ascontiguousarray(bounds, np.float32)
+        self._check(self._L.orbx_search_for_initialization_device(
+            self._h, n_pairs, frames1[0], frames1[1], frames2[0], frames2[1], dp(d_kps_un), dp(d_desc), dp(d_n), capacity,
+            dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_prev_matched), window, nnratio, int(check_orientation),
+            dp(d_matches12), dp(d_n_matches)))
 
     def set_stream(self, stream_ptr):
         self._check(self._L.orbx_set_stream(self._h, C.c_void_p(int(stream_ptr))))

@@ -182,6 +182,24 @@ int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* 
                              const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
                              int* d_grid_idx, int* d_n_inside);
 
+/* ---- next row: monocular initialisation matching ------------------------------------------
+ * Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821; caller src/Tracking.cc:2065-2066 with
+ * ORBmatcher(0.9, true) and windowSize 100) with Frame::GetFeaturesInArea (src/Frame.cc:655-724),
+ * ORBmatcher::DescriptorDistance (:2349-2365) and ComputeThreeMaxima (:2303-2344), for n_pairs frame pairs of one
+ * device-resident batch: pair p matches F1 = frame frame1_first + p*frame1_step against F2 = frame
+ * frame2_first + p*frame2_step (a stream: 0,1,1,1; one initial frame against many: 0,0,1,1).
+ *   d_kps_un, d_grid_off, d_grid_idx : as written by orbx_frame_finish_device (mvKeysUn, mGrid) for all frames
+ *   d_desc, d_n_out                  : mDescriptors, N of all frames (orbx_extract_batch_device)
+ *   d_prev_matched[(p*capacity + i)*2 + {0,1}] : vbPrevMatched of pair p, in/out (Tracking.cc:2029-2031 seeds it
+ *                                      with F1.mvKeysUn[i].pt; matched entries become F2.mvKeysUn[match].pt, :815-817)
+ *   d_matches12[p*capacity + i]      : vnMatches12, -1 = unmatched;  d_n_matches[p] : the return value
+ * Asynchronous on the handle's stream. */
+int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame1_first, int frame1_step, int frame2_first,
+                                          int frame2_step, const orbx_keypoint* d_kps_un, const uint8_t* d_desc,
+                                          const int* d_n_out, int capacity, const int* d_grid_off, const int* d_grid_idx,
+                                          const float* bounds4, float* d_prev_matched, int window_size, float nn_ratio,
+                                          int check_orientation, int* d_matches12, int* d_n_matches);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -945,6 +946,121 @@ int oracle_frame_finish(const void* cam_, const void* kps_, int N, const float* 
     }
     gridOff[COLS * ROWS] = o;
     return inside;
+}
+
+// ---------------------------------------------------------------------------------------------
+// "Next" row: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821) with
+// Frame::GetFeaturesInArea (src/Frame.cc:655-724) and ComputeThreeMaxima (src/ORBmatcher.cc:2303-2344).
+// Inputs are what the Frame constructor leaves behind: mvKeysUn + mDescriptors of both frames, frame 2's mGrid
+// (as the CSR of oracle_frame_finish) and the image bounds.  TH_LOW = 50, HISTO_LENGTH = 30 (ORBmatcher.cc:37-38).
+// ---------------------------------------------------------------------------------------------
+static std::vector<size_t> getFeaturesInArea(const KeyPoint* mvKeysUn, const int* gridOff, const int* gridIdx, const float* bounds,
+                                             float x, float y, float r, int minLevel, int maxLevel) {
+    const int COLS = 64, ROWS = 48;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float mfGridElementWidthInv = static_cast<float>(COLS) / static_cast<float>(mnMaxX - mnMinX);
+    const float mfGridElementHeightInv = static_cast<float>(ROWS) / static_cast<float>(mnMaxY - mnMinY);
+    std::vector<size_t> vIndices;
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - factorX) * mfGridElementWidthInv));     // Frame.cc:666
+    if (nMinCellX >= COLS) return vIndices;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - mnMinX + factorX) * mfGridElementWidthInv));  // :672
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - factorY) * mfGridElementHeightInv));    // :678
+    if (nMinCellY >= ROWS) return vIndices;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - mnMinY + factorY) * mfGridElementHeightInv)); // :684
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);                                              // :690
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+            for (int j = gridOff[ix * ROWS + iy]; j < gridOff[ix * ROWS + iy + 1]; j++) {
+                const KeyPoint& kpUn = mvKeysUn[gridIdx[j]];
+                if (bCheckLevels) {
+                    if (kpUn.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                }
+                const float distx = kpUn.x - x, disty = kpUn.y - y;
+                if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) vIndices.push_back((size_t)gridIdx[j]);   // :717
+            }
+    return vIndices;
+}
+
+static void computeThreeMaxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// prevMatched: N1 x (x, y), in/out (vbPrevMatched).  matches12: N1 ints out (vnMatches12).  Returns nmatches.
+int oracle_search_for_initialization(const void* kpsUn1_, const uint8_t* desc1, int N1, const void* kpsUn2_, const uint8_t* desc2,
+                                     int N2, const int* gridOff2, const int* gridIdx2, const float* bounds, float* prevMatched,
+                                     int windowSize, float nnratio, int checkOrientation, int* matches12) {
+    const KeyPoint* k1 = (const KeyPoint*)kpsUn1_;
+    const KeyPoint* k2 = (const KeyPoint*)kpsUn2_;
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    int nmatches = 0;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(N2, INT_MAX), vnMatches21(N2, -1);
+    for (int i1 = 0; i1 < N1; i1++) {
+        const KeyPoint kp1 = k1[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = getFeaturesInArea(k2, gridOff2, gridIdx2, bounds, prevMatched[2 * i1], prevMatched[2 * i1 + 1],
+                                                          (float)windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            const int dist = descriptorDistance(d1, desc2 + i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < N1; i1++)
+        if (matches12[i1] >= 0) { prevMatched[2 * i1] = k2[matches12[i1]].x; prevMatched[2 * i1 + 1] = k2[matches12[i1]].y; }
+    return nmatches;
+}
+
+// Frame::GetFeaturesInArea alone (src/Frame.cc:655-724): indices in traversal order; returns their number.
+int oracle_features_in_area(const void* kpsUn, const int* gridOff, const int* gridIdx, const float* bounds, float x, float y, float r,
+                            int minLevel, int maxLevel, int* out, int capacity) {
+    std::vector<size_t> v = getFeaturesInArea((const KeyPoint*)kpsUn, gridOff, gridIdx, bounds, x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < capacity; i++) out[i] = (int)v[i];
+    return (int)v.size();
 }
 
 // ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,

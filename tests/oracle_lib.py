@@ -71,6 +71,10 @@ def lib():
         L.oracle_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
         L.oracle_frame_finish.restype = C.c_int
         L.oracle_frame_finish.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+        L.oracle_search_for_initialization.restype = C.c_int
+        L.oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
+        L.oracle_features_in_area.restype = C.c_int
+        L.oracle_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
         L.oracle_time_frames.restype = C.c_double
         L.oracle_time_frames.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -183,6 +187,32 @@ def frame_finish(cam, kps, bounds):
     n = lib().oracle_frame_finish(_ptr(np.ascontiguousarray(cam, np.float32)), _ptr(kps), len(kps),
                                   _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(un), _ptr(off), _ptr(idx))
     return un, off, idx[:n].copy()
+
+
+def features_in_area(kps_un, grid_off, grid_idx, bounds, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea (reference src/Frame.cc:655-724): keypoint indices in traversal order."""
+    kps_un = np.ascontiguousarray(kps_un, KEYPOINT_DTYPE)
+    out = np.zeros(max(len(kps_un), 1), np.int32)
+    n = lib().oracle_features_in_area(_ptr(kps_un), _ptr(np.ascontiguousarray(grid_off, np.int32)),
+                                      _ptr(np.ascontiguousarray(grid_idx, np.int32)), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                      x, y, r, min_level, max_level, _ptr(out), len(out))
+    return out[:n].copy()
+
+
+def search_for_initialization(kps_un1, desc1, kps_un2, desc2, grid_off2, grid_idx2, bounds, prev_matched, window=100, nnratio=0.9,
+                              check_orientation=True):
+    """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:706-821).
+    Returns (nmatches, vnMatches12[N1], updated vbPrevMatched[N1,2])."""
+    k1 = np.ascontiguousarray(kps_un1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(kps_un2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    prev = np.array(prev_matched, np.float32).reshape(len(k1), 2).copy()
+    m12 = np.zeros(max(len(k1), 1), np.int32)
+    gi = np.ascontiguousarray(grid_idx2, np.int32) if len(grid_idx2) else np.zeros(1, np.int32)
+    n = lib().oracle_search_for_initialization(_ptr(k1), _ptr(d1), len(k1), _ptr(k2), _ptr(d2), len(k2),
+                                               _ptr(np.ascontiguousarray(grid_off2, np.int32)), _ptr(gi),
+                                               _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), window, nnratio,
+                                               int(check_orientation), _ptr(m12))
+    return n, m12[:len(k1)].copy(), prev
 
 
 def descriptor_distance(a, b):
