@@ -33,6 +33,81 @@ __device__ __forceinline__ unsigned vmax3(unsigned a, unsigned b, unsigned c) {
     return r;
 }
 
+// Two pixels per register: u16 halves holding 0..255.  As IEEE binary16 bit patterns those are non-negative
+// denormals, whose order is the integer order, and minimum/maximum return one operand unchanged (the kernel runs
+// with FP16 denormals preserved, the HIP default), so the packed 3-input f16 ops ARE integer min3/max3 on both halves.
+__device__ __forceinline__ unsigned pkmin3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pkmax3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pksub(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// bytes O, O+1 of the 12-byte string L|C|R (three consecutive dwords of a tile row), zero-extended to two u16
+template <int O>
+__device__ __forceinline__ unsigned pairAt(unsigned L, unsigned C, unsigned R) {
+    static_assert(O >= 0 && O <= 10, "pair outside the three dwords");
+    if constexpr (O <= 6) return __builtin_amdgcn_perm(C, L, 0x0C000C00u | O | ((O + 1) << 16));
+    else return __builtin_amdgcn_perm(R, C, 0x0C000C00u | (O - 4) | ((O - 3) << 16));
+}
+
+// Ring of the two pixels at bytes P, P+1 of the centre dword (P = 0 or 2) in cv::FAST order, r[16] = the centre pair:
+// L/C/R[d] = the three dwords of tile row (centre row + d - 3).
+template <int P>
+__device__ __forceinline__ void pairRing(const unsigned (&L)[7], const unsigned (&C)[7], const unsigned (&R)[7], unsigned (&r)[17]) {
+    constexpr int B = 4 + P;      // byte of the first pixel inside L|C|R
+    r[0] = pairAt<B>(L[6], C[6], R[6]);       r[1] = pairAt<B + 1>(L[6], C[6], R[6]);   r[2] = pairAt<B + 2>(L[5], C[5], R[5]);
+    r[3] = pairAt<B + 3>(L[4], C[4], R[4]);   r[4] = pairAt<B + 3>(L[3], C[3], R[3]);   r[5] = pairAt<B + 3>(L[2], C[2], R[2]);
+    r[6] = pairAt<B + 2>(L[1], C[1], R[1]);   r[7] = pairAt<B + 1>(L[0], C[0], R[0]);   r[8] = pairAt<B>(L[0], C[0], R[0]);
+    r[9] = pairAt<B - 1>(L[0], C[0], R[0]);   r[10] = pairAt<B - 2>(L[1], C[1], R[1]);  r[11] = pairAt<B - 3>(L[2], C[2], R[2]);
+    r[12] = pairAt<B - 3>(L[3], C[3], R[3]);  r[13] = pairAt<B - 3>(L[4], C[4], R[4]);  r[14] = pairAt<B - 2>(L[5], C[5], R[5]);
+    r[15] = pairAt<B - 1>(L[6], C[6], R[6]);
+    r[16] = pairAt<B>(L[3], C[3], R[3]);
+}
+// BRIGHT: max over the 16 arcs of the arc minimum (and the centre); else min over the arcs of the arc maximum (and the
+// centre).  One polarity at a time keeps 16 + 16 values live instead of 16 + 32.
+template <bool BRIGHT>
+__device__ __forceinline__ unsigned arcExtreme(const unsigned (&r)[17]) {
+    unsigned x3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        x3[k] = BRIGHT ? pkmin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]) : pkmax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+    unsigned g[6];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        unsigned x9[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int k = 3 * j + i;
+            x9[i] = BRIGHT ? pkmin3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]) : pkmax3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]);
+        }
+        g[j] = BRIGHT ? pkmax3(x9[0], x9[1], x9[2]) : pkmin3(x9[0], x9[1], x9[2]);
+    }
+    g[5] = BRIGHT ? pkmin3(x3[15], x3[2], x3[5]) : pkmax3(x3[15], x3[2], x3[5]);      // arc 15
+    return BRIGHT ? pkmax3(pkmax3(g[0], g[1], g[2]), pkmax3(g[3], g[4], g[5]), r[16])
+                  : pkmin3(pkmin3(g[0], g[1], g[2]), pkmin3(g[3], g[4], g[5]), r[16]);
+}
+// S = max(maxMin - v, v - minMax): the centre took part in both reductions, so neither difference is negative
+__device__ __forceinline__ unsigned pairScore(const unsigned (&r)[17]) {
+    const unsigned maxMin = arcExtreme<true>(r);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned minMax = arcExtreme<false>(r);
+    return pkmax(pksub(maxMin, r[16]), pksub(r[16], minMax));
+}
+
 template <int TS>
 __device__ __forceinline__ int fastScore(const uint8_t* c) {
     // ring order of cv::FAST: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),(-3,-1),
@@ -67,6 +142,12 @@ __device__ __forceinline__ int fastScore(const uint8_t* c) {
 }
 
 constexpr int kFastWaves = 4;
+#ifndef ORBX_FAST_WAVES
+#define ORBX_FAST_WAVES 4   // waves per SIMD the packed (non-prefilter) variant is compiled for
+#endif
+#ifndef ORBX_FAST_SKIP
+#define ORBX_FAST_SKIP 0   // diagnostic builds (tools/fast_breakdown.py): 1 = no score pass, 2 = stop after the score pass, 4 = no staging loads
+#endif
 
 // LDS operations of one wave execute in issue order, so lanes of a wave only need the COMPILER to keep the
 // order of the stores before and the loads after this point.
@@ -79,7 +160,7 @@ __device__ __forceinline__ void waveLdsSync() {
 
 // TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.
 template <int TS, int ROWS, bool PREFILTER>
-__global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ cells, int nCells,
+__global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount) {
@@ -91,13 +172,14 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
     constexpr int STEPS = (ROWS + RPI - 1) / RPI;
     constexpr int kMaxPix = (ROWS - 6) * (ROWS - 6);  // interior pixels of the largest cell
     constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
-    __shared__ __align__(16) uint8_t smem[kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
+    // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword
+    __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ci = blockIdx.x * kFastWaves + wave, f = blockIdx.y;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
-    uint8_t* tile = smem + wave * (kTileBytes + kScoreBytes + kPassBytes);
+    uint8_t* tile = smem + 16 + wave * (kTileBytes + kScoreBytes + kPassBytes);
     uint8_t* score = tile + kTileBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
 
@@ -112,7 +194,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             const int r = s * RPI + rsub;
-            w[s] = (dcol < nd && r < roiH) ? *(const unsigned*)(sp + (long long)r * g.pyrStride + 4 * dcol) : 0u;
+            w[s] = (!(ORBX_FAST_SKIP & 4) && dcol < nd && r < roiH) ? *(const unsigned*)(sp + (long long)r * g.pyrStride + 4 * dcol) : 0u;
         }
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
@@ -164,18 +246,43 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
         for (int i = lane; i < nPass; i += 64) {
             const int e = pass[i], px = e & 63, py = e >> 6;
             const int s = fastScore<TS>(tile + (py + 3) * TS + mis + px + 3);
-            score[(py + 1) * TS + px + 1] = (uint8_t)s;
+            score[(py + 1) * TS + mis + px + 3] = (uint8_t)s;
         }
-    } else {
-        int x = x00, y = y00;
-        for (int p = lane; p < npix; p += 64) {
-            const int s = fastScore<TS>(tile + (y + 3) * TS + mis + x + 3);
-            score[(y + 1) * TS + x + 1] = (uint8_t)s;
-            x += qx; y += qy;
-            if (x >= cw) { x -= cw; y++; }
+    } else if (!(ORBX_FAST_SKIP & 1)) {
+        // one lane = the four pixels of one tile dword (two packed pairs); 21 dword reads feed 4 scores.  Score row y+1
+        // keeps the tile's column alignment, so the four scores are one dword store; bytes outside the interior
+        // (first / last dword of a row) are written as 0 = "outside the ROI interior".
+        const int q0 = (mis + 3) >> 2, q1 = (mis + 2 + cw) >> 2, nq = q1 - q0 + 1;
+        const int nItems = nq * ch;
+        const int lo = mis + 3 - 4 * q0, hi = mis + 3 + cw - 4 * q1;            // first valid byte of dword q0 / valid bytes of q1
+        const unsigned maskFirst = 0xFFFFFFFFu << (8 * lo), maskLast = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
+        const int sx = 64 % nq, sy = 64 / nq;
+        int qi = lane % nq, y = lane / nq;
+        for (int item = lane; item < nItems; item += 64) {
+            const uint8_t* base = tile + y * TS + 4 * (q0 + qi);                 // row y = centre row - 3
+            unsigned L[7], C[7], R[7];
+#pragma unroll
+            for (int d = 0; d < 7; d++) {
+                L[d] = *(const unsigned*)(base + d * TS - 4);
+                C[d] = *(const unsigned*)(base + d * TS);
+                R[d] = *(const unsigned*)(base + d * TS + 4);
+            }
+            unsigned rA[17], rB[17];
+            pairRing<0>(L, C, R, rA);
+            pairRing<2>(L, C, R, rB);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned sA = pairScore(rA);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned sB = pairScore(rB);
+            unsigned m = qi == 0 ? maskFirst : 0xFFFFFFFFu;
+            m = qi == nq - 1 ? (m & maskLast) : m;
+            *(unsigned*)(score + (y + 1) * TS + 4 * (q0 + qi)) = __builtin_amdgcn_perm(sB, sA, 0x06040200u) & m;
+            qi += sx; y += sy;
+            if (qi >= nq) { qi -= nq; y++; }
         }
     }
     waveLdsSync();
+    if (ORBX_FAST_SKIP & 2) { if (lane == 0) cellCount[(long long)f * nCells + ci] = 0u; return; }
 
     // ---- pass 2: strict local maxima (all 9 loads unconditional, 3-input max); survivors at minThFAST are
     //      appended in raster order to a list that reuses the pixel tile (no longer needed) ----
@@ -186,7 +293,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const CellDesc* __restrict__ ce
         for (int base = 0; base < npix; base += 64) {
             int s = 0, m = 255;
             if (base + lane < npix) {
-                const uint8_t* q = score + (y + 1) * TS + x + 1;
+                const uint8_t* q = score + (y + 1) * TS + mis + 3 + x;
                 s = q[0];
                 const unsigned a = vmax3(q[-TS - 1], q[-TS], q[-TS + 1]), b = vmax3(q[-1], q[1], q[TS - 1]);
                 m = (int)vmax3(a, b, max((unsigned)q[TS], (unsigned)q[TS + 1]));

@@ -173,8 +173,8 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
                 const int dist = __popc(w0 ^ d2w[s]) + __popc(w1 ^ d2w[capA + s]) + __popc(w2 ^ d2w[2 * capA + s]) +
                                  __popc(w3 ^ d2w[3 * capA + s]) + __popc(w4 ^ d2w[4 * capA + s]) + __popc(w5 ^ d2w[5 * capA + s]) +
                                  __popc(w6 ^ d2w[6 * capA + s]) + __popc(w7 ^ d2w[7 * capA + s]);
-                const bool in = (cy >= loCY) & (cy <= hiCY) & (fabsf(distx) < p.r) & (fabsf(disty) < p.r)    // Frame.cc:717
-                                & !(md <= dist);                                                             // :744-745
+                const bool in = (int)(cy >= loCY) & (int)(cy <= hiCY) & (int)(fabsf(distx) < p.r) & (int)(fabsf(disty) < p.r)    // Frame.cc:717
+                                & (int)!(md <= dist);                                                            // :744-745
                 if (in) {
                     if (dist < (key >> 16)) { second = key >> 16; key = (dist << 16) | s; }   // :747-752 (slots ascend per lane)
                     else if (dist < second) second = dist;                                     // :753-756
