@@ -78,27 +78,29 @@ __device__ __forceinline__ void pairRing(const unsigned (&L)[7], const unsigned 
     r[16] = pairAt<B>(L[3], C[3], R[3]);
 }
 // BRIGHT: max over the 16 arcs of the arc minimum (and the centre); else min over the arcs of the arc maximum (and the
-// centre).  One polarity at a time keeps 16 + 16 values live instead of 16 + 32.
+// centre).  Arcs k and k+1 (k even) share the 8 ring pixels k+1..k+8, and
+//     max(min(core, r_k), min(core, r_k+9)) = min(core, max(r_k, r_k+9)),
+// so 8 "arc pairs" replace 16 arcs.  The cores are two 4-runs starting at odd positions, each 4-run two 2-runs:
+// 8 + 8 + 8 (end points) + 8 (3-input) + 4 (reduction) = 36 instructions per polarity.
 template <bool BRIGHT>
 __device__ __forceinline__ unsigned arcExtreme(const unsigned (&r)[17]) {
-    unsigned x3[16];
+    unsigned x2[8], x4[8], g[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        x3[k] = BRIGHT ? pkmin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]) : pkmax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
-    unsigned g[6];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        unsigned x9[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int k = 3 * j + i;
-            x9[i] = BRIGHT ? pkmin3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]) : pkmax3(x3[k], x3[(k + 3) & 15], x3[(k + 6) & 15]);
-        }
-        g[j] = BRIGHT ? pkmax3(x9[0], x9[1], x9[2]) : pkmin3(x9[0], x9[1], x9[2]);
+    for (int i = 0; i < 8; i++) {            // x2[i] = extreme of ring pixels 2i+1, 2i+2
+        const int p = 2 * i + 1;
+        x2[i] = BRIGHT ? pkmin3(r[p], r[(p + 1) & 15], r[(p + 1) & 15]) : pkmax3(r[p], r[(p + 1) & 15], r[(p + 1) & 15]);
     }
-    g[5] = BRIGHT ? pkmin3(x3[15], x3[2], x3[5]) : pkmax3(x3[15], x3[2], x3[5]);      // arc 15
-    return BRIGHT ? pkmax3(pkmax3(g[0], g[1], g[2]), pkmax3(g[3], g[4], g[5]), r[16])
-                  : pkmin3(pkmin3(g[0], g[1], g[2]), pkmin3(g[3], g[4], g[5]), r[16]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)              // x4[i] = extreme of ring pixels 2i+1 .. 2i+4
+        x4[i] = BRIGHT ? pkmin3(x2[i], x2[(i + 1) & 7], x2[(i + 1) & 7]) : pkmax3(x2[i], x2[(i + 1) & 7], x2[(i + 1) & 7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {            // arcs 2i and 2i+1: core = pixels 2i+1 .. 2i+8, end points 2i and 2i+9
+        const int k = 2 * i;
+        const unsigned e = BRIGHT ? pkmax3(r[k], r[(k + 9) & 15], r[(k + 9) & 15]) : pkmin3(r[k], r[(k + 9) & 15], r[(k + 9) & 15]);
+        g[i] = BRIGHT ? pkmin3(x4[i], x4[(i + 2) & 7], e) : pkmax3(x4[i], x4[(i + 2) & 7], e);
+    }
+    return BRIGHT ? pkmax3(pkmax3(g[0], g[1], g[2]), pkmax3(g[3], g[4], g[5]), pkmax3(g[6], g[7], r[16]))
+                  : pkmin3(pkmin3(g[0], g[1], g[2]), pkmin3(g[3], g[4], g[5]), pkmin3(g[6], g[7], r[16]));
 }
 // S = max(maxMin - v, v - minMax): the centre took part in both reductions, so neither difference is negative
 __device__ __forceinline__ unsigned pairScore(const unsigned (&r)[17]) {
@@ -117,28 +119,28 @@ __device__ __forceinline__ int fastScore(const uint8_t* c) {
     r[4] = c[3];            r[5] = c[-TS + 3];      r[6] = c[-2 * TS + 2];  r[7] = c[-3 * TS + 1];
     r[8] = c[-3 * TS];      r[9] = c[-3 * TS - 1];  r[10] = c[-2 * TS - 2]; r[11] = c[-TS - 3];
     r[12] = c[-3];          r[13] = c[TS - 3];      r[14] = c[2 * TS - 2];  r[15] = c[3 * TS - 1];
-    const int v = c[0];
-    unsigned lo3[16], hi3[16];
+    const unsigned v = c[0];
+    // arc pairs as in arcExtreme: 36 instructions per polarity
+    unsigned lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = vmin3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
-        hi3[k] = vmax3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+    for (int i = 0; i < 8; i++) {
+        lo2[i] = min(r[2 * i + 1], r[(2 * i + 2) & 15]);
+        hi2[i] = max(r[2 * i + 1], r[(2 * i + 2) & 15]);
     }
-    unsigned lo9[16], hi9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo9[k] = vmin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);   // min of the arc k..k+8
-        hi9[k] = vmax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);   // max of the arc
+    for (int i = 0; i < 8; i++) {
+        lo4[i] = min(lo2[i], lo2[(i + 1) & 7]);
+        hi4[i] = max(hi2[i], hi2[(i + 1) & 7]);
     }
-    // brightest "darkest pixel of an arc" and darkest "brightest pixel of an arc"
-    unsigned a = vmax3(lo9[0], lo9[1], lo9[2]), b = vmax3(lo9[3], lo9[4], lo9[5]), cc = vmax3(lo9[6], lo9[7], lo9[8]),
-             d = vmax3(lo9[9], lo9[10], lo9[11]), e = vmax3(lo9[12], lo9[13], lo9[14]);
-    const unsigned maxMin = vmax3(vmax3(a, b, cc), vmax3(d, e, lo9[15]), 0u);
-    a = vmin3(hi9[0], hi9[1], hi9[2]); b = vmin3(hi9[3], hi9[4], hi9[5]); cc = vmin3(hi9[6], hi9[7], hi9[8]);
-    d = vmin3(hi9[9], hi9[10], hi9[11]); e = vmin3(hi9[12], hi9[13], hi9[14]);
-    const unsigned minMax = vmin3(vmin3(a, b, cc), vmin3(d, e, hi9[15]), 255u);
-    const int sDark = v - (int)minMax, sBright = (int)maxMin - v;
-    return max(max(sDark, sBright), 0);
+    unsigned gl[8], gh[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        gl[i] = vmin3(lo4[i], lo4[(i + 2) & 7], max(r[2 * i], r[(2 * i + 9) & 15]));
+        gh[i] = vmax3(hi4[i], hi4[(i + 2) & 7], min(r[2 * i], r[(2 * i + 9) & 15]));
+    }
+    const unsigned maxMin = vmax3(vmax3(gl[0], gl[1], gl[2]), vmax3(gl[3], gl[4], gl[5]), vmax3(gl[6], gl[7], v));
+    const unsigned minMax = vmin3(vmin3(gh[0], gh[1], gh[2]), vmin3(gh[3], gh[4], gh[5]), vmin3(gh[6], gh[7], v));
+    return (int)max(maxMin - v, v - minMax);
 }
 
 constexpr int kFastWaves = 4;

@@ -78,6 +78,9 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
         bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);    // bytes of the dword outside the bordered row are padding
         const ResizeX cx = xt[reflect101(bx - kEdge, d.w)];
         c0[j] = cx.sx0 - fx0; c1[j] = cx.sx1 - fx0; a0[j] = cx.a0; a1[j] = cx.a1;
+#ifdef ORBX_RESIZE_EXP   // diagnostic: conflict-free tap addresses (wrong pixels, same instruction count)
+        c0[j] = 4 * col + j; c1[j] = 4 * col + j;
+#endif
     }
     const int by0 = tileY * kTileRows + rgrp * kPyrRows;
     // the 32 rows' vertical coefficients go through LDS (a runtime-indexed register array would live in scratch)
