@@ -9,10 +9,8 @@ namespace orbx {
 // ================================================================================================
 // IC_Angle + rotated BRIEF + final placement.  One wave64 per kept keypoint.
 // ================================================================================================
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
-#include "orbx_brief_pattern.inc"
-};
 __constant__ int c_umax[16];
+__constant__ __attribute__((aligned(16))) float c_patternF[1024];   // the same pattern as floats (filled by uploadUmax)
 
 // cv::fastAtan2: every operation rounded separately in binary32.
 __device__ __forceinline__ float fastAtan2Deg(float y, float x) {
@@ -85,8 +83,10 @@ constexpr int kBlurRows = 2 * kBriefReach + 1;        // 37
 constexpr int kBlurStride = 40;                       // 3 + 37 bytes -> 10 dwords
 constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per keypoint (dword multiple)
 
-// One half-wave (32 lanes) per kept keypoint:
-//   * both patches are staged in LDS with aligned dword loads that are all in flight at once;
+// One half-wave (32 lanes) per kept keypoint; the two keypoints of a wave share a level (selOff is even):
+//   * both patches are staged in LDS with aligned dword loads that are all in flight at once: a half-wave covers
+//     three patch rows per step (lane = (row % 3, dword column)), so the address of step s is one add away from
+//     step 0's and the LDS destination is an immediate offset;
 //   * IC_Angle: lane = patch row; the row's 31 pixels are byte-aligned with v_alignbyte and reduced with
 //     v_dot4_u32_u8 against per-row weight words (u+16 inside the disc, 0 outside) — sum(u*I) = dot(I, u+16) - 16*dot(I, 1);
 //   * rBRIEF: lane = 8 of the 256 test pairs; a ballot per group of 32 pairs packs 4 descriptor bytes of each keypoint.
@@ -112,12 +112,13 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         wtab[which][a][j] = w;
     }
     __syncthreads();
-    const int slot = (blockIdx.x * kDescWaves + wave) * 2 + half;
-    // totals of this frame and the level this slot belongs to (per half-wave)
+    const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kDescWaves + wave) * 2);   // wave-uniform
+    const int slot = slot0 + half;
+    // totals of this frame and the level this wave belongs to (scalar: slot0 is uniform)
     int total = 0, totalLap = 0, level = 0, seqBase = 0, lapBase = 0;
     for (int l = 0; l < nlevels; l++) {
         const int c = levelCount[f * nlevels + l], lp = levelLap[f * nlevels + l];
-        if (slot >= lv[l].selOff) { level = l; seqBase = total; lapBase = totalLap; }
+        if (slot0 >= lv[l].selOff) { level = l; seqBase = total; lapBase = totalLap; }
         total += c;
         totalLap += lp;
     }
@@ -130,10 +131,9 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const int i = slot - selOff;
     const bool active = slot < selPerFrame && i < levelCount[f * nlevels + level];
     if (__ballot(active) == 0) return;
-    // per-half geometry (the two halves of a wave may sit in different levels)
     const int gw = lv[level].w, gh = lv[level].h, pyrStride = lv[level].pyrStride, blurStride = lv[level].blurStride;
-    const long long pyrBase = lv[level].pyrOff + (long long)f * lv[level].pyrFrameBytes;
-    const long long blurBase = lv[level].blurOff + (long long)f * lv[level].blurFrameBytes;
+    const uint8_t* pyrL = pyr + lv[level].pyrOff + (long long)f * lv[level].pyrFrameBytes;      // wave-uniform bases:
+    const uint8_t* blurL = blur + lv[level].blurOff + (long long)f * lv[level].blurFrameBytes;   // lanes add 32-bit offsets
     const uint2 e = active ? sel[(long long)f * selPerFrame + slot] : make_uint2(0u, 0u);
     int kx = e.x & 0xfff, ky = (e.x >> 12) & 0xfff;
     const float response = (float)(e.x >> 24);
@@ -148,29 +148,30 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const int rawCol0 = kPadL + kx - kHalfPatch, rawMis = rawCol0 & 3;
     const int blurCol0 = kx - kBriefReach, blurMis = blurCol0 & 3;
     {
-        const uint8_t* rp = pyr + pyrBase + (long long)(kEdge + ky - kHalfPatch) * pyrStride + (rawCol0 - rawMis);
-        const uint8_t* bp = blur + blurBase + (long long)(ky - kBriefReach) * blurStride + (blurCol0 - blurMis);
-        constexpr int nRaw = kRawRows * (kRawStride / 4), nBlur = kBlurRows * (kBlurStride / 4);
-        constexpr int steps = (nRaw + nBlur + 31) / 32;
-        unsigned w[steps];
+        constexpr int kRawDw = kRawStride / 4, kBlurDw = kBlurStride / 4;            // 9, 10 dwords per tile row
+        constexpr int kRawSteps = (kRawRows + 2) / 3, kBlurSteps = (kBlurRows + 2) / 3;   // 11, 13
+        const int rr = hl / kRawDw, rc = hl - rr * kRawDw;        // lanes 0..26: row (mod 3) and dword column of the raw tile
+        const int br = hl / kBlurDw, bcw = hl - br * kBlurDw;     // lanes 0..29: the same for the blurred tile
+        const bool rawLane = hl < 3 * kRawDw;
+        // the last dword of a blurred row can start past the row's padded end when the patch touches the right edge
+        const bool blurLane = hl < 3 * kBlurDw && blurCol0 - blurMis + 4 * bcw < blurStride;
+        const int rOff = (kEdge + ky - kHalfPatch + rr) * pyrStride + (rawCol0 - rawMis) + 4 * rc;
+        const int bOff = (ky - kBriefReach + br) * blurStride + (blurCol0 - blurMis) + 4 * bcw;
+        unsigned wr[kRawSteps], wb[kBlurSteps];
 #pragma unroll
-        for (int s = 0; s < steps; s++) {
-            const int idx = hl + 32 * s;
-            w[s] = 0u;
-            if (idx < nRaw) {
-                const int r = idx / (kRawStride / 4), c = idx - r * (kRawStride / 4);
-                w[s] = *(const unsigned*)(rp + r * pyrStride + 4 * c);
-            } else if (idx < nRaw + nBlur) {
-                const int k = idx - nRaw, r = k / (kBlurStride / 4), c = k - r * (kBlurStride / 4);
-                // the last dword of a row can start past the blurred row's padded end when the patch touches the right edge
-                if (blurCol0 - blurMis + 4 * c < blurStride) w[s] = *(const unsigned*)(bp + r * blurStride + 4 * c);
-            }
-        }
+        for (int s = 0; s < kRawSteps; s++)
+            wr[s] = (rawLane && rr + 3 * s < kRawRows) ? *(const unsigned*)(pyrL + (rOff + 3 * s * pyrStride)) : 0u;
 #pragma unroll
-        for (int s = 0; s < steps; s++) {
-            const int idx = hl + 32 * s;
-            if (idx < nRaw + nBlur) *(unsigned*)(rawT + 4 * idx) = w[s];   // the two tiles are adjacent and dword-granular
-        }
+        for (int s = 0; s < kBlurSteps; s++)
+            wb[s] = (blurLane && br + 3 * s < kBlurRows) ? *(const unsigned*)(blurL + (bOff + 3 * s * blurStride)) : 0u;
+        uint8_t* rdst = rawT + rr * kRawStride + 4 * rc;
+        uint8_t* bdst = blurT + br * kBlurStride + 4 * bcw;
+#pragma unroll
+        for (int s = 0; s < kRawSteps; s++)
+            if (rawLane && rr + 3 * s < kRawRows) *(unsigned*)(rdst + 3 * s * kRawStride) = wr[s];
+#pragma unroll
+        for (int s = 0; s < kBlurSteps; s++)
+            if (hl < 3 * kBlurDw && br + 3 * s < kBlurRows) *(unsigned*)(bdst + 3 * s * kBlurStride) = wb[s];
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int p = hl + 32 * j;        // test pair index; bit (p & 7) of descriptor byte (p >> 3)
-        const char4 pt = ((const char4*)c_pattern)[p];
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
+        const float4 pt = ((const float4*)c_patternF)[p];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
@@ -262,7 +263,16 @@ void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint
                        pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
                        outLevelCounts);
 }
-hipError_t uploadUmax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }
+static const int8_t kHostPattern[1024] = {
+#include "orbx_brief_pattern.inc"
+};
+hipError_t uploadUmax(const int* umax16) {
+    float pf[1024];
+    for (int i = 0; i < 1024; i++) pf[i] = (float)kHostPattern[i];
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_patternF), pf, sizeof(pf));
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+}
 
 
 }  // namespace orbx

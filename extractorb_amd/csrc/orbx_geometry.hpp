@@ -175,7 +175,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         L.cellCount = (int)g.cells.size() - L.cellFirst;
         L.candCap = (int)cap;
         int nodes = L.quota + 3 > 4 * L.nIni ? L.quota + 3 : 4 * L.nIni;
-        L.selCap = nodes + 1;
+        L.selCap = (nodes + 2) & ~1;   // even, so the two keypoints a wave of k_describe owns always share a level
         if (nodes + 1 > g.maxNodes) g.maxNodes = nodes + 1;
         L.selOff = g.selPerFrame;
         g.selPerFrame += L.selCap;
