@@ -190,9 +190,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             // bytes u = 4j-15 .. 4j-12 of the row: shift the dword pair by the patch's misalignment
-            const unsigned px = rawMis == 0 ? d[j] : (rawMis == 1 ? __builtin_amdgcn_alignbyte(d[j + 1], d[j], 1)
-                                                  : (rawMis == 2 ? __builtin_amdgcn_alignbyte(d[j + 1], d[j], 2)
-                                                                 : __builtin_amdgcn_alignbyte(d[j + 1], d[j], 3)));
+            const unsigned px = __builtin_amdgcn_alignbyte(d[j + 1], d[j], (unsigned)rawMis);   // the shift comes from a register
             s1 = __builtin_amdgcn_udot4(px, wtab[0][a][j], s1, false);
             s0 = __builtin_amdgcn_udot4(px, wtab[1][a][j], s0, false);
         }

@@ -37,8 +37,26 @@ struct SrcView {            // where a level's source pixels live
     int aligned;            // p, stride and frame are multiples of 4
 };
 
+__device__ __forceinline__ unsigned mulHi24(unsigned a, unsigned b) {     // (a[23:0] * b[23:0]) >> 32
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pkLshr2(unsigned a) {                  // both u16 halves >> 2
+    unsigned r;
+    // the shift count is per half too: an inline constant 2 would shift only the low half
+    asm("v_pk_lshrrev_b16 %0, %2, %1" : "=v"(r) : "v"(a), "s"(0x00020002u));
+    return r;
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 // cv::resize(INTER_LINEAR) 8u: horizontal pass in 11-bit fixed point, vertical pass with the (x>>4, >>16, +2>>2)
 // rounding; all products fit 24-bit multiplies.
+// PACKED (the host checked that the 8 taps of every dword column lie inside 8 consecutive source bytes): a source
+// row costs three LDS dword reads and two v_alignbyte for the thread's four pixels, then per pixel one v_perm
+// (the tap pair as two u16) and one v_dot2_u32_u16 against the packed weight pair; the vertical pass uses
+// (b << 12) * (h & ~15) >> 32 == (b * (h >> 4)) >> 16 in one v_mul_hi_u32_u24.
+template <bool PACKED>
 __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d, const ResizeX* __restrict__ xt,
                                            const ResizeX* __restrict__ yt, const TileFoot ft, uint8_t* __restrict__ pyr,
                                            int tileX, int tileY, int f, uint8_t* tile, int ldsStride) {
@@ -50,27 +68,8 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
     const int fx0 = ft.fx0, fy0 = ft.fy0, nDw = ft.nDw, nRows = ft.nRows;
     const uint8_t* sp = sv.p + (long long)f * sv.frame;
 
-    // ---- stage the footprint: 128 dword columns x 2 rows per step ----
-    {
-        const int c = tid & 127;
-        int srcOff = (fy0 + (tid >> 7)) * sv.stride + fx0 + 4 * c;
-        int ldsOff = (tid >> 7) * ldsStride + 4 * c;
-        for (int r = tid >> 7; r < nRows; r += 2, srcOff += 2 * sv.stride, ldsOff += 2 * ldsStride) {
-            for (int cc = c, so = srcOff, lo = ldsOff; cc < nDw; cc += 128, so += 512, lo += 512) {
-                unsigned w;
-                if (sv.aligned && fx0 + 4 * cc + 3 < sv.readableCols) {
-                    w = *(const unsigned*)(sp + so);
-                } else {
-                    w = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (fx0 + 4 * cc + b < sv.readableCols) w |= (unsigned)sp[so + b] << (8 * b);
-                }
-                *(unsigned*)(tile + lo) = w;
-            }
-        }
-    }
-    // ---- this thread's 4 columns: LDS byte offsets of the two taps and their 11-bit weights ----
+    // ---- this thread's 4 columns: LDS byte offsets of the two taps and their 11-bit weights (loads issued first,
+    //      so their latency overlaps the staging loads') ----
     int c0[4], c1[4], a0[4], a1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -78,17 +77,77 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
         bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);    // bytes of the dword outside the bordered row are padding
         const ResizeX cx = xt[reflect101(bx - kEdge, d.w)];
         c0[j] = cx.sx0 - fx0; c1[j] = cx.sx1 - fx0; a0[j] = cx.a0; a1[j] = cx.a1;
-#ifdef ORBX_RESIZE_EXP   // diagnostic: conflict-free tap addresses (wrong pixels, same instruction count)
-        c0[j] = 4 * col + j; c1[j] = 4 * col + j;
-#endif
     }
-    const int by0 = tileY * kTileRows + rgrp * kPyrRows;
     // the 32 rows' vertical coefficients go through LDS (a runtime-indexed register array would live in scratch)
     __shared__ ResizeX ycoef[kTileRows];
-    if (tid < kTileRows) ycoef[tid] = yt[reflect101(min(tileY * kTileRows + tid, d.pyrRows - 1) - kEdge, d.h)];
+    ResizeX myY{};
+    if (tid < kTileRows) myY = yt[reflect101(min(tileY * kTileRows + tid, d.pyrRows - 1) - kEdge, d.h)];
+
+    // ---- stage the footprint: 128 dword columns x 2 rows per step, kStageRows loads in flight per thread (a
+    //      load -> store loop would pay one memory latency per row pair) ----
+    {
+        constexpr int kStageRows = 12;
+        const int c = tid & 127, rsub = tid >> 7;
+        for (int cc = c; cc < nDw; cc += 128) {           // one trip unless a tile's footprint is wider than 512 bytes
+            const bool whole = sv.aligned && fx0 + 4 * cc + 3 < sv.readableCols;
+            const unsigned colOff = (unsigned)(fx0 + 4 * cc);
+            for (int rb = rsub; rb < nRows; rb += 2 * kStageRows) {
+                unsigned w[kStageRows];
+#pragma unroll
+                for (int k = 0; k < kStageRows; k++) {
+                    const int r = min(rb + 2 * k, nRows - 1);     // clamped: every lane loads, only valid rows are stored
+                    const uint8_t* q = sp + ((unsigned)((fy0 + r) * sv.stride) + colOff);
+                    if (whole) {
+                        w[k] = *(const unsigned*)q;
+                    } else {
+                        w[k] = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            if (fx0 + 4 * cc + b < sv.readableCols) w[k] |= (unsigned)q[b] << (8 * b);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kStageRows; k++)
+                    if (rb + 2 * k < nRows) *(unsigned*)(tile + (rb + 2 * k) * ldsStride + 4 * cc) = w[k];
+            }
+        }
+    }
+    if (tid < kTileRows) ycoef[tid] = myY;
     __syncthreads();
+    const int by0 = tileY * kTileRows + rgrp * kPyrRows;
     const ResizeX* cy = ycoef + rgrp * kPyrRows;
     uint8_t* dst = pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)by0 * d.pyrStride + bc0;
+    if constexpr (PACKED) {
+        int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
+        const int base = lo & ~3;
+        const unsigned sh = (unsigned)(lo & 3);
+        unsigned sel[4];
+        u16x2 wt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sel[j] = 0x0C000C00u | (unsigned)(c0[j] - lo) | ((unsigned)(c1[j] - lo) << 16);
+            wt[j] = u16x2{(unsigned short)a0[j], (unsigned short)a1[j]};
+        }
+#pragma unroll 2
+        for (int r = 0; r < kPyrRows; r++) {
+            const unsigned* r0 = (const unsigned*)(tile + __mul24(cy[r].sx0 - fy0, ldsStride) + base);
+            const unsigned* r1 = (const unsigned*)(tile + __mul24(cy[r].sx1 - fy0, ldsStride) + base);
+            const unsigned b0 = (unsigned)cy[r].a0 << 12, b1 = (unsigned)cy[r].a1 << 12;
+            const unsigned p0 = r0[0], p1 = r0[1], p2 = r0[2], q0 = r1[0], q1 = r1[1], q2 = r1[2];
+            const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
+            const unsigned Q0 = __builtin_amdgcn_alignbyte(q1, q0, sh), Q1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
+            unsigned t[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[j])), wt[j], 0u, false);
+                const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(Q1, Q0, sel[j])), wt[j], 0u, false);
+                t[j] = mulHi24(b0, h0 & ~15u) + mulHi24(b1, h1 & ~15u) + 2u;
+            }
+            const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
+            if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);
+        }
+        return;
+    }
     // two rows per trip: enough LDS reads in flight without holding all 128 taps of the thread in registers
 #pragma unroll 2
     for (int r = 0; r < kPyrRows; r++) {
@@ -140,6 +199,7 @@ __device__ __forceinline__ void copyTile(const SrcView& sv, const LevelGeom& g0,
 
 // grid (nTiles0 + nTiles1, B): the first tiles copy the caller's image into bordered level 0, the rest build
 // bordered level 1 from the caller's image (== level 0's interior).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, LevelGeom g1, int tilesX0, int nTiles0,
                                                     int tilesX1, const ResizeX* __restrict__ xt, const ResizeX* __restrict__ yt,
                                                     const TileFoot* __restrict__ foot, uint8_t* __restrict__ pyr, int ldsStride) {
@@ -151,11 +211,12 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
     } else {
         t -= nTiles0;
         const int tileY = t / tilesX1;
-        resizeTile(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, blockIdx.y, tile, ldsStride);
+        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, blockIdx.y, tile, ldsStride);
     }
 }
 
 // grid (tilesX*tilesY, B): level d from level s of the pyramid.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt,
                                                  const ResizeX* __restrict__ yt, const TileFoot* __restrict__ foot,
                                                  uint8_t* __restrict__ pyr, int ldsStride) {
@@ -164,23 +225,28 @@ __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int ti
     sv.p = pyr + s.pyrOff + (long long)kEdge * s.pyrStride + kPadL;
     sv.stride = s.pyrStride; sv.frame = s.pyrFrameBytes; sv.readableCols = s.w + kEdge; sv.aligned = 1;
     const int tileY = blockIdx.x / tilesX;
-    resizeTile(sv, d, xt, yt, foot[blockIdx.x], pyr, blockIdx.x - tileY * tilesX, tileY, blockIdx.y, tile, ldsStride);
+    resizeTile<PACKED>(sv, d, xt, yt, foot[blockIdx.x], pyr, blockIdx.x - tileY * tilesX, tileY, blockIdx.y, tile, ldsStride);
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,
                     const LevelGeom* g1, int tilesX0, int tilesY0, int tilesX1, int tilesY1, const ResizeX* xt,
-                    const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, int B) {
+                    const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int B) {
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = g0.w;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
     const int n0 = tilesX0 * tilesY0, n1 = g1 ? tilesX1 * tilesY1 : 0;
-    hipLaunchKernelGGL(k_pyr_first, dim3(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows, st, sv, g0, g1 ? *g1 : g0,
-                       tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride);
+    // + 16: the packed path reads three dwords from the first tap's dword, i.e. up to 8 bytes past a row's footprint
+    if (packed) hipLaunchKernelGGL(k_pyr_first<true>, dim3(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
+                                   g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride);
+    else hipLaunchKernelGGL(k_pyr_first<false>, dim3(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
+                            g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride);
 }
 void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt,
-                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, int B) {
-    hipLaunchKernelGGL(k_resize, dim3(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows, st, s, d, tilesX, xt, yt,
-                       foot, pyr, ldsStride);
+                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int B) {
+    if (packed) hipLaunchKernelGGL(k_resize<true>, dim3(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
+                                   tilesX, xt, yt, foot, pyr, ldsStride);
+    else hipLaunchKernelGGL(k_resize<false>, dim3(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
+                            tilesX, xt, yt, foot, pyr, ldsStride);
 }
 
 }  // namespace orbx

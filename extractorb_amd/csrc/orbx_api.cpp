@@ -17,9 +17,9 @@
 namespace orbx {
 // launch wrappers, defined in the k_*.hip files
 void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
-                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, int);
+                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
-                  uint8_t*, int, int, int);
+                  uint8_t*, int, int, bool, int);
 void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int);
@@ -114,6 +114,7 @@ struct orbx_handle {
     // when most can (noise: 55 %).  Chosen from the candidate density of the previous batch of the stream, read back
     // asynchronously (never waited for); ORBX_FAST_PREFILTER=0/1 forces a variant.
     int fastMode = -1;              // -1 auto, 0 direct, 1 prefilter
+    bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
     hipEvent_t statEvent = nullptr;
@@ -265,12 +266,13 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         Prof p(h, S_LEVEL0);
         launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
                        g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
-                       g.tileLdsStride, g.tileLdsRows, B);
+                       g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, B);
     }
     for (int l = 2; l < g.nlevels; l++) {
         Prof p(h, S_RESIZE);
         launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
-                     h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, B);
+                     h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
+                     g.packedTaps[l] && !h->resizeBytewise, B);
     }
     { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     if (h->statPending && hipEventQuery(h->statEvent) == hipSuccess) {
@@ -457,6 +459,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
+    h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;   // diagnostic: the byte-gather form of k_resize
     CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));

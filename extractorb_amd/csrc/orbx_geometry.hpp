@@ -10,6 +10,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,7 @@ struct FrameGeom {
     std::vector<TileFoot> foot[kMaxLevels];  // per 256x32 tile of bordered level l (l >= 1), row-major over tiles
     int tilesX[kMaxLevels] = {}, tilesY[kMaxLevels] = {};
     int tileLdsStride = 16, tileLdsRows = 1; // LDS tile able to hold the largest footprint
+    bool packedTaps[kMaxLevels] = {};        // level l: the 8 source taps of every aligned 4-pixel group span <= 8 bytes
     long long pyrBytesPerFrame = 0, blurBytesPerFrame = 0;
     long long candPerFrame = 0;              // sum of candCap
     int selPerFrame = 0;                     // sum of selCap
@@ -192,6 +194,18 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
             g.tilesY[l] = (L.pyrRows + 31) / 32;
             auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
             if (l > 0) {
+                bool packed = true;      // k_resize's packed path gathers a dword column's taps from one 8-byte window
+                for (int dw = 0; dw < nd; dw++) {
+                    int lo = 1 << 30, hi = -1;
+                    for (int j = 0; j < 4; j++) {
+                        int bx = 4 * dw + j - (kPadL - kEdge);
+                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                        const ResizeX& c = g.rx[l][refl(bx - kEdge, L.w)];
+                        lo = std::min(lo, (int)std::min(c.sx0, c.sx1)); hi = std::max(hi, (int)std::max(c.sx0, c.sx1));
+                    }
+                    if (hi - lo > 7) packed = false;
+                }
+                g.packedTaps[l] = packed;
                 for (int ty = 0; ty < g.tilesY[l]; ty++)
                     for (int tx = 0; tx < g.tilesX[l]; tx++) {
                         int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
