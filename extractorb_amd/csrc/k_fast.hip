@@ -213,6 +213,9 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     const int npix = cw * ch;
     const int qx = 64 % cw, qy = 64 / cw;               // how (x, y) advance when the pixel index advances by 64
     const int x00 = lane % cw, y00 = lane / cw;
+    // "items" of the packed passes: one tile dword (4 pixels) of an interior row; q0..q1 are the dwords that touch it
+    const int q0 = (mis + 3) >> 2, q1 = (mis + 2 + cw) >> 2, nq = q1 - q0 + 1;
+    const int nItems = nq * ch;
     // ---- pass 1: scores ----
     if (PREFILTER) {
         // 1a. cheap exact rejection: a 9-arc contains one pixel of every opposite ring pair, so a bright (dark) corner
@@ -254,8 +257,6 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         // one lane = the four pixels of one tile dword (two packed pairs); 21 dword reads feed 4 scores.  Score row y+1
         // keeps the tile's column alignment, so the four scores are one dword store; bytes outside the interior
         // (first / last dword of a row) are written as 0 = "outside the ROI interior".
-        const int q0 = (mis + 3) >> 2, q1 = (mis + 2 + cw) >> 2, nq = q1 - q0 + 1;
-        const int nItems = nq * ch;
         const int lo = mis + 3 - 4 * q0, hi = mis + 3 + cw - 4 * q1;            // first valid byte of dword q0 / valid bytes of q1
         const unsigned maskFirst = 0xFFFFFFFFu << (8 * lo), maskLast = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
         const int sx = 64 % nq, sy = 64 / nq;
@@ -286,30 +287,59 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     waveLdsSync();
     if (ORBX_FAST_SKIP & 2) { if (lane == 0) cellCount[(long long)f * nCells + ci] = 0u; return; }
 
-    // ---- pass 2: strict local maxima (all 9 loads unconditional, 3-input max); survivors at minThFAST are
-    //      appended in raster order to a list that reuses the pixel tile (no longer needed) ----
+    // ---- pass 2: strict local maxima, four pixels per lane (the score rows keep the tile's dword grid): nine dword
+    //      reads, the 3 x 5 neighbour pairs by v_perm, packed 3-input maxima with minThFAST folded in, so
+    //      "keep" is simply S > max.  Survivors are appended in raster order (lane order, then pixel order inside the
+    //      lane) to a list that reuses the pixel tile (no longer needed) ----
     unsigned* list = (unsigned*)tile;                   // entry: x | y << 6 | S << 12
-    int nIni = 0, nMin = 0;
+    int nMin = 0;
     {
-        int x = x00, y = y00;
-        for (int base = 0; base < npix; base += 64) {
-            int s = 0, m = 255;
-            if (base + lane < npix) {
-                const uint8_t* q = score + (y + 1) * TS + mis + 3 + x;
-                s = q[0];
-                const unsigned a = vmax3(q[-TS - 1], q[-TS], q[-TS + 1]), b = vmax3(q[-1], q[1], q[TS - 1]);
-                m = (int)vmax3(a, b, max((unsigned)q[TS], (unsigned)q[TS + 1]));
+        const unsigned thPair = (unsigned)minTh | ((unsigned)minTh << 16);
+        const int sx = 64 % nq, sy = 64 / nq;
+        int qi = lane % nq, y = lane / nq;
+        for (int item0 = 0; item0 < nItems; item0 += 64) {
+            const bool act = item0 + lane < nItems;
+            const uint8_t* base = score + (act ? y * TS + 4 * (q0 + qi) : 4);     // score row y = the row above the centre row
+            unsigned U[3], M[3], D[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                U[k] = *(const unsigned*)(base + 4 * k - 4);
+                M[k] = *(const unsigned*)(base + TS + 4 * k - 4);
+                D[k] = *(const unsigned*)(base + 2 * TS + 4 * k - 4);
             }
-            const bool keepMin = s > m && s > minTh;
-            const unsigned long long bMin = __ballot(keepMin);
-            if (keepMin) list[nMin + __popcll(bMin & ((1ull << lane) - 1))] = (unsigned)x | ((unsigned)y << 6) | ((unsigned)s << 12);
-            nMin += __popcll(bMin);
-            nIni += __popcll(__ballot(keepMin && s > iniTh));
-            x += qx; y += qy;
-            if (x >= cw) { x -= cw; y++; }
+            // pairs a..e = bytes (3,4) (4,5) (5,6) (6,7) (7,8) of L|C|R; up/down maxima per pair column, threshold folded in
+            const unsigned Wa = pkmax3(pairAt<3>(U[0], U[1], U[2]), pairAt<3>(D[0], D[1], D[2]), thPair);
+            const unsigned Wb = pkmax3(pairAt<4>(U[0], U[1], U[2]), pairAt<4>(D[0], D[1], D[2]), thPair);
+            const unsigned Wc = pkmax3(pairAt<5>(U[0], U[1], U[2]), pairAt<5>(D[0], D[1], D[2]), thPair);
+            const unsigned Wd = pkmax3(pairAt<6>(U[0], U[1], U[2]), pairAt<6>(D[0], D[1], D[2]), thPair);
+            const unsigned We = pkmax3(pairAt<7>(U[0], U[1], U[2]), pairAt<7>(D[0], D[1], D[2]), thPair);
+            const unsigned Ma = pairAt<3>(M[0], M[1], M[2]), Mc = pairAt<5>(M[0], M[1], M[2]), Me = pairAt<7>(M[0], M[1], M[2]);
+            const unsigned sA = pairAt<4>(M[0], M[1], M[2]), sB = pairAt<6>(M[0], M[1], M[2]);
+            const unsigned mA = pkmax3(pkmax3(Wa, Wb, Wc), Ma, Mc), mB = pkmax3(pkmax3(Wc, Wd, We), Mc, Me);
+            unsigned dA, dB;                             // per half: S - max, saturated at 0: nonzero <=> strict maximum above minThFAST
+            asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dA) : "v"(sA), "v"(mA));
+            asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dB) : "v"(sB), "v"(mB));
+            const bool f0 = act && (dA & 0xFFFFu) != 0, f1 = act && dA > 0xFFFFu, f2 = act && (dB & 0xFFFFu) != 0, f3 = act && dB > 0xFFFFu;
+            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
+            if (b0 | b1 | b2 | b3) {
+                const unsigned long long lt = (1ull << lane) - 1;
+                int at = nMin + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+                const unsigned xy = (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6);   // pixel 0 of the dword (x may be "negative": only kept pixels are used)
+                if (f0) list[at++] = xy | ((sA & 0xFFFFu) << 12);
+                if (f1) list[at++] = (xy + 1) | ((sA >> 16) << 12);
+                if (f2) list[at++] = (xy + 2) | ((sB & 0xFFFFu) << 12);
+                if (f3) list[at++] = (xy + 3) | ((sB >> 16) << 12);
+                nMin += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+            }
+            qi += sx; y += sy;
+            if (qi >= nq) { qi -= nq; y++; }
         }
     }
+    waveLdsSync();
     // the reference retries the cell at minThFAST only when the first call returned nothing (:835-838)
+    int nIni = 0;
+    for (int i0 = 0; i0 < nMin; i0 += 64)
+        nIni += __popcll(__ballot(i0 + lane < nMin && (int)(list[i0 + lane] >> 12) > iniTh));
     const bool useIni = nIni > 0;
     const int total = useIni ? nIni : nMin;
     // every cell owns a fixed, exactly sized segment of the level's candidate arena (no two 8-adjacent NMS survivors
@@ -317,7 +347,6 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     // segments in cell order, which is the reference's vToDistributeKeys order (cell row, cell column, y, x)
     if (lane == 0) cellCount[(long long)f * nCells + ci] = (unsigned)total;
     if (total == 0) return;
-    waveLdsSync();
     unsigned base = 0;
     unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
     const unsigned segCap = (unsigned)(((cw + 1) >> 1) * ((ch + 1) >> 1));
