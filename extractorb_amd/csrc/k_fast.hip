@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
     // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword
     __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
     const int ci = blockIdx.x * kFastWaves + wave, f = blockIdx.y;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
@@ -190,14 +190,17 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     const int mis = gx0 & 3;                            // its offset inside the first dword
     const int nd = (mis + roiW + 3) >> 2;               // dwords per row actually needed (<= DW)
     {
+        // wave-uniform base + 32-bit lane offsets; rows / dword columns past the ROI are clamped, not predicated (their
+        // tile bytes are never read by an interior pixel)
         const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride + (gx0 - mis);
         const int dcol = lane & (LPR - 1), rsub = lane / LPR;
+        const unsigned colOff = 4u * (unsigned)min(dcol, nd - 1);
+        const unsigned off0 = (unsigned)__mul24(rsub, g.pyrStride) + colOff, offMax = (unsigned)__mul24(roiH - 1, g.pyrStride) + colOff;
+        const unsigned stepOff = (unsigned)(RPI * g.pyrStride);
         unsigned w[STEPS];
 #pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            const int r = s * RPI + rsub;
-            w[s] = (!(ORBX_FAST_SKIP & 4) && dcol < nd && r < roiH) ? *(const unsigned*)(sp + (long long)r * g.pyrStride + 4 * dcol) : 0u;
-        }
+        for (int s = 0; s < STEPS; s++)
+            w[s] = (ORBX_FAST_SKIP & 4) ? 0u : *(const unsigned*)(sp + min(off0 + s * stepOff, offMax));
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             const int r = s * RPI + rsub;
@@ -322,8 +325,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
             const bool f0 = act && (dA & 0xFFFFu) != 0, f1 = act && dA > 0xFFFFu, f2 = act && (dB & 0xFFFFu) != 0, f3 = act && dB > 0xFFFFu;
             const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
             if (b0 | b1 | b2 | b3) {
-                const unsigned long long lt = (1ull << lane) - 1;
-                int at = nMin + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+                int at = nMin;                           // + kept pixels of the lower lanes: one v_mbcnt pair per ballot
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, at));
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, at));
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, at));
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, at));
                 const unsigned xy = (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6);   // pixel 0 of the dword (x may be "negative": only kept pixels are used)
                 if (f0) list[at++] = xy | ((sA & 0xFFFFu) << 12);
                 if (f1) list[at++] = (xy + 1) | ((sA >> 16) << 12);
