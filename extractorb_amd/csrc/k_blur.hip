@@ -25,18 +25,14 @@ __device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
     return __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
 }
 
-// items: one per (level, row block); lanes of the whole grid.x enumerate (item, column group) pairs.
-__global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items, int nLanes, const LevelGeom* __restrict__ lv,
+// items: one per (level, row block); lanes of the whole grid.x enumerate (item, column group) pairs; laneItem[lane]
+// names the lane's item (a per-thread binary search would start every workgroup with eight dependent loads).
+__global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items, const unsigned short* __restrict__ laneItem,
+                                               int nLanes, const LevelGeom* __restrict__ lv,
                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     const int gl = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (gl >= nLanes) return;
-    // binary search the item whose lane range holds gl (items are sorted by firstLane; <= ~200 of them)
-    int lo = 0, hi = (int)items[0].count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].firstLane <= gl) lo = mid; else hi = mid - 1;
-    }
-    const BlurItem it = items[lo];
+    const BlurItem it = items[laneItem[gl]];      // host table: the (level, row block) this lane works on
     const LevelGeom g = lv[it.level];
     const int grp = gl - it.firstLane;          // column group inside the row block
     const int x0 = 4 * grp, y0 = it.y0;
@@ -78,9 +74,9 @@ __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items
     }
 }
 
-void launchBlur(hipStream_t st, const BlurItem* items, int nLanes, const LevelGeom* lv, const uint8_t* pyr, uint8_t* blur,
-                int B) {
-    hipLaunchKernelGGL(k_blur, dim3((nLanes + 255) / 256, B), dim3(256), 0, st, items, nLanes, lv, pyr, blur);
+void launchBlur(hipStream_t st, const BlurItem* items, const unsigned short* laneItem, int nLanes, const LevelGeom* lv,
+                const uint8_t* pyr, uint8_t* blur, int B) {
+    hipLaunchKernelGGL(k_blur, dim3((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur);
 }
 
 }  // namespace orbx

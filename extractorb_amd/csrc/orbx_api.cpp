@@ -20,7 +20,7 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int);
-void launchBlur(hipStream_t, const BlurItem*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
+void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
@@ -92,6 +92,8 @@ struct orbx_handle {
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel
+    unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid
+    size_t laneCap = 0;
     int nBlurLanes = 0;
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
@@ -152,7 +154,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_outK,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -197,15 +199,19 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         fo += g.foot[l].size();
     }
     std::vector<BlurItem> tiles;
+    std::vector<unsigned short> laneItem;
     int lanes = 0;
     for (int l = 0; l < g.nlevels; l++)
         for (int y0 = 0; y0 < g.lv[l].h; y0 += 32) {
+            laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)tiles.size());
             tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
             lanes += (g.lv[l].w + 3) / 4;
         }
     tiles[0].count = (int)tiles.size();
-    if (tiles.size() > h->tileCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
+    if (tiles.size() > h->tileCap || tiles.size() > 65535 || laneItem.size() > h->laneCap)
+        return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
     HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size(), hipMemcpyHostToDevice));
     h->nBlurLanes = lanes;
     h->geom = g;
     return ORBX_OK;
@@ -274,7 +280,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                      h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                      g.packedTaps[l] && !h->resizeBytewise, B);
     }
-    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
+    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     if (h->statPending && hipEventQuery(h->statEvent) == hipSuccess) {
         long long total = 0;
         for (int i = 0; i < h->statB * g.nlevels; i++) total += h->h_candStat[i];
@@ -410,6 +416,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->cellCap = roomy(mg.cells.size());
     h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
     h->tileCap = roomy((size_t)((max_width + 63) / 64 + 1) * ((max_height + 31) / 32 + 1) * nlevels);
+    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * ((max_height + 31) / 32 + 1) * nlevels);
     // quad-tree LDS: M nodes (multiple of 8), P = next power of two for the bitonic sort
     int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
     M = (M + 7) / 8 * 8;
@@ -446,6 +453,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_rx, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurItem) * h->tileCap));
+    CREATE_TRY(hipMalloc(&h->d_laneItem, sizeof(unsigned short) * h->laneCap));
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_TRY(hipMalloc(&h->d_foot, sizeof(TileFoot) * h->footCap));
     const size_t oc = (size_t)h->outCap * max_batch;
