@@ -22,10 +22,10 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p >= n ? 2 * (n - 1) - p : p;
 }
 
-constexpr int kPyrRows = 8;      // destination rows per thread
+constexpr int kPyrRows = kResizeTileRows / 4;   // destination rows per thread
 constexpr int kTileCols = 64;    // dword columns per workgroup tile (256 pixels)
 constexpr int kTileRowGroups = 4;
-constexpr int kTileRows = kPyrRows * kTileRowGroups;   // 32 destination rows per workgroup tile
+constexpr int kTileRows = kPyrRows * kTileRowGroups;   // destination rows per workgroup tile
 
 static __host__ __device__ inline int rowDwords(const LevelGeom& g) { return (kPadL - kEdge + g.w + 2 * kEdge + 3) / 4; }
 

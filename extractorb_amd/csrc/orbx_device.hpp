@@ -57,7 +57,9 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
 };
 static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
 
-// Source footprint of one 256 x 32 destination tile of the resize kernel (host-computed from the coefficient tables)
+constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
+
+// Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
 struct TileFoot { short fx0, nDw, fy0, nRows; };   // first source column (multiple of 4), dwords per row, first row, rows
 
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)

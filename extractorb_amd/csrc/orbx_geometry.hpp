@@ -104,7 +104,7 @@ struct FrameGeom {
     std::vector<CellDesc> cells;             // all levels, level 0 first, raster order inside a level
     std::vector<ResizeX> rx[kMaxLevels];     // level l from level l-1 (l >= 1)
     std::vector<ResizeX> ry[kMaxLevels];
-    std::vector<TileFoot> foot[kMaxLevels];  // per 256x32 tile of bordered level l (l >= 1), row-major over tiles
+    std::vector<TileFoot> foot[kMaxLevels];  // per 256 x kResizeTileRows tile of bordered level l (l >= 1), row-major over tiles
     int tilesX[kMaxLevels] = {}, tilesY[kMaxLevels] = {};
     int tileLdsStride = 16, tileLdsRows = 1; // LDS tile able to hold the largest footprint
     bool packedTaps[kMaxLevels] = {};        // level l: the 8 source taps of every aligned 4-pixel group span <= 8 bytes
@@ -187,11 +187,11 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
             resizeAxis(g.lv[l - 1].w, L.w, true, g.rx[l]);
             resizeAxis(g.lv[l - 1].h, L.h, false, g.ry[l]);
         }
-        // tiles of the bordered level: 64 dword columns x 32 rows; their source footprints
+        // tiles of the bordered level: 64 dword columns x kResizeTileRows rows; their source footprints
         {
             const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
             g.tilesX[l] = (nd + 63) / 64;
-            g.tilesY[l] = (L.pyrRows + 31) / 32;
+            g.tilesY[l] = (L.pyrRows + kResizeTileRows - 1) / kResizeTileRows;
             auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
             if (l > 0) {
                 bool packed = true;      // k_resize's packed path gathers a dword column's taps from one 8-byte window
@@ -218,7 +218,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                                 sx0 = c.sx0 < sx0 ? c.sx0 : sx0; sx1 = c.sx1 > sx1 ? c.sx1 : sx1;
                             }
                         }
-                        for (int by = ty * 32; by < ty * 32 + 32; by++) {
+                        for (int by = ty * kResizeTileRows; by < (ty + 1) * kResizeTileRows; by++) {
                             const int b = by < L.pyrRows ? by : L.pyrRows - 1;
                             const ResizeX& c = g.ry[l][refl(b - kEdge, L.h)];
                             sy0 = c.sx0 < sy0 ? c.sx0 : sy0; sy1 = c.sx1 > sy1 ? c.sx1 : sy1;
