@@ -29,6 +29,8 @@ WORKLOADS = {
     # configs[2]
     "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=64, variant="noise",
                    desc="1920x1080 mono stream, 8 levels, 2000 features, synthetic noise frames"),
+    "hd720": dict(rows=720, cols=1280, nfeatures=1500, lapping=(0, 1000), batch=128, variant="noise",
+                  desc="1280x720 mono stream, 8 levels, 1500 features (between configs[1] and configs[2])"),
     # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
     "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="noise",
                       desc="stereo 640x480 L+R pairs (128 pairs per step), 8 levels, 1200 features per eye"),

@@ -25,7 +25,7 @@ void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const 
                 int, int, bool, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, int);
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
@@ -116,6 +116,9 @@ struct orbx_handle {
     // when most can (noise: 55 %).  Chosen from the candidate density of the previous batch of the stream, read back
     // asynchronously (never waited for); ORBX_FAST_PREFILTER=0/1 forces a variant.
     int fastMode = -1;              // -1 auto, 0 direct, 1 prefilter
+    int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
+                                       // chosen by the image area — separate launches per size measured slower)
+    int octThreadsForced = 0;          // ORBX_OCT_THREADS
     bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
@@ -213,6 +216,12 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size(), hipMemcpyHostToDevice));
     h->nBlurLanes = lanes;
+    {
+        const long long px = (long long)g.lv[0].w * g.lv[0].h;
+        int T = px <= 500000 ? 256 : 1024;     // measured: 640x480 -> 256 (0.16 vs 0.25 ms per 256 frames), 1280x720 and 1920x1080 -> 1024
+        if (h->octThreadsForced == 256 || h->octThreadsForced == 512 || h->octThreadsForced == 1024) T = h->octThreadsForced;
+        for (int l = 0; l < g.nlevels; l++) h->octThreads[l] = T;
+    }
     h->geom = g;
     return ORBX_OK;
 }
@@ -297,7 +306,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         Prof p(h, S_OCTREE);
         launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                      h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, B);
+                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, h->octThreads, B);
     }
     if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
@@ -467,7 +476,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
-    h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;   // diagnostic: the byte-gather form of k_resize
+    h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
+    if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024   // diagnostic: the byte-gather form of k_resize
     CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));
