@@ -45,6 +45,9 @@ WORKLOADS = {
                               "AssignFeaturesToGrid + SearchForInitialization(frame i, frame i+1)"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# integer / packed VALU issue: one wave64 instruction per 4.15 cycles per SIMD at 2.4 GHz (tools/ubench/valu_rate.hip,
+# profiles/r01_valu_issue_rate.md) x 1024 SIMDs
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.15
 
 
 def main():
@@ -211,11 +214,23 @@ def main():
                 traffic = tj.get(args.workload, {}).get(str(B), {}).get(dominant)
             except Exception:
                 traffic = None
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu.json")           # PMC SQ_INSTS_VALU per launch, if collected
+        if os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath)).get(args.workload, {}).get(str(B), {}).get(dominant)
+                if vj:
+                    g_instr = vj["SQ_INSTS_VALU"] / (dom_avg_ms * 1e-3) / 1e9
+                    valu = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
+                                peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
+                                note="the dominant kernel is bound by vector-instruction issue, not by HBM: this is its binding roofline")
+            except Exception:
+                valu = None
         roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),
                         path_achieved=round(fps / N * b_alg / 1e9, 2), path_frac=round(fps / N * b_alg / 1e9 / HBM_PEAK_GBS, 5),
-                        kernel_ms_per_step={k: round(v, 4) for k, v in sorted(per_step_ms.items())})
+                        kernel_ms_per_step={k: round(v, 4) for k, v in sorted(per_step_ms.items())}, valu_issue=valu)
         cpu = None
         if N == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

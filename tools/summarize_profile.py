@@ -3,6 +3,7 @@
 
   python tools/summarize_profile.py stats <kernel_stats.csv> <out.md> "<title>" "<command>"
   python tools/summarize_profile.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <batch> <out.json> <out.md>
+  python tools/summarize_profile.py valu <sq_summary.md> <workload> <batch> <out.json>     (SQ_INSTS_VALU per launch per kernel)
 """
 import collections, csv, json, os, sys
 
@@ -49,8 +50,22 @@ def traffic(fetch_csv, write_csv, workload, batch, out_json, out_md):
     json.dump(data, open(out_json, "w"), indent=1, sort_keys=True)
 
 
+def valu(sq_md, workload, batch, out_json):
+    lines = [l for l in open(sq_md) if l.startswith("|")]
+    names = [c.strip() for c in lines[0].strip().strip("|").split("|")]
+    data = json.load(open(out_json)) if os.path.exists(out_json) else {}
+    per = data.setdefault(workload, {}).setdefault(str(batch), {})
+    for l in lines[2:]:
+        cells = [c.strip() for c in l.strip().strip("|").split("|")]
+        row = dict(zip(names, cells))
+        per[row["kernel"]] = {k: float(row[k]) for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU") if k in row and row[k] != "-"}
+    json.dump(data, open(out_json, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(*sys.argv[2:6])
+    elif sys.argv[1] == "valu":
+        valu(*sys.argv[2:6])
     else:
         traffic(*sys.argv[2:9])
