@@ -185,16 +185,19 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     uint8_t* score = tile + kTileBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
 
-    // ---- stage the ROI: row r of the tile holds the aligned dwords covering pixels [x0, x0+roiW) ----
-    const int gx0 = kPadL + c.x0;                       // byte column of the ROI's first pixel in the bordered row
-    const int mis = gx0 & 3;                            // its offset inside the first dword
-    const int nd = (mis + roiW + 3) >> 2;               // dwords per row actually needed (<= DW)
+    // ---- stage the ROI, re-aligned: tile byte k of row r is ROI pixel (k - 1, r), whatever the ROI's alignment in
+    //      HBM, so the interior (ROI pixels 3 ..) always starts on a dword of the tile.  The packed passes walk the
+    //      interior dword by dword: a 31- or 32-pixel cell is then 8 dwords wide, not 9, and its 8 x 32 four-pixel
+    //      items are exactly 4 wave iterations.  Cost: the lane's right neighbour's dword (DPP) and one v_alignbyte. ----
+    const int gx1 = kPadL + c.x0 - 1;                   // byte column of tile byte 0 in the bordered row
+    const int gsh = gx1 & 3;                            // its offset inside the aligned dword the lanes load
+    constexpr int mis = 1;                              // tile byte of ROI pixel 0 (the passes below are written for any value)
     {
         // wave-uniform base + 32-bit lane offsets; rows / dword columns past the ROI are clamped, not predicated (their
         // tile bytes are never read by an interior pixel)
-        const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride + (gx0 - mis);
+        const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride + (gx1 - gsh);
         const int dcol = lane & (LPR - 1), rsub = lane / LPR;
-        const unsigned colOff = 4u * (unsigned)min(dcol, nd - 1);
+        const unsigned colOff = 4u * (unsigned)min(dcol, (gsh + roiW) >> 2);    // last dword holding a needed byte
         const unsigned off0 = (unsigned)__mul24(rsub, g.pyrStride) + colOff, offMax = (unsigned)__mul24(roiH - 1, g.pyrStride) + colOff;
         const unsigned stepOff = (unsigned)(RPI * g.pyrStride);
         unsigned w[STEPS];
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             const int r = s * RPI + rsub;
-            if (dcol < DW && r < ROWS) *(unsigned*)(tile + r * TS + 4 * dcol) = w[s];
+            const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[s], 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, true);
+            if (dcol < DW && r < ROWS) *(unsigned*)(tile + r * TS + 4 * dcol) = __builtin_amdgcn_alignbyte(next, w[s], (unsigned)gsh);
         }
     }
     // zero the score tile (its 1-px apron stands for "outside the ROI interior")
