@@ -208,7 +208,8 @@ def main():
         achieved = b_alg * B / (dom_avg_ms * 1e-3) / 1e9               # GB/s: algorithmic bytes of one launch / its duration
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
+        default_variant = variant == WORKLOADS[args.workload]["variant"]   # the PMC files were collected on the default variant
+        if os.path.exists(tpath) and default_variant:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(args.workload, {}).get(str(B), {}).get(dominant)
@@ -216,7 +217,7 @@ def main():
                 traffic = None
         valu = None
         vpath = os.path.join(ROOT, "profiles", "valu.json")           # PMC SQ_INSTS_VALU per launch, if collected
-        if os.path.exists(vpath):
+        if os.path.exists(vpath) and default_variant:
             try:
                 vj = json.load(open(vpath)).get(args.workload, {}).get(str(B), {}).get(dominant)
                 if vj:

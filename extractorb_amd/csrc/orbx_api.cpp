@@ -119,6 +119,7 @@ struct orbx_handle {
     int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
                                        // chosen by the image area — separate launches per size measured slower)
     int octThreadsForced = 0;          // ORBX_OCT_THREADS
+    int numCUs = 256;
     bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
@@ -304,9 +305,15 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     }
     {
         Prof p(h, S_OCTREE);
+        // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
+        // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
+        int octT[kMaxLevels];
+        const long long slots = 2048LL * h->numCUs, wgs = (long long)B * g.nlevels;
+        const int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : 0);
+        for (int l = 0; l < g.nlevels; l++) octT[l] = residentT && !h->octThreadsForced ? residentT : h->octThreads[l];
         launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                      h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, h->octThreads, B);
+                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, B);
     }
     if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
@@ -477,7 +484,11 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
-    if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024   // diagnostic: the byte-gather form of k_resize
+    if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;
+    }   // diagnostic: the byte-gather form of k_resize
     CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
     CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));
