@@ -297,3 +297,42 @@ def test_async_host_api_with_two_handles_and_pinned_input():
         assert_same_result(ra[f], oracle_run(fa[f])[1], "handle a frame %d" % f)
         assert_same_result(rb[f], oracle_run(fb[f])[1], "handle b frame %d" % f)
     X.pinned_free(pa); X.pinned_free(pb)
+
+
+@pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
+                                          ("ORBX_RESIZE_BYTEWISE", "1")])
+def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
+    # the quad-tree kernel exists in three workgroup sizes and the resize kernel in a packed and a byte-gather form; the
+    # host picks by batch size / image area / tap geometry, and every choice must give the reference result
+    monkeypatch.setenv(switch, value)
+    for shape, nf, variant in (((480, 640), 1000, "noise"), ((333, 517), 700, "textured"), ((480, 640), 1200, "natural")):
+        img = synth.frames(variant, 21, 1, *shape)[0]
+        o, want = oracle_run(img, nf)
+        ex = X.ORBextractor(nf, max_width=shape[1], max_height=shape[0])
+        mono, k, d, lvl = ex(img)
+        check_stages(ex, o, lvl)
+        assert_same_result((mono, k, d), want, "%s=%s %s" % (switch, value, variant))
+
+
+@pytest.mark.parametrize("B", [72, 136, 300])
+def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B):
+    # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above
+    fr = synth.frames("textured", 40, B, 240, 320)
+    ex = X.ORBextractor(500, max_width=320, max_height=240, max_batch=B)
+    out = ex.extract_batch(fr)
+    one = X.ORBextractor(500, max_width=320, max_height=240)
+    for f in (0, 1, B // 2, B - 1):
+        mono, k, d, _ = one(fr[f])
+        assert_same_result(out[f][:3], (mono, k, d), "frame %d of %d" % (f, B))
+    o, want = oracle_run(fr[B - 1], 500)
+    assert_same_result(out[B - 1][:3], want, "last frame of %d vs oracle" % B)
+
+
+def test_scale_factor_two_uses_the_byte_gather_resize():
+    # scaleFactor 2.0: the taps of four adjacent pixels span more than 8 source bytes, so the packed resize does not apply
+    img = synth.frames("textured", 5, 1, 480, 640)[0]
+    o, want = oracle_run(img, 600, (0, 1000), 3, 2.0, 20, 7)
+    ex = X.ORBextractor(600, 2.0, 3, 20, 7, max_width=640, max_height=480)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl, 3)
+    assert_same_result((mono, k, d), want, "scale 2.0")
