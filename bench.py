@@ -24,30 +24,30 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
-    "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=256, variant="noise",
+    "mono640": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise",
                     desc="640x480 mono stream, 8 levels, 1000 features, synthetic noise frames"),
     # configs[2]
-    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=64, variant="noise",
+    "hd1080": dict(rows=1080, cols=1920, nfeatures=2000, lapping=(0, 1000), batch=128, variant="noise",
                    desc="1920x1080 mono stream, 8 levels, 2000 features, synthetic noise frames"),
     "hd720": dict(rows=720, cols=1280, nfeatures=1500, lapping=(0, 1000), batch=128, variant="noise",
                   desc="1280x720 mono stream, 8 levels, 1500 features (between configs[1] and configs[2])"),
     # configs[3]: L+R pairs, 1200 features per eye, rectified-stereo lapping {0,0}; a frame here is one eye
-    "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="noise",
-                      desc="stereo 640x480 L+R pairs (128 pairs per step), 8 levels, 1200 features per eye"),
+    "stereo640": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=512, variant="noise",
+                      desc="stereo 640x480 L+R pairs (256 pairs per step), 8 levels, 1200 features per eye"),
     # configs[3] + the reference's next step on a stereo frame, Frame::ComputeStereoMatches, fed from HBM
-    "stereo640_match": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=256, variant="stereo", match=True,
-                            desc="stereo 640x480 L+R pairs (128 pairs per step, right eye = left shifted by 6..40 px), 8 levels, "
+    "stereo640_match": dict(rows=480, cols=640, nfeatures=1200, lapping=(0, 0), batch=512, variant="stereo", match=True,
+                            desc="stereo 640x480 L+R pairs (256 pairs per step, right eye = left shifted by 6..40 px), 8 levels, "
                                  "1200 features per eye, extraction + ComputeStereoMatches"),
     # configs[1] + the rest of the Frame constructor + monocular initialisation matching of consecutive
     # frames (§8f-2), all fed from HBM
-    "mono640_init": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=256, variant="pan", init_match=True,
+    "mono640_init": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", init_match=True,
                          desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
                               "AssignFeaturesToGrid + SearchForInitialization(frame i, frame i+1)"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# integer / packed VALU issue: one wave64 instruction per 4.15 cycles per SIMD at 2.4 GHz (tools/ubench/valu_rate.hip,
-# profiles/r01_valu_issue_rate.md) x 1024 SIMDs
-VALU_PEAK_GINSTR = 1024 * 2.4 / 4.15
+# integer / packed VALU issue: one wave64 instruction per 4 cycles per SIMD (16 lanes per clock) x 1024 SIMDs x 2.4 GHz;
+# tools/ubench/valu_rate.hip measures 4.11-4.2 cycles at the nominal clock (profiles/r01_valu_issue_rate.md)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
 
 
 def main():
@@ -237,7 +237,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O      # the checker, timed as the CPU baseline; never the product path
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            sample = 8 * threads if rows * cols <= 640 * 480 else 2 * threads
+            sample = 24 * threads if rows * cols <= 640 * 480 else 4 * threads     # about 25 CPU-seconds of work
             cf = synth.frames(variant, 0, min(sample, 64), rows, cols)
             cf = np.concatenate([cf] * ((sample + len(cf) - 1) // len(cf)))[:sample]
             sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=threads)

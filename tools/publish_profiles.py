@@ -22,15 +22,15 @@ stats = {}
 for r in csv.DictReader(open(stem + "_kernel_stats.csv")):
     n = r["Name"].split("(")[0].replace("orbx::", "").replace("void ", "").split("<")[0]
     stats[n] = float(r["AverageNs"]) / 1e6
-peak = 1024 * 2.4 / 4.15
+peak = 1024 * 2.4 / 4.0
 out = ["# SQ counters per launch - round 1, %s (%s, %s frames per launch)\n\n" % (desc, workload, batch),
        "Two `rocprofv3 --pmc` passes of `%s` (no trace options), averaged per kernel by `tools/pmc_summary.py`:\n" % cmd,
        "pass A `SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES`, pass B `SQ_LDS_BANK_CONFLICT "
        "SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY`.\n\n",
        open(os.path.join(src, "sq_summary.md")).read(),
        "\n## Vector-instruction issue roofline\n\n",
-       "Peak = 1024 SIMDs x 2.4 GHz / 4.15 cycles per wave64 instruction = %.0f G wave-instr/s (measured issue rate of the integer / packed\n"
-       "instructions these kernels use: `profiles/r01_valu_issue_rate.md`).  Duration = average of the same kernel in the kernel stats of this state.\n\n" % peak,
+       "Peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (16 lanes per clock per SIMD) = %.0f G wave-instr/s; the microbenchmark\n"
+       "`profiles/r01_valu_issue_rate.md` reaches 4.11-4.2 cycles (592 G/s) for the integer / packed instructions these kernels use.  Duration = average of the same kernel in the kernel stats of this state.\n\n" % peak,
        "| kernel | SQ_INSTS_VALU per launch | per wave | avg duration ms | G wave-instr/s | fraction of VALU issue peak |\n|---|---|---|---|---|---|\n"]
 for k in sorted(v):
     if k in stats:
