@@ -694,13 +694,27 @@ int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoin
     if (n > L.candCap) return fail(h, ORBX_ERR_CAPACITY, "candidate arena overflow (internal bound violated)");
     if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity too small");
     if (n == 0) return ORBX_OK;
-    Keypoint* tmp = nullptr;
-    HIP_TRY(h, hipMalloc(&tmp, sizeof(Keypoint) * n));
-    launchUnpackCandidates(h->stream, h->d_candPos + L.candOff + (long long)frame * L.candCap, n, tmp);
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, tmp, sizeof(Keypoint) * n, hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    HIP_TRY(h, e);
+    // The quad-tree compacts the keys into candPos only when it has to sweep them more than once; the per-cell segments
+    // k_fast wrote always hold them, in the reference's order (cell by cell, raster order inside a cell).
+    const FrameGeom& g = h->geom;
+    const int nCells = (int)g.cells.size();
+    std::vector<unsigned> counts(L.cellCount), seg(L.candCap);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(counts.data(), h->d_cellCount + (long long)frame * nCells + L.cellFirst, sizeof(unsigned) * L.cellCount,
+                         hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(seg.data(), h->d_candSeg + L.candOff + (long long)frame * L.candCap, sizeof(unsigned) * L.candCap,
+                         hipMemcpyDeviceToHost));
+    int at = 0;
+    for (int c = 0; c < L.cellCount; c++) {
+        const int so = g.cells[L.cellFirst + c].segOff;
+        for (unsigned i = 0; i < counts[c] && at < n; i++) {
+            const unsigned w = seg[so + i];
+            orbx_keypoint& k = out[at++];
+            k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff); k.size = 7.f; k.angle = -1.f;
+            k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
+        }
+    }
+    if (at != n) return fail(h, ORBX_ERR_HIP, "candidate count and per-cell counts disagree (internal)");
     return ORBX_OK;
 }
 

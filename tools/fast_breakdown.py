@@ -14,7 +14,7 @@ M._LIB = os.path.abspath(sys.argv[1])
 import numpy as np, torch
 import extractorb_amd as X
 from extractorb_amd import synth
-B = 256
+B = int(os.environ.get("B", "256"))
 variant = os.environ.get("VARIANT", "noise")
 fr = synth.frames(variant, 0, B, 480, 640)
 ex = X.ORBextractor(1000, max_batch=B)
