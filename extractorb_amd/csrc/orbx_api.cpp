@@ -219,7 +219,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     h->nBlurLanes = lanes;
     {
         const long long px = (long long)g.lv[0].w * g.lv[0].h;
-        int T = px <= 500000 ? 256 : 1024;     // measured: 640x480 -> 256 (0.16 vs 0.25 ms per 256 frames), 1280x720 and 1920x1080 -> 1024
+        int T = px <= 500000 ? 256 : (px <= 1200000 ? 512 : 1024);   // measured: 640x480 -> 256, 1280x720 -> 512, 1920x1080 -> 1024 (512 equal)
         if (h->octThreadsForced == 256 || h->octThreadsForced == 512 || h->octThreadsForced == 1024) T = h->octThreadsForced;
         for (int l = 0; l < g.nlevels; l++) h->octThreads[l] = T;
     }
