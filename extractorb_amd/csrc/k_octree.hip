@@ -142,7 +142,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
     b += (size_t)R * kHistPerRoot * sizeof(int);    // hist
     b += (size_t)R * kLeaves * sizeof(unsigned short);   // cell
     b += 2 * (size_t)XT;                            // xcode, ycode
-    b += (size_t)R * kLeaves * sizeof(unsigned long long) + 8;   // leafBest
+    b += (size_t)R * kLeaves * sizeof(unsigned) + 8;   // leafBest
     return b + 64;
 }
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
