@@ -18,6 +18,7 @@
 //     reference compares heap addresses there, SURVEY.md §8c].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -137,12 +138,10 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
     b += (size_t)M * sizeof(unsigned short);        // mapKeep
     b += (size_t)M * sizeof(int);                   // fwd
     b += (size_t)M * sizeof(int);                   // keepIdx
-    b += (size_t)P * sizeof(unsigned long long);    // sortKey
+    b += std::max((size_t)P * sizeof(unsigned long long), (2 * (size_t)XT + 7) & ~(size_t)7);   // sortKey | xcode, ycode
     b += 2 * (size_t)M * sizeof(unsigned);          // ncode
     b += (size_t)R * kHistPerRoot * sizeof(int);    // hist
-    b += (size_t)R * kLeaves * sizeof(unsigned short);   // cell
-    b += 2 * (size_t)XT;                            // xcode, ycode
-    b += (size_t)R * kLeaves * sizeof(unsigned) + 8;   // leafBest
+    b += (size_t)R * kLeaves * sizeof(unsigned);    // leafBest | cell
     return b + 64;
 }
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
