@@ -312,6 +312,17 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
         mono, k, d, lvl = ex(img)
         check_stages(ex, o, lvl)
         assert_same_result((mono, k, d), want, "%s=%s %s" % (switch, value, variant))
+    # tight clusters: a node deeper than the dense phase's leaf grid has to split, so the keys are gathered late
+    rng = np.random.default_rng(4)
+    img = np.full((480, 640), 90, np.uint8)
+    for cy, cx in [(100, 120), (300, 500), (240, 320), (400, 90)]:
+        ys = np.clip(cy + rng.integers(-24, 24, 900), 20, 459); xs = np.clip(cx + rng.integers(-24, 24, 900), 20, 619)
+        img[ys, xs] = rng.integers(150, 255, 900)
+    o, want = oracle_run(img, 3000)
+    ex = X.ORBextractor(3000)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, "%s=%s clustered" % (switch, value))
 
 
 @pytest.mark.parametrize("B", [72, 136, 300])
