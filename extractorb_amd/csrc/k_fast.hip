@@ -5,15 +5,22 @@
 // Score.  With ring pixels r_k and centre v:  S_dark = v - min_arcs(max_arc r),  S_bright = max_arcs(min_arc r) - v,
 // S = max(S_dark, S_bright, 0) over the 16 arcs of 9 contiguous ring pixels.  "corner at threshold t" <=> S > t
 // and the reference's response is S - 1, so ONE score serves iniThFAST and the minThFAST retry.
-// The arc minima/maxima use the 3-input VALU ops: m3[k] = min3(r_k, r_k+1, r_k+2), m9[k] = min3(m3[k], m3[k+3],
-// m3[k+6]) — 2 x 32 instructions for all 16 arcs of both polarities, plus 2 x 8 for the reductions.
+// Arcs k and k+1 (k even) share 8 ring pixels, and max(min(core, r_k), min(core, r_k+9)) = min(core, max(r_k, r_k+9)):
+// 8 "arc pairs" instead of 16 arcs, 36 three-input min/max instructions per polarity.
+//
+// Packed form (the variant used on dense content): one lane = the four pixels of one tile dword, as two pixel PAIRS held
+// as 2 x u16 per register.  The bit patterns 0..255 are non-negative binary16 denormals, whose order is the integer
+// order, so gfx950's packed v_pk_minimum3_f16 / v_pk_maximum3_f16 are exact integer min3 / max3 on both pixels; ring
+// pairs are cut out of the tile's dwords with v_perm_b32.  The byte-per-lane form (fastScore) serves the prefilter
+// variant, which scores only the few pixels that pass a cheap exact test.
 //
 // NMS is a strict 3x3 maximum of S with everything outside the cell interior counted as 0; a surviving centre has
-// S > t, so neighbours below t can never suppress it: NMS is threshold independent and runs once.
+// S > t, so neighbours below t can never suppress it: NMS is threshold independent and runs once (also four pixels
+// per lane, minThFAST folded into the neighbour maximum).
 //
-// LDS: each wave stages its ROI (<= 45 x 45 for the usual 31..37-px cells) as aligned dwords with every global load
-// in flight at once, then keeps the 8-bit score tile next to it.  Strides are compile-time so all 16 ring
-// offsets and the 8 NMS neighbours are instruction immediates.
+// LDS: each wave stages its ROI (<= 45 x 45 for the usual 31..37-px cells) re-aligned so that the cell interior starts
+// on a tile dword (a 31/32-px cell is then 8 dwords wide = 4 wave iterations per pass), then keeps the 8-bit score
+// tile next to it on the same dword grid.  Strides are compile-time so ring offsets are instruction immediates.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

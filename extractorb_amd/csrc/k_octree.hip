@@ -1,6 +1,9 @@
 // k_octree.hip — DistributeOctTree quad-tree culling (reference ORBextractor.cc:544-771).
 //
-// One 1024-thread workgroup per (frame, level); the node list lives in LDS, the keys stay in HBM/L2.
+// One workgroup per (frame, level) — 256, 512 or 1024 threads, chosen by the host (k_octree_body.inc is compiled per
+// size); the node list lives in LDS.  While no node deeper than a 32x32 leaf grid per root has to split ("dense
+// phase", the normal case) the keys are read once from k_fast's per-cell segments and only per-leaf counts and
+// per-leaf best keys are kept; otherwise they are compacted to HBM and swept once per pass as described next.
 //
 // The reference's std::list is modelled as an array in list order.  A key never needs its position
 // inside a node: the final pick per node is max response, first in candidate order on ties

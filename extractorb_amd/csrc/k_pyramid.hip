@@ -4,8 +4,9 @@
 // One workgroup = one 256 x 32 tile of a bordered destination level; a thread owns one aligned dword column
 // (4 pixels) over 8 rows, so stores are coalesced 256-B wave stores.  The tile's source footprint — a rectangle
 // the host derives from the coefficient tables (they are monotonic and REFLECT_101 only folds indices back inside)
-// — is staged in LDS with coalesced dword loads; the 4 taps of a pixel are then LDS byte reads (global byte
-// gathers run at a quarter of the dword rate, and unaligned 16-bit LDS reads at half rate).
+// — is staged in LDS with coalesced dword loads (12 in flight per thread); a thread then reads the three dwords
+// that hold the taps of its four pixels and cuts the tap pairs out with v_alignbyte / v_perm (packed form, when the
+// host found the taps of every dword column within 8 source bytes), or reads single bytes (any scale factor).
 // copyMakeBorder(REFLECT_101) is fused: a border byte recomputes the interior pixel it mirrors.
 // Level l depends on the rounded u8 pixels of level l-1 (the reference's 7-deep chain), hence one launch per
 // level; the first launch builds level 0 (copy) AND level 1 (resized straight from the caller's image).
