@@ -396,6 +396,28 @@ void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGe
     }
 }
 
+// Create-time check of the assumption the packed passes rest on: v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_sub_u16
+// behave as integer min3 / max3 / subtract on u16 halves holding 0..255 (FP16 denormals preserved).  One wave; lane l
+// tests the triple (l*4+1, 255-l*3, (l*37) & 255) in the low half and a rotated triple in the high half.
+__global__ void k_packedSelfTest(unsigned* __restrict__ bad) {
+    const unsigned l = threadIdx.x;
+    const unsigned a0 = (l * 4 + 1) & 255, b0 = (255 - l * 3) & 255, c0 = (l * 37) & 255;
+    const unsigned a = a0 | (b0 << 16), b = b0 | (c0 << 16), c = c0 | (a0 << 16);
+    const unsigned mn = pkmin3(a, b, c), mx = pkmax3(a, b, c), df = pksub(mx, mn), m2 = pkmax(a, b);
+    const unsigned emn = min(a0, min(b0, c0)), emx = max(a0, max(b0, c0));
+    const bool ok = mn == (emn | (emn << 16)) && mx == (emx | (emx << 16)) && df == ((emx - emn) | ((emx - emn) << 16)) &&
+                    m2 == (max(a0, b0) | (max(b0, c0) << 16)) && pkmin3(0u, 0x00010001u, 0x00ff00ffu) == 0u;
+    if (!ok) atomicAdd(bad, 1u);
+}
+hipError_t runPackedSelfTest(hipStream_t st, unsigned* d_scratch, unsigned* h_bad) {
+    hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_packedSelfTest, dim3(1), dim3(64), 0, st, d_scratch);
+    e = hipMemcpyAsync(h_bad, d_scratch, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+
 // unpack one level's candidates into reference KeyPoints (introspection for tests)
 __global__ void k_unpackCandidates(const unsigned* __restrict__ keys, int n, Keypoint* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

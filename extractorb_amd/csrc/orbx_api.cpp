@@ -29,6 +29,7 @@ void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, cons
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
 hipError_t uploadUmax(const int* umax16);
+hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
 struct StereoParams {
     float scale[kMaxLevels], invScale[kMaxLevels];
     float bf, b;
@@ -500,6 +501,14 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMemset(h->d_pyr, 0, h->pyrBytes));
     CREATE_TRY(hipMemset(h->d_blur, 0, h->blurBytes));
     CREATE_TRY(uploadUmax(h->tabs.umax));
+    {   // k_fast's packed passes assume the 3-input packed f16 min/max act as integer min/max on u16 halves 0..255
+        unsigned bad = 1;
+        CREATE_TRY(runPackedSelfTest(h->stream, (unsigned*)h->d_candCount, &bad));
+        if (bad) {
+            h->err = "packed min/max self-test failed on this device (FP16 denormals not preserved?): the FAST kernel would not be exact";
+            return bail(ORBX_ERR_UNSUPPORTED);
+        }
+    }
 #undef CREATE_TRY
     h->geom = FrameGeom();   // installed on first use
     *out = h;
