@@ -169,6 +169,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # one untimed priming step outside the warmup count: the first call installs the geometry tables, and the first gather
+    # builds RCCL's point-to-point channels (seconds at N = 8); --warmup 0 must not put either into the timed region
+    step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
