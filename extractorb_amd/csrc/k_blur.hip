@@ -5,7 +5,7 @@
 // BORDER_REFLECT_101 frame of the level (19 px >= the 3 px the blur reaches over the edge), so the
 // kernel never special-cases an image edge.
 //
-// HBM-bound design: a lane owns 4 adjacent output columns and walks down a block of 32 rows, keeping the
+// HBM-bound design: a lane owns 4 adjacent output columns and walks down a block of kBlurBlockRows rows, keeping the
 // last seven rows of horizontal sums in registers.  Per row it reads three aligned dwords (12 pixels, two of
 // the three served by L1), forms the four horizontal sums with v_alignbyte + v_dot4_u32_u8 (2 dot products
 // per sum), the four vertical sums with 24-bit mads, and stores one dword: no LDS, every HBM byte of the
@@ -17,7 +17,7 @@
 
 namespace orbx {
 
-constexpr int kBlurRows = 32;   // output rows per lane
+constexpr int kBlurRows = kBlurBlockRows;   // output rows per lane
 
 __device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
     // lo = pixels x-3..x, hi = pixels x+1..x+4 (the last one weighted 0)

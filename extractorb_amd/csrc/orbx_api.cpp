@@ -207,7 +207,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     std::vector<unsigned short> laneItem;
     int lanes = 0;
     for (int l = 0; l < g.nlevels; l++)
-        for (int y0 = 0; y0 < g.lv[l].h; y0 += 32) {
+        for (int y0 = 0; y0 < g.lv[l].h; y0 += kBlurBlockRows) {
             laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)tiles.size());
             tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
             lanes += (g.lv[l].w + 3) / 4;

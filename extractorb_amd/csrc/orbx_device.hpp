@@ -19,7 +19,7 @@ struct Keypoint {             // == orbx_keypoint == cv::KeyPoint (28 bytes)
 };
 static_assert(sizeof(Keypoint) == 28, "cv::KeyPoint layout");
 
-// One 32-row block of one level for the blur kernel: lanes [firstLane, firstLane + ceil(w/4)) own its 4-column groups.
+// One kBlurBlockRows-row block of one level for the blur kernel: lanes [firstLane, firstLane + ceil(w/4)) own its 4-column groups.
 // items[0].count holds the number of items.
 struct BlurItem { int firstLane; int count; short level; short y0; };
 
@@ -57,6 +57,7 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
 };
 static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
 
+constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (plus a 6-row halo)
 constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
 
 // Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
