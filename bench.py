@@ -43,6 +43,9 @@ WORKLOADS = {
     "mono640_init": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", init_match=True,
                          desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
                               "AssignFeaturesToGrid + SearchForInitialization(frame i, frame i+1)"),
+    # the caller's side: BGR frames as Tracking::GrabImageMonocular receives them, cvtColor(BGR2GRAY) on the device, then configs[1]
+    "mono640_bgr": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", color=3,
+                        desc="640x480 BGR stream: cvtColor(BGR2GRAY) + extraction, 8 levels, 1000 features"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # integer / packed VALU issue: one wave64 instruction per 4 cycles per SIMD (16 lanes per clock) x 1024 SIMDs x 2.4 GHz;
@@ -102,6 +105,9 @@ def main():
     else:
         frames = synth.frames(variant, rank * B, B, rows, cols)
     d_img = torch.from_numpy(frames).cuda()
+    color = int(wl.get("color", 0))
+    if color:      # channel c of frame f = gray frame (f + c) of the stream: three different planes, interleaved
+        d_color = torch.stack([torch.roll(d_img, -c, 0) for c in range(color)], dim=-1).contiguous()
     nH = max(1, args.handles)
     exs = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank) for _ in range(nH)]
     ex = exs[0]
@@ -148,6 +154,8 @@ def main():
         e_ = exs[counter[0] % nH]
         counter[0] += 1
         b = slabs[k].data_ptr()
+        if color:
+            e_.gray_from_color_device(B, d_color, rows, cols, color, False, d_img)     # Tracking.cc:991-993 (mbRGB = 0: BGR)
         e_.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
         if match:
             e_.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)

@@ -47,6 +47,8 @@ struct InitMatchParams {
 size_t initMatchLdsBytes(int capacity);
 void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
                       float*, int*, int*, int);
+struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
+void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
 }  // namespace orbx
 
@@ -851,6 +853,23 @@ int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float*
     } else {
         b[0] = 0.0f; b[1] = (float)cols; b[2] = 0.0f; b[3] = (float)rows;
     }
+    return ORBX_OK;
+}
+
+int orbx_gray_from_color_device(orbx_handle* h, int n_frames, const uint8_t* d_src, int rows, int cols, int channels, int red_first,
+                                ptrdiff_t src_stride, ptrdiff_t src_frame_stride, uint8_t* d_gray, ptrdiff_t gray_stride,
+                                ptrdiff_t gray_frame_stride) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_src || !d_gray || n_frames < 1 || rows < 1 || cols < 1 || (channels != 3 && channels != 4) ||
+        src_stride < (ptrdiff_t)cols * channels || gray_stride < cols || rows > 65535 || n_frames > 65535)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, channels not 3 or 4, stride shorter than a row, or more than 65535 rows / frames");
+    HIP_TRY(h, hipSetDevice(h->device));
+    GrayParams p;
+    p.rows = rows; p.cols = cols; p.channels = channels; p.redFirst = red_first != 0;
+    p.srcStride = src_stride; p.srcFrame = src_frame_stride; p.dstStride = gray_stride; p.dstFrame = gray_frame_stride;
+    p.aligned = (((uintptr_t)d_src | (uintptr_t)src_stride | (uintptr_t)src_frame_stride) & 3) == 0;
+    launchGray(h->stream, d_src, d_gray, p, n_frames);
+    HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
 }
 

@@ -97,6 +97,8 @@ def load_library():
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_search_for_initialization_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp,
                                                         vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+    L.orbx_gray_from_color_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp,
+                                              C.c_ssize_t, C.c_ssize_t]
     L.orbx_set_stream.argtypes = [vp, vp]
     L.orbx_get_stream.restype = vp
     L.orbx_get_stream.argtypes = [vp]
@@ -343,6 +345,18 @@ class ORBextractor:
             self._h, n_pairs, frames1[0], frames1[1], frames2[0], frames2[1], dp(d_kps_un), dp(d_desc), dp(d_n), capacity,
             dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_prev_matched), window, nnratio, int(check_orientation),
             dp(d_matches12), dp(d_n_matches)))
+
+    def gray_from_color_device(self, n_frames, d_src, rows, cols, channels, red_first, d_gray, src_stride=None, src_frame_stride=None,
+                               gray_stride=None, gray_frame_stride=None):
+        """cv::cvtColor(RGB/BGR/RGBA/BGRA -> GRAY) as Tracking::GrabImage* applies it (reference src/Tracking.cc:915-941)."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        src_stride = cols * channels if src_stride is None else src_stride
+        src_frame_stride = rows * src_stride if src_frame_stride is None else src_frame_stride
+        gray_stride = cols if gray_stride is None else gray_stride
+        gray_frame_stride = rows * gray_stride if gray_frame_stride is None else gray_frame_stride
+        self._check(self._L.orbx_gray_from_color_device(self._h, n_frames, dp(d_src), rows, cols, channels, int(red_first), src_stride,
+                                                        src_frame_stride, dp(d_gray), gray_stride, gray_frame_stride))
 
     def set_stream(self, stream_ptr):
         self._check(self._L.orbx_set_stream(self._h, C.c_void_p(int(stream_ptr))))

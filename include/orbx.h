@@ -161,6 +161,15 @@ int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d
 int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
                            int* n_matched);
 
+/* ---- the caller's side of the path: colour input ----------------------------------------------------------------
+ * Replaces the cv::cvtColor(RGB2GRAY | BGR2GRAY | RGBA2GRAY | BGRA2GRAY) calls of Tracking::GrabImageMonocular / Stereo /
+ * RGBD (src/Tracking.cc:915-941, 985-1001) for n_frames device-resident 8-bit frames of `channels` (3 or 4) interleaved
+ * channels; red_first = Tracking::mbRGB.  gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14 (OpenCV's 14-bit fixed point).
+ * The result feeds orbx_extract_batch_device.  Asynchronous on the handle's stream. */
+int orbx_gray_from_color_device(orbx_handle* h, int n_frames, const uint8_t* d_src, int rows, int cols, int channels, int red_first,
+                                ptrdiff_t src_stride, ptrdiff_t src_frame_stride, uint8_t* d_gray, ptrdiff_t gray_stride,
+                                ptrdiff_t gray_frame_stride);
+
 /* ---- next row: the rest of the Frame constructor ------------------------------------------
  * Frame::mK and Frame::mDistCoef as plain floats (fx, fy, cx, cy: src/Frame.cc:342-345; k1, k2, p1, p2[, k3]). */
 typedef struct orbx_camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;

@@ -1063,6 +1063,19 @@ int oracle_features_in_area(const void* kpsUn, const int* gridOff, const int* gr
     return (int)v.size();
 }
 
+// cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8-bit images as Tracking::GrabImage* calls it
+// (src/Tracking.cc:915-941, 985-1001).  OpenCV 3.4 generic path: 14-bit fixed point with R2Y = 4899, G2Y = 9617,
+// B2Y = 1868 and CV_DESCALE's rounding; alpha ignored.
+void oracle_gray_from_color(const uint8_t* src, int rows, int cols, int channels, int redFirst, long srcStride, uint8_t* dst, long dstStride) {
+    const int yuv_shift = 14, R2Y = 4899, G2Y = 9617, B2Y = 1868;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            const uint8_t* p = src + (size_t)y * srcStride + (size_t)x * channels;
+            const int r = redFirst ? p[0] : p[2], g = p[1], b = redFirst ? p[2] : p[0];
+            dst[(size_t)y * dstStride + x] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (yuv_shift - 1))) >> yuv_shift);
+        }
+}
+
 // ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,
 // the reference's own execution model per Frame.cc:109-112); returns wall seconds. ------------
 double oracle_time_frames(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,

@@ -75,6 +75,8 @@ def lib():
         L.oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
         L.oracle_features_in_area.restype = C.c_int
         L.oracle_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_gray_from_color.restype = None
+        L.oracle_gray_from_color.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, vp, C.c_long]
         L.oracle_time_frames.restype = C.c_double
         L.oracle_time_frames.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -213,6 +215,14 @@ def search_for_initialization(kps_un1, desc1, kps_un2, desc2, grid_off2, grid_id
                                                _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), window, nnratio,
                                                int(check_orientation), _ptr(m12))
     return n, m12[:len(k1)].copy(), prev
+
+
+def gray_from_color(img, red_first):
+    """cv::cvtColor(... 2GRAY) of an 8-bit H x W x {3,4} image (reference src/Tracking.cc:915-941)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(img.shape[:2], np.uint8)
+    lib().oracle_gray_from_color(_ptr(img), img.shape[0], img.shape[1], img.shape[2], int(red_first), img.strides[0], _ptr(out), out.strides[0])
+    return out
 
 
 def descriptor_distance(a, b):
