@@ -106,6 +106,37 @@ __global__ __launch_bounds__(1024) void k_frame_finish(const Keypoint* __restric
     }
 }
 
+// Frame::ComputeStereoFromRGBD (reference src/Frame.cc:994-1015) with the depth conversion Tracking::GrabImageRGBD applies
+// first (imDepth.convertTo(CV_32F, mDepthMapFactor), src/Tracking.cc:1003-1004): d = depth(int(v), int(u)) [* factor];
+// d > 0: mvDepth = d, mvuRight = kpUn.x - mbf / d; else both -1.  One thread per keypoint slot.
+struct RgbdParams {
+    int capacity, rows, cols, isU16, scale;     // scale: convertTo runs (a 16-bit map always, a float map when factor != 1)
+    long long stride, frame;                    // bytes
+    float factor, mbf;
+};
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(const Keypoint* __restrict__ kps, const Keypoint* __restrict__ kpsUn,
+                                                           const int* __restrict__ nOut, const uint8_t* __restrict__ depth,
+                                                           RgbdParams p, float* __restrict__ uRight, float* __restrict__ depthOut) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= p.capacity) return;
+    float ur = -1.f, dz = -1.f;
+    if (i < min(nOut[f], p.capacity)) {
+        const Keypoint k = kps[(long long)f * p.capacity + i];
+        const int v = min(max((int)k.y, 0), p.rows - 1), u = min(max((int)k.x, 0), p.cols - 1);   // Mat::at<float>(float, float) truncates
+        const uint8_t* row = depth + (long long)f * p.frame + (long long)v * p.stride;
+        float d = p.isU16 ? (float)((const unsigned short*)row)[u] : ((const float*)row)[u];
+        if (p.scale) d = __fmul_rn(d, p.factor);
+        if (d > 0.f) { dz = d; ur = __fsub_rn(kpsUn[(long long)f * p.capacity + i].x, __fdiv_rn(p.mbf, d)); }
+    }
+    uRight[(long long)f * p.capacity + i] = ur;
+    depthOut[(long long)f * p.capacity + i] = dz;
+}
+void launchStereoFromRgbd(hipStream_t st, const Keypoint* kps, const Keypoint* kpsUn, const int* nOut, const uint8_t* depth,
+                          const RgbdParams& p, float* uRight, float* depthOut, int nFrames) {
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((p.capacity + 255) / 256, nFrames), dim3(256), 0, st, kps, kpsUn, nOut, depth, p,
+                       uRight, depthOut);
+}
+
 void launchFrameFinish(hipStream_t st, const Keypoint* kps, const int* nOut, const FrameFinishParams& p, Keypoint* kpsUn,
                        int* gridOff, int* gridIdx, int* nInside, int nFrames) {
     const size_t lds = (size_t)(kGridCells + 1) * sizeof(int) + (size_t)((p.capacity + 1) & ~1) * sizeof(short);

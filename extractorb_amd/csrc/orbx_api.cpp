@@ -47,6 +47,8 @@ struct InitMatchParams {
 size_t initMatchLdsBytes(int capacity);
 void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
                       float*, int*, int*, int);
+struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, frame; float factor, mbf; };
+void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
@@ -853,6 +855,27 @@ int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float*
     } else {
         b[0] = 0.0f; b[1] = (float)cols; b[2] = 0.0f; b[3] = (float)rows;
     }
+    return ORBX_OK;
+}
+
+int orbx_stereo_from_rgbd_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un,
+                                 const int* d_n_out, int capacity, const void* d_depth, int depth_is_u16, int rows, int cols,
+                                 ptrdiff_t depth_stride_bytes, ptrdiff_t depth_frame_stride_bytes, float depth_map_factor, float mbf,
+                                 float* d_u_right, float* d_depth_out) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    const ptrdiff_t elem = depth_is_u16 ? 2 : 4;
+    if (!d_kps || !d_kps_un || !d_n_out || !d_depth || !d_u_right || !d_depth_out || capacity < 1 || n_frames < 1 || rows < 1 || cols < 1 ||
+        depth_stride_bytes < (ptrdiff_t)cols * elem || (depth_stride_bytes % elem) != 0 || (depth_frame_stride_bytes % elem) != 0 ||
+        ((uintptr_t)d_depth % elem) != 0 || n_frames > 65535)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames/rows/cols < 1, or a depth stride / pointer that is not a multiple of the element size");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RgbdParams p;
+    p.capacity = capacity; p.rows = rows; p.cols = cols; p.isU16 = depth_is_u16 != 0;
+    p.scale = p.isU16 || std::fabs(depth_map_factor - 1.0f) > 1e-5f;      // Tracking.cc:1003
+    p.stride = depth_stride_bytes; p.frame = depth_frame_stride_bytes; p.factor = depth_map_factor; p.mbf = mbf;
+    launchStereoFromRgbd(h->stream, (const Keypoint*)d_kps, (const Keypoint*)d_kps_un, d_n_out, (const uint8_t*)d_depth, p, d_u_right,
+                         d_depth_out, n_frames);
+    HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
 }
 

@@ -97,6 +97,8 @@ def load_library():
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_search_for_initialization_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp,
                                                         vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+    L.orbx_stereo_from_rgbd_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
+                                               C.c_float, C.c_float, vp, vp]
     L.orbx_gray_from_color_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp,
                                               C.c_ssize_t, C.c_ssize_t]
     L.orbx_set_stream.argtypes = [vp, vp]
@@ -345,6 +347,18 @@ class ORBextractor:
             self._h, n_pairs, frames1[0], frames1[1], frames2[0], frames2[1], dp(d_kps_un), dp(d_desc), dp(d_n), capacity,
             dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_prev_matched), window, nnratio, int(check_orientation),
             dp(d_matches12), dp(d_n_matches)))
+
+    def stereo_from_rgbd_device(self, n_frames, d_kps, d_kps_un, d_n, capacity, d_depth, depth_is_u16, rows, cols, depth_map_factor, mbf,
+                                d_u_right, d_depth_out, depth_stride_bytes=None, depth_frame_stride_bytes=None):
+        """Frame::ComputeStereoFromRGBD with GrabImageRGBD's depth conversion (reference src/Frame.cc:994-1015, src/Tracking.cc:1003-1004)."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        elem = 2 if depth_is_u16 else 4
+        depth_stride_bytes = cols * elem if depth_stride_bytes is None else depth_stride_bytes
+        depth_frame_stride_bytes = rows * depth_stride_bytes if depth_frame_stride_bytes is None else depth_frame_stride_bytes
+        self._check(self._L.orbx_stereo_from_rgbd_device(self._h, n_frames, dp(d_kps), dp(d_kps_un), dp(d_n), capacity, dp(d_depth),
+                                                         int(depth_is_u16), rows, cols, depth_stride_bytes, depth_frame_stride_bytes,
+                                                         depth_map_factor, mbf, dp(d_u_right), dp(d_depth_out)))
 
     def gray_from_color_device(self, n_frames, d_src, rows, cols, channels, red_first, d_gray, src_stride=None, src_frame_stride=None,
                                gray_stride=None, gray_frame_stride=None):

@@ -170,6 +170,17 @@ int orbx_gray_from_color_device(orbx_handle* h, int n_frames, const uint8_t* d_s
                                 ptrdiff_t src_stride, ptrdiff_t src_frame_stride, uint8_t* d_gray, ptrdiff_t gray_stride,
                                 ptrdiff_t gray_frame_stride);
 
+/* ---- RGB-D frames: Frame::ComputeStereoFromRGBD (src/Frame.cc:994-1015) with the depth conversion of
+ * Tracking::GrabImageRGBD (imDepth.convertTo(CV_32F, mDepthMapFactor), src/Tracking.cc:1003-1004) fused in.
+ * d_depth: n_frames depth maps, float32 or uint16 (depth_is_u16); a uint16 map is always scaled by depth_map_factor
+ * (= 1 / DepthMapFactor of the settings file, Tracking.cc:680-684), a float map only when |factor - 1| > 1e-5.
+ * For keypoint i of frame f (d_kps: mvKeys, d_kps_un: mvKeysUn): d = depth(int(y), int(x)); d > 0 gives
+ * d_depth_out = d and d_u_right = kpUn.x - mbf / d, else both are -1.  Slots past n_out[f] are filled with -1. */
+int orbx_stereo_from_rgbd_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un,
+                                 const int* d_n_out, int capacity, const void* d_depth, int depth_is_u16, int rows, int cols,
+                                 ptrdiff_t depth_stride_bytes, ptrdiff_t depth_frame_stride_bytes, float depth_map_factor, float mbf,
+                                 float* d_u_right, float* d_depth_out);
+
 /* ---- next row: the rest of the Frame constructor ------------------------------------------
  * Frame::mK and Frame::mDistCoef as plain floats (fx, fy, cx, cy: src/Frame.cc:342-345; k1, k2, p1, p2[, k3]). */
 typedef struct orbx_camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;

@@ -1076,6 +1076,24 @@ void oracle_gray_from_color(const uint8_t* src, int rows, int cols, int channels
         }
 }
 
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:994-1015) preceded by Tracking::GrabImageRGBD's depth conversion
+// (src/Tracking.cc:1003-1004: convertTo(CV_32F, mDepthMapFactor) unless the map is float and the factor is 1).
+void oracle_stereo_from_rgbd(const void* kps_, const void* kpsUn_, int N, const void* depth, int isU16, int rows, int cols, long strideBytes,
+                             float mDepthMapFactor, float mbf, float* mvuRight, float* mvDepth) {
+    const KeyPoint* mvKeys = (const KeyPoint*)kps_;
+    const KeyPoint* mvKeysUn = (const KeyPoint*)kpsUn_;
+    const bool convert = (std::fabs(mDepthMapFactor - 1.0f) > 1e-5) || isU16;
+    (void)rows; (void)cols;
+    for (int i = 0; i < N; i++) {
+        mvuRight[i] = -1; mvDepth[i] = -1;
+        const float v = mvKeys[i].y, u = mvKeys[i].x;
+        const uint8_t* row = (const uint8_t*)depth + (size_t)(int)v * strideBytes;       // Mat::at<float>(int, int) from float arguments
+        float d = isU16 ? (float)((const unsigned short*)row)[(int)u] : ((const float*)row)[(int)u];
+        if (convert) d = d * mDepthMapFactor;                                            // cvtScale: one float multiply
+        if (d > 0) { mvDepth[i] = d; mvuRight[i] = mvKeysUn[i].x - mbf / d; }
+    }
+}
+
 // ---- CPU baseline: nframes extractions over nthreads host threads (one extractor per thread,
 // the reference's own execution model per Frame.cc:109-112); returns wall seconds. ------------
 double oracle_time_frames(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh,

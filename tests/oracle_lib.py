@@ -75,6 +75,8 @@ def lib():
         L.oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
         L.oracle_features_in_area.restype = C.c_int
         L.oracle_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_stereo_from_rgbd.restype = None
+        L.oracle_stereo_from_rgbd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_float, vp, vp]
         L.oracle_gray_from_color.restype = None
         L.oracle_gray_from_color.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, vp, C.c_long]
         L.oracle_time_frames.restype = C.c_double
@@ -215,6 +217,18 @@ def search_for_initialization(kps_un1, desc1, kps_un2, desc2, grid_off2, grid_id
                                                _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), window, nnratio,
                                                int(check_orientation), _ptr(m12))
     return n, m12[:len(k1)].copy(), prev
+
+
+def stereo_from_rgbd(kps, kps_un, depth, factor, mbf):
+    """Frame::ComputeStereoFromRGBD after GrabImageRGBD's convertTo (reference src/Frame.cc:994-1015, src/Tracking.cc:1003-1004).
+    depth: H x W float32 or uint16.  Returns (mvuRight, mvDepth)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); kps_un = np.ascontiguousarray(kps_un, KEYPOINT_DTYPE)
+    depth = np.ascontiguousarray(depth)
+    assert depth.dtype in (np.float32, np.uint16)
+    u = np.zeros(max(len(kps), 1), np.float32); d = np.zeros(max(len(kps), 1), np.float32)
+    lib().oracle_stereo_from_rgbd(_ptr(kps), _ptr(kps_un), len(kps), _ptr(depth), int(depth.dtype == np.uint16), depth.shape[0], depth.shape[1],
+                                  depth.strides[0], factor, mbf, _ptr(u), _ptr(d))
+    return u[:len(kps)].copy(), d[:len(kps)].copy()
 
 
 def gray_from_color(img, red_first):
