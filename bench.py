@@ -115,7 +115,7 @@ def main():
     streams = [stream] + [torch.cuda.Stream() for _ in range(nH - 1)]
     for e, st_ in zip(exs, streams):
         e.set_stream(st_.cuda_stream)
-    cap = ex.capacity
+    cap = min(ex.capacity, nf + 3 * 8)      # the reference's bound: every level keeps at most quota + 3 keypoints
     # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
     lay = sharding.slab_layout(B, cap)
     off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
