@@ -5,10 +5,10 @@ import csv, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workload, batch = sys.argv[1], sys.argv[2], sys.argv[3]
 desc = sys.argv[4] if len(sys.argv) > 4 else "state " + tag
-src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag + ("_" + workload if workload != "mono640" else ""))
 stem = os.path.join(ROOT, "profiles", "r01_%s_%s_b%s" % (tag, workload, batch))
 tool = os.path.join(ROOT, "tools", "summarize_profile.py")
-cmd = "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+cmd = "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline" + ("" if workload == "mono640" else " --workload " + workload)
 subprocess.check_call(["cp", os.path.join(src, "kernel_stats.csv"), stem + "_kernel_stats.csv"])
 subprocess.check_call([sys.executable, tool, "stats", os.path.join(src, "kernel_stats.csv"), stem + "_kernel_stats.md",
                        "rocprofv3 --kernel-trace --stats - round 1, %s (%s, %s frames per launch)" % (desc, workload, batch),
