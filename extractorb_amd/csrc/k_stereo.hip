@@ -78,6 +78,19 @@ __device__ __forceinline__ int waveSumI(int v) {
     return v;
 }
 
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dppAdd(unsigned v) { return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false); }
+// sum over the 64 lanes without the LDS crossbar, returned wave-uniform
+__device__ __forceinline__ unsigned waveSumDpp(unsigned v) {
+    v = dppAdd<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v = dppAdd<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v = dppAdd<0x141, 0xF>(v);    // row_half_mirror
+    v = dppAdd<0x140, 0xF>(v);    // row_mirror: every lane of a row holds the row's sum
+    v = dppAdd<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+    v = dppAdd<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // grid (ceil(capacity/4), n_pairs), 256 threads: one wave per left keypoint.
 __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ lv, const uint8_t* __restrict__ pyr,
                                                        const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
@@ -143,6 +156,19 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
     if (y0 < -kEdge || y0 + 10 >= g.h + kEdge || xl0 < -kEdge || xl0 + 10 >= g.w + kEdge) return;
     const uint8_t* pl = pyr + g.pyrOff + (long long)fL * g.pyrFrameBytes + (long long)kEdge * g.pyrStride + kPadL;
     const uint8_t* pr = pyr + g.pyrOff + (long long)fR * g.pyrFrameBytes + (long long)kEdge * g.pyrStride + kPadL;
+    // The right strip (11 rows x 21 columns: the 11x11 window at all 11 shifts) goes through LDS once; the early return
+    // above guarantees scaleduR0 - 10 >= -10 and scaleduR0 + 10 < g.w, so every shift's window lies inside the bordered level.
+    __shared__ uint8_t strips[4][11 * 21 + 25];
+    uint8_t* R = strips[threadIdx.x >> 6];
+    const int xrBase = (int)__fsub_rn(__fadd_rn(scaleduR0, -5.f), (float)w);          // xr0 of incR = -5; xr0(incR) = xrBase + incR + 5
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int p = lane + 64 * t;
+        if (p < 11 * 21) {
+            const int ry = p / 21, rx = p - ry * 21;
+            R[p] = pr[(long long)(y0 + ry) * g.pyrStride + xrBase + rx];
+        }
+    }
     // lane owns window pixels p = lane and lane + 64 (121 in all)
     int il[2], oy[2], ox[2];
     bool in[2];
@@ -156,21 +182,36 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
     }
     const int cL = pl[(long long)(y0 + w) * g.pyrStride + xl0 + w];
     il[0] -= cL; il[1] -= cL;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    // per-lane partial SADs of all 11 shifts (<= 2 * 510 each: two shifts share a register, 16 bits apiece, and the wave
+    // totals (<= 65 280) still fit), then 6 DPP wave sums instead of 11 shuffle reductions
+    unsigned packed[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+        const int cR = R[w * 21 + w + s];
+        int part = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            if (in[t]) part += abs(il[t] - ((int)R[oy[t] * 21 + ox[t] + s] - cR));
+        packed[s >> 1] |= (unsigned)part << (16 * (s & 1));
+    }
     float vDists[11];
     int bestS = 2147483647, bestincR = 0;
 #pragma unroll
-    for (int incR = -5; incR <= 5; incR++) {
-        const int xr0 = (int)__fsub_rn(__fadd_rn(scaleduR0, (float)incR), (float)w);
-        int part = 0;
-        if (xr0 >= -kEdge && xr0 + 10 < g.w + kEdge) {
-            const int cR = pr[(long long)(y0 + w) * g.pyrStride + xr0 + w];
+    for (int j = 0; j < 6; j++) {
+        const unsigned tot = waveSumDpp(packed[j]);
 #pragma unroll
-            for (int t = 0; t < 2; t++)
-                if (in[t]) part += abs(il[t] - ((int)pr[(long long)(y0 + oy[t]) * g.pyrStride + xr0 + ox[t]] - cR));
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const int s = 2 * j + hlf;
+            if (s < 11) {
+                const float dist = (float)((tot >> (16 * hlf)) & 0xffffu);
+                if (dist < (float)bestS) { bestS = (int)dist; bestincR = s - 5; }
+                vDists[s] = dist;
+            }
         }
-        const float dist = (float)waveSumI(part);
-        if (dist < (float)bestS) { bestS = (int)dist; bestincR = incR; }
-        vDists[incR + 5] = dist;
     }
     if (bestincR == -L || bestincR == L) return;
     float dist1 = 0, dist2 = 0, dist3 = 0;
