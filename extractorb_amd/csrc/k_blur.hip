@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items
             unsigned outw = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const unsigned s = 18u * (h[0][j] + h[6][j]) + 34u * (h[1][j] + h[5][j]) + 49u * (h[2][j] + h[4][j]) + 55u * h[3][j];
+                // 24-bit multiplies (row sums <= 2 * 65535): a 32-bit v_mul_lo_u32 issues at a quarter of the rate
+                const unsigned s = __umul24(18u, h[0][j] + h[6][j]) + __umul24(34u, h[1][j] + h[5][j]) + __umul24(49u, h[2][j] + h[4][j]) +
+                                   __umul24(55u, h[3][j]);
                 unsigned v = (s + 32768u) >> 16;
                 v = v > 255u ? 255u : v;
                 outw |= v << (8 * j);
