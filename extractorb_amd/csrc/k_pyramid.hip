@@ -97,7 +97,7 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
 #pragma unroll
                 for (int k = 0; k < kStageRows; k++) {
                     const int r = min(rb + 2 * k, nRows - 1);     // clamped: every lane loads, only valid rows are stored
-                    const uint8_t* q = sp + ((unsigned)((fy0 + r) * sv.stride) + colOff);
+                    const uint8_t* q = sp + ((unsigned)__mul24(fy0 + r, sv.stride) + colOff);      // 24-bit: full-rate multiply
                     if (whole) {
                         w[k] = *(const unsigned*)q;
                     } else {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void copyTile(const SrcView& sv, const LevelGeom& g0,
     unsigned out[kPyrRows];
 #pragma unroll
     for (int r = 0; r < kPyrRows; r++) {
-        const uint8_t* row = sp + reflect101(min(by0 + r, g0.pyrRows - 1) - kEdge, g0.h) * sv.stride;
+        const uint8_t* row = sp + __mul24(reflect101(min(by0 + r, g0.pyrRows - 1) - kEdge, g0.h), sv.stride);
         if (inner) out[r] = *(const unsigned*)(row + x0);
         else out[r] = (unsigned)row[sx[0]] | ((unsigned)row[sx[1]] << 8) | ((unsigned)row[sx[2]] << 16) | ((unsigned)row[sx[3]] << 24);
     }
