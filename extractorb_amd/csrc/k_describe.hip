@@ -150,20 +150,21 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     {
         constexpr int kRawDw = kRawStride / 4, kBlurDw = kBlurStride / 4;            // 9, 10 dwords per tile row
         constexpr int kRawSteps = (kRawRows + 2) / 3, kBlurSteps = (kBlurRows + 2) / 3;   // 11, 13
-        const int rr = hl / kRawDw, rc = hl - rr * kRawDw;        // lanes 0..26: row (mod 3) and dword column of the raw tile
-        const int br = hl / kBlurDw, bcw = hl - br * kBlurDw;     // lanes 0..29: the same for the blurred tile
+        static_assert(kRawDw == 9 && kBlurDw == 10, "the multiply-shift divisions below are for 9 and 10");
+        const int rr = (hl * 57) >> 9, rc = hl - rr * kRawDw;     // hl / 9 for hl < 32: lanes 0..26: row (mod 3) and dword column of the raw tile
+        const int br = (hl * 52) >> 9, bcw = hl - br * kBlurDw;   // hl / 10 for hl < 32: lanes 0..29: the same for the blurred tile
         const bool rawLane = hl < 3 * kRawDw;
         // the last dword of a blurred row can start past the row's padded end when the patch touches the right edge
         const bool blurLane = hl < 3 * kBlurDw && blurCol0 - blurMis + 4 * bcw < blurStride;
-        const int rOff = (kEdge + ky - kHalfPatch + rr) * pyrStride + (rawCol0 - rawMis) + 4 * rc;
-        const int bOff = (ky - kBriefReach + br) * blurStride + (blurCol0 - blurMis) + 4 * bcw;
+        const int rOff = __mul24(kEdge + ky - kHalfPatch + rr, pyrStride) + (rawCol0 - rawMis) + 4 * rc;   // 24-bit: full-rate multiplies
+        const int bOff = __mul24(ky - kBriefReach + br, blurStride) + (blurCol0 - blurMis) + 4 * bcw;
         unsigned wr[kRawSteps], wb[kBlurSteps];
 #pragma unroll
         for (int s = 0; s < kRawSteps; s++)
-            wr[s] = (rawLane && rr + 3 * s < kRawRows) ? *(const unsigned*)(pyrL + (rOff + 3 * s * pyrStride)) : 0u;
+            wr[s] = (rawLane && rr + 3 * s < kRawRows) ? *(const unsigned*)(pyrL + ((unsigned)rOff + (unsigned)(3 * s * pyrStride))) : 0u;   // uniform base + u32 offset
 #pragma unroll
         for (int s = 0; s < kBlurSteps; s++)
-            wb[s] = (blurLane && br + 3 * s < kBlurRows) ? *(const unsigned*)(blurL + (bOff + 3 * s * blurStride)) : 0u;
+            wb[s] = (blurLane && br + 3 * s < kBlurRows) ? *(const unsigned*)(blurL + ((unsigned)bOff + (unsigned)(3 * s * blurStride))) : 0u;
         uint8_t* rdst = rawT + rr * kRawStride + 4 * rc;
         uint8_t* bdst = blurT + br * kBlurStride + 4 * bcw;
 #pragma unroll
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         const int q0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * kBlurStride + q0], t1 = bc[r1 * kBlurStride + q1];
+        const int t0 = bc[__mul24(r0, kBlurStride) + q0], t1 = bc[__mul24(r1, kBlurStride) + q1];
         const unsigned long long m = __ballot(t0 < t1);
         const unsigned mine = half ? (unsigned)(m >> 32) : (unsigned)m;
         myWord = hl == j ? mine : myWord;
