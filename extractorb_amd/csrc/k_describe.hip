@@ -64,15 +64,14 @@ __device__ __forceinline__ void sincosGlibc(float y, float* s_out, float* c_out)
                      c = __dadd_rn(c1, __dmul_rn(x4, sg * C2));
         return __dadd_rn(c, __dmul_rn(x6, c2));
     };
-    {
-        const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[n & 3]
-        *s_out = (n & 1) ? (float)polyCos((n & 2) ? -1.0 : 1.0) : (float)polySin(x * sgn);
-    }
-    {
-        const int m = n + 1;
-        const double sgn = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
-        *c_out = (m & 1) ? (float)polyCos((m & 2) ? -1.0 : 1.0) : (float)polySin(x * sgn);
-    }
+    // sin(y) and cos(y) = "sin" of quadrants n and n + 1; a quadrant takes the sine polynomial when even and the cosine
+    // polynomial when odd, so exactly one of each is evaluated and the parity of n says which result is which.
+    const bool odd = (n & 1) != 0;
+    const int ns = odd ? n + 1 : n, nc = odd ? n : n + 1;
+    const double sgnS = ((ns & 3) == 1 || (ns & 3) == 2) ? -1.0 : 1.0;   // sign[ns & 3]
+    const float ps = (float)polySin(x * sgnS), pc = (float)polyCos((nc & 2) ? -1.0 : 1.0);
+    *s_out = odd ? pc : ps;
+    *c_out = odd ? ps : pc;
 }
 
 constexpr int kDescWaves = 4;                         // waves per workgroup; each half-wave (32 lanes) owns one keypoint
