@@ -150,7 +150,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
                   const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
                   unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
-                  int M, int P, int R, int XT, const int* threadsOfLevel, int B) {
+                  int M, int P, int R, int XT, const int* threadsOfLevel, int f0, int B) {
     // consecutive levels with the same workgroup size share a launch; the smallest levels (many short workgroups) go
     // first so that the long workgroups of the large levels form the tail
     int hi = nlevels;
@@ -161,7 +161,7 @@ void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDe
         auto kern = T == 256 ? k_octree_256 : (T == 512 ? k_octree_512 : k_octree_1024);
         hipLaunchKernelGGL(kern, dim3(B, hi - lo), dim3(T), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, cells, nCellsTotal,
                            candSeg, cellCount, cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap,
-                           lapArea, M, P, R, XT, lo);
+                           lapArea, M, P, R, XT, lo, f0);
         hi = lo;
     }
 }

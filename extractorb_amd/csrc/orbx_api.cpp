@@ -17,17 +17,17 @@
 namespace orbx {
 // launch wrappers, defined in the k_*.hip files
 void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
-                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int);
+                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
-                  uint8_t*, int, int, bool, int);
-void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, const LevelGeom*, const uint8_t*, uint8_t*, int);
+                  uint8_t*, int, int, bool, int, int);
+void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, bool, int);
+                int, int, bool, int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, int);
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, int, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
-                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int);
+                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int, int);
 hipError_t uploadUmax(const int* umax16);
 hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
 struct StereoParams {
@@ -129,6 +129,12 @@ struct orbx_handle {
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
     hipEvent_t statEvent = nullptr;
+    // A batch of >= kSplitBatch frames runs as two half-batches on two streams (fork / join with events): the kernels of
+    // one half overlap the other's (HBM-bound blur and copies under VALU-bound FAST, tails under heads).  ORBX_NO_SPLIT=1
+    // or profiling keeps everything on the caller's stream.
+    hipStream_t aux = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool splitBatches = true;
     bool statPending = false;
     int statB = 0;
     // stereo matching (allocated on first use)
@@ -168,6 +174,9 @@ void freeAll(orbx_handle* h) {
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->statEvent) (void)hipEventDestroy(h->statEvent);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     void* host[] = {h->h_candStat, h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -283,19 +292,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             h->lapCached = want;
         }
     }
-    {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
-        Prof p(h, S_LEVEL0);
-        launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
-                       g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
-                       g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, B);
-    }
-    for (int l = 2; l < g.nlevels; l++) {
-        Prof p(h, S_RESIZE);
-        launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
-                     h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
-                     g.packedTaps[l] && !h->resizeBytewise, B);
-    }
-    { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, B); }
     if (h->statPending && hipEventQuery(h->statEvent) == hipSuccess) {
         long long total = 0;
         for (int i = 0; i < h->statB * g.nlevels; i++) total += h->h_candStat[i];
@@ -303,33 +299,64 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         h->statPending = false;
     }
     const bool prefilter = h->fastMode == 1 || (h->fastMode < 0 && h->candDensity >= 0.f && h->candDensity < kPrefilterDensity);
-    {
-        Prof p(h, S_FAST);
-        launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
-                   h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, B);
-    }
-    {
-        Prof p(h, S_OCTREE);
-        // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
-        // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
-        int octT[kMaxLevels];
-        const long long slots = 2048LL * h->numCUs, wgs = (long long)B * g.nlevels;
-        const int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : 0);
-        for (int l = 0; l < g.nlevels; l++) octT[l] = residentT && !h->octThreadsForced ? residentT : h->octThreads[l];
-        launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
-                     h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                     h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, B);
+    // the launch sequence of frames [f0, f0 + Bn) on stream st
+    auto pipeline = [&](hipStream_t st, int f0, int Bn) -> int {
+        {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
+            Prof p(h, S_LEVEL0);
+            launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
+                           g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
+                           g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
+        }
+        for (int l = 2; l < g.nlevels; l++) {
+            Prof p(h, S_RESIZE);
+            launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
+                         h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
+                         g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
+        }
+        { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, f0, Bn); }
+        {
+            Prof p(h, S_FAST);
+            launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
+                       h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn);
+        }
+        {
+            Prof p(h, S_OCTREE);
+            // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
+            // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
+            int octT[kMaxLevels];
+            const long long slots = 2048LL * h->numCUs, wgs = (long long)Bn * g.nlevels;
+            const int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : 0);
+            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT && !h->octThreadsForced ? residentT : h->octThreads[l];
+            launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
+                         h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, f0, Bn);
+        }
+        {
+            Prof p(h, S_DESCRIBE);
+            launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
+                           h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
+        }
+        return ORBX_OK;
+    };
+    constexpr int kSplitBatch = 256;   // measured at 640x480: B = 256 +2 %, 384 +4 %, 512 +3 %; B = 128 (two 64-frame halves) -7 %
+    if (h->splitBatches && !h->profiling && B >= kSplitBatch) {
+        const int B0 = (B + 1) / 2;
+        HIP_TRY(h, hipEventRecord(h->evFork, st));
+        HIP_TRY(h, hipStreamWaitEvent(h->aux, h->evFork, 0));
+        int rc = pipeline(st, 0, B0);
+        if (rc == ORBX_OK) rc = pipeline(h->aux, B0, B - B0);
+        HIP_TRY(h, hipEventRecord(h->evJoin, h->aux));
+        HIP_TRY(h, hipStreamWaitEvent(st, h->evJoin, 0));
+        if (rc != ORBX_OK) return rc;
+    } else {
+        const int rc = pipeline(st, 0, B);
+        if (rc != ORBX_OK) return rc;
     }
     if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipEventRecord(h->statEvent, st));
         h->statPending = true;
         h->statB = B;
-    }
-    {
-        Prof p(h, S_DESCRIBE);
-        launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
-                       h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, B);
     }
     HIP_TRY(h, hipGetLastError());
     h->lastB = B;
@@ -487,6 +514,10 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
+    h->splitBatches = getenv("ORBX_NO_SPLIT") == nullptr;
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
