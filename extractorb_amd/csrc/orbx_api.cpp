@@ -129,12 +129,13 @@ struct orbx_handle {
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
     hipEvent_t statEvent = nullptr;
-    // A batch of >= kSplitBatch frames runs as two half-batches on two streams (fork / join with events): the kernels of
-    // one half overlap the other's (HBM-bound blur and copies under VALU-bound FAST, tails under heads).  ORBX_NO_SPLIT=1
-    // or profiling keeps everything on the caller's stream.
+    // ORBX_SPLIT_BATCHES=1: a batch of >= kSplitBatch frames runs as two half-batches on two streams (fork / join with
+    // events): the kernels of one half overlap the other's (HBM-bound blur and copies under VALU-bound FAST, tails under
+    // heads; +2-4 % at 640x480).  Off by default so that one launch = one batch and per-kernel durations mean what they say;
+    // profiling always runs unsplit.
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    bool splitBatches = true;
+    bool splitBatches = false;
     bool statPending = false;
     int statB = 0;
     // stereo matching (allocated on first use)
@@ -517,7 +518,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
-    h->splitBatches = getenv("ORBX_NO_SPLIT") == nullptr;
+    h->splitBatches = getenv("ORBX_SPLIT_BATCHES") != nullptr && atoi(getenv("ORBX_SPLIT_BATCHES")) != 0;
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024

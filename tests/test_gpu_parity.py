@@ -325,12 +325,12 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     assert_same_result((mono, k, d), want, "%s=%s clustered" % (switch, value))
 
 
-@pytest.mark.parametrize("B,no_split", [(72, False), (136, False), (300, False), (300, True), (257, False)])
-def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, no_split, monkeypatch):
+@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True)])
+def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
-    # from 256 frames on the batch runs as two halves on two streams unless ORBX_NO_SPLIT is set (odd B: unequal halves)
-    if no_split:
-        monkeypatch.setenv("ORBX_NO_SPLIT", "1")
+    # with ORBX_SPLIT_BATCHES=1 a batch of 256+ frames runs as two halves on two streams (odd B: unequal halves)
+    if split:
+        monkeypatch.setenv("ORBX_SPLIT_BATCHES", "1")
     fr = synth.frames("textured", 40, B, 240, 320)
     ex = X.ORBextractor(500, max_width=320, max_height=240, max_batch=B)
     out = ex.extract_batch(fr)
