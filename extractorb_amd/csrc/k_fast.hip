@@ -418,19 +418,4 @@ hipError_t runPackedSelfTest(hipStream_t st, unsigned* d_scratch, unsigned* h_ba
     return hipStreamSynchronize(st);
 }
 
-// unpack one level's candidates into reference KeyPoints (introspection for tests)
-__global__ void k_unpackCandidates(const unsigned* __restrict__ keys, int n, Keypoint* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned w = keys[i];
-    Keypoint k;
-    k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff); k.size = 7.f; k.angle = -1.f;
-    k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
-    out[i] = k;
-}
-void launchUnpackCandidates(hipStream_t st, const unsigned* keys, int n, Keypoint* out) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_unpackCandidates, dim3((n + 255) / 256), dim3(256), 0, st, keys, n, out);
-}
-
 }  // namespace orbx

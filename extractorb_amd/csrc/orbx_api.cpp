@@ -51,7 +51,6 @@ struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, fr
 void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
-void launchUnpackCandidates(hipStream_t, const unsigned*, int, Keypoint*);
 }  // namespace orbx
 
 using namespace orbx;
