@@ -91,6 +91,14 @@ __device__ __forceinline__ unsigned waveSumDpp(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dppMinU(unsigned v) { return min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false)); }
+__device__ __forceinline__ unsigned waveMinDpp(unsigned v) {
+    v = dppMinU<0xB1, 0xF>(v); v = dppMinU<0x4E, 0xF>(v); v = dppMinU<0x141, 0xF>(v); v = dppMinU<0x140, 0xF>(v);
+    v = dppMinU<0x142, 0xA>(v); v = dppMinU<0x143, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // grid (ceil(capacity/4), n_pairs), 256 threads: one wave per left keypoint.
 __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restrict__ lv, const uint8_t* __restrict__ pyr,
                                                        const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
@@ -137,8 +145,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
         const unsigned key = ((unsigned)dist << 16) | (unsigned)iR;
         best = dist < kThHigh && key < best ? key : best;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    best = waveMinDpp(best);
     const int bestDist = (int)(best >> 16);
     if (bestDist >= (kThHigh + kThLow) / 2) return;                    // thOrbDist  (:896)
     const int bestIdxR = (int)(best & 0xffff);
