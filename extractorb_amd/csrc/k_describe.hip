@@ -197,11 +197,17 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         m10 = (int)s1 - 16 * (int)s0;     // sum u*I
         m01 = v * (int)s0;                // v * sum I
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {    // reduce inside the half-wave
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
+    // reduce inside the half-wave: four DPP steps cover a row of 16 lanes, one cross-lane exchange joins the two rows
+    auto rowSum = [](int v) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);    // row_half_mirror
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);    // row_mirror
+        return v;
+    };
+    m10 = rowSum(m10); m01 = rowSum(m01);
+    m10 += __shfl_xor(m10, 16);
+    m01 += __shfl_xor(m01, 16);
     const float angle = fastAtan2Deg((float)m01, (float)m10);
 
     // ---- computeOrbDescriptor (:106-145) on the blurred level ----
