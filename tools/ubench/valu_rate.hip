@@ -1,75 +1,160 @@
-// Microbenchmark: issue rate of the VALU instructions the FAST kernel is built from (gfx950).
-// Every wave runs ITER x 64 independent instructions of one kind (8 accumulators, no memory traffic);
-// reports SIMD cycles per wave-instruction at a given occupancy.   hipcc --offload-arch=gfx950 -O3 valu_rate.hip
+// Microbenchmark: issue rate of VALU instructions on gfx950 — the integer / packed-16 instructions the kernels are built
+// from, next to f32 calibration lines (v_fma_f32, v_add_f32, v_max3_f32, v_pk_fma_f32, v_cvt_f32_ubyte0), so that the
+// "vector-instruction issue" roofline is priced against the same yardstick as the hardware guide's 2-cycle v_fma_f32.
+//
+// Every wave runs ITER x (8 x NACC) instructions of one kind, no memory traffic.  Three dependency shapes:
+//   acc8   8 accumulators, each instruction reads its own previous result (a dependent chain per accumulator)
+//   acc16  16 accumulators (twice the distance between dependent instructions)
+//   indep  the destination is write-only (no read-after-write at all): pure issue
+// Reported per (instruction, shape, waves per SIMD): SIMD cycles per wave64 instruction two ways —
+//   "ev"  from HIP-event time at the nominal 2.4 GHz, and
+//   "mt"  from s_memtime ticks measured inside the waves (the guide: one tick = one shader cycle), which does not
+//         depend on the clock the chip actually ran at.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate [csv]
 #include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
-#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned* out, int iters) {
-    unsigned a[8], b = threadIdx.x * 2654435761u, c = blockIdx.x * 40503u + 7;
+enum Op {
+    OP_MIN3_U32, OP_PK_MINIMUM3_F16, OP_PK_MIN_U16, OP_PERM_B32, OP_MIN_U32, OP_PK_SUB_U16, OP_BFE_U32, OP_ALIGNBYTE,
+    OP_DOT4_U32_U8, OP_MAD_U32_U24, OP_ADD_U32, OP_AND_B32, OP_LSHLREV_B32, OP_MUL_LO_U32,
+    OP_FMA_F32, OP_ADD_F32, OP_MAX3_F32, OP_PK_FMA_F32, OP_CVT_F32_UBYTE0, OP_PK_ADD_F16, OP_MOV_B32, OP_COUNT
+};
+static const char* kNames[OP_COUNT] = {
+    "v_min3_u32", "v_pk_minimum3_f16", "v_pk_min_u16", "v_perm_b32", "v_min_u32", "v_pk_sub_u16", "v_bfe_u32", "v_alignbyte_b32",
+    "v_dot4_u32_u8", "v_mad_u32_u24", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_mul_lo_u32",
+    "v_fma_f32", "v_add_f32", "v_max3_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_pk_add_f16", "v_mov_b32"};
+
+// DEP: 1 = the instruction reads its own destination (accumulator chain), 0 = destination is write-only
+template <int OP, int DEP>
+__device__ __forceinline__ void one(unsigned& a, unsigned long long& a2, unsigned b, unsigned c, unsigned long long b2) {
+#define I3(NAME)                                                                                         \
+    if (DEP) asm volatile(NAME " %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));                          \
+    else asm volatile(NAME " %0, %1, %2, %1" : "=v"(a) : "v"(b), "v"(c));
+#define I2(NAME)                                                                                         \
+    if (DEP) asm volatile(NAME " %0, %0, %1" : "+v"(a) : "v"(b));                                      \
+    else asm volatile(NAME " %0, %1, %2" : "=v"(a) : "v"(b), "v"(c));
+    if constexpr (OP == OP_MIN3_U32) { I3("v_min3_u32") }
+    else if constexpr (OP == OP_PK_MINIMUM3_F16) { I3("v_pk_minimum3_f16") }
+    else if constexpr (OP == OP_PK_MIN_U16) { I2("v_pk_min_u16") }
+    else if constexpr (OP == OP_PERM_B32) { I3("v_perm_b32") }
+    else if constexpr (OP == OP_MIN_U32) { I2("v_min_u32") }
+    else if constexpr (OP == OP_PK_SUB_U16) { I2("v_pk_sub_u16") }
+    else if constexpr (OP == OP_BFE_U32) {
+        if (DEP) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a)); else asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a) : "v"(b));
+    }
+    else if constexpr (OP == OP_ALIGNBYTE) { I3("v_alignbyte_b32") }
+    else if constexpr (OP == OP_DOT4_U32_U8) {
+        if (DEP) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+        else asm volatile("v_dot4_u32_u8 %0, %1, %2, %1" : "=v"(a) : "v"(b), "v"(c));
+    }
+    else if constexpr (OP == OP_MAD_U32_U24) {
+        if (DEP) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+        else asm volatile("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(a) : "v"(b), "v"(c));
+    }
+    else if constexpr (OP == OP_ADD_U32) { I2("v_add_u32") }
+    else if constexpr (OP == OP_AND_B32) { I2("v_and_b32") }
+    else if constexpr (OP == OP_LSHLREV_B32) {
+        if (DEP) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a)); else asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(a) : "v"(b));
+    }
+    else if constexpr (OP == OP_MUL_LO_U32) { I2("v_mul_lo_u32") }
+    else if constexpr (OP == OP_FMA_F32) {
+        if (DEP) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+        else asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(a) : "v"(b), "v"(c));
+    }
+    else if constexpr (OP == OP_ADD_F32) { I2("v_add_f32") }
+    else if constexpr (OP == OP_MAX3_F32) { I3("v_max3_f32") }
+    else if constexpr (OP == OP_PK_FMA_F32) {
+        if (DEP) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(a2) : "v"(b2));
+        else asm volatile("v_pk_fma_f32 %0, %1, %1, %1" : "=v"(a2) : "v"(b2));
+    }
+    else if constexpr (OP == OP_CVT_F32_UBYTE0) {
+        if (DEP) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a)); else asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(a) : "v"(b));
+    }
+    else if constexpr (OP == OP_PK_ADD_F16) { I2("v_pk_add_f16") }
+    else if constexpr (OP == OP_MOV_B32) {
+        if (DEP) asm volatile("v_mov_b32 %0, %0" : "+v"(a)); else asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
+    }
+#undef I3
+#undef I2
+}
+
+template <int OP, int NACC, int DEP>
+__global__ __launch_bounds__(256) void k(unsigned* out, unsigned long long* ticks, int iters) {
+    unsigned a[NACC], b = (threadIdx.x * 2654435761u) & 0x00ff00ffu, c = (blockIdx.x * 40503u + 7) & 0x00ff00ffu;
+    unsigned long long a2[NACC], b2 = ((unsigned long long)__float_as_uint(1.0f) << 32) | __float_as_uint(0.5f);
 #pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = (threadIdx.x + i * 977u) & 0x00ff00ffu;
+    for (int i = 0; i < NACC; i++) { a[i] = (threadIdx.x + i * 977u) & 0x00ff00ffu; a2[i] = b2 + i; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-#define ONE(i)                                                                                                          \
-    if (OP == 0) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                            \
-    else if (OP == 1) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));               \
-    else if (OP == 2) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                 \
-    else if (OP == 3) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                       \
-    else if (OP == 4) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                    \
-    else if (OP == 5) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                 \
-    else if (OP == 6) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                 \
-    else if (OP == 7) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                       \
-    else if (OP == 8) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                 \
-    else if (OP == 9) asm volatile("v_min3_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                       \
-    else if (OP == 10) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));                                          \
-    else if (OP == 11) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
-            REP8(ONE)
-#undef ONE
+#pragma unroll
+            for (int i = 0; i < NACC; i++) one<OP, DEP>(a[i], a2[i], b, c, b2);
         }
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned r = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r ^= a[i];
+    for (int i = 0; i < NACC; i++) r ^= a[i] ^ (unsigned)a2[i] ^ (unsigned)(a2[i] >> 32);
     if (r == 0x12345678u) out[threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int OP>
-double run(unsigned* d, int blocks, int iters) {
+struct Res { double evCycles, mtCycles; };
+
+template <int OP, int NACC, int DEP>
+Res run(unsigned* d, unsigned long long* dT, int blocks, int wavesPerSimd) {
+    const int iters = 16000 / NACC;                  // 8 * NACC * iters = 128000 instructions per wave
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<OP, NACC, DEP>), dim3(blocks), dim3(256), 0, 0, d, dT, iters);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<OP, NACC, DEP>), dim3(blocks), dim3(256), 0, 0, d, dT, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    return ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    std::vector<unsigned long long> t((size_t)blocks * 4);
+    hipMemcpy(t.data(), dT, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (auto v : t) sum += (double)v;
+    const double instrPerWave = 8.0 * NACC * iters;
+    Res r;
+    r.evCycles = ms * 1e6 / (instrPerWave * wavesPerSimd) * 2.4;                 // ns per wave-instr per SIMD x 2.4 GHz
+    r.mtCycles = sum / t.size() / (instrPerWave * wavesPerSimd);                 // a wave's ticks cover wavesPerSimd waves' instructions
+    return r;
 }
 
-int main() {
-    unsigned* d;
-    hipMalloc(&d, 4096);
-    const char* names[] = {"v_min3_u32", "v_pk_minimum3_f16", "v_pk_min_u16", "v_perm_b32", "v_min_u32", "v_pk_max_u16",
-                           "v_pk_min_f16", "v_max3_u32", "v_pk_sub_u16", "v_min3_i16", "v_bfe_u32", "v_pk_maximum3_f16"};
-    const int iters = 2000;
+template <int OP>
+void runOp(unsigned* d, unsigned long long* dT, bool csv) {
     for (int wavesPerSimd : {1, 2, 4, 8}) {
         const int blocks = 256 * wavesPerSimd;     // 256 CUs x (4 waves per block = 1 per SIMD) x wavesPerSimd
-        double ms[12];
-        ms[0] = run<0>(d, blocks, iters); ms[1] = run<1>(d, blocks, iters); ms[2] = run<2>(d, blocks, iters); ms[3] = run<3>(d, blocks, iters);
-        ms[4] = run<4>(d, blocks, iters); ms[5] = run<5>(d, blocks, iters); ms[6] = run<6>(d, blocks, iters); ms[7] = run<7>(d, blocks, iters);
-        ms[8] = run<8>(d, blocks, iters); ms[9] = run<9>(d, blocks, iters); ms[10] = run<10>(d, blocks, iters); ms[11] = run<11>(d, blocks, iters);
-        for (int i = 0; i < 12; i++) {
-            const double instrPerWave = (double)iters * 64, ns = ms[i] * 1e6;
-            // time per wave-instruction per SIMD (ns) = total time / (instructions per wave * waves per SIMD)
-            printf("waves/SIMD %d  %-20s %8.3f ms  %6.3f ns per wave-instr per SIMD (= %.2f cycles at 2.4 GHz)\n", wavesPerSimd, names[i],
-                   ms[i], ns / (instrPerWave * wavesPerSimd), ns / (instrPerWave * wavesPerSimd) * 2.4);
-        }
+        const Res a8 = run<OP, 8, 1>(d, dT, blocks, wavesPerSimd), a16 = run<OP, 16, 1>(d, dT, blocks, wavesPerSimd),
+                  in = run<OP, 8, 0>(d, dT, blocks, wavesPerSimd);
+        if (csv) printf("%s,%d,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f\n", kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles);
+        else printf("%-20s waves/SIMD %d   acc8 ev %6.2f mt %6.2f   acc16 ev %6.2f mt %6.2f   indep ev %6.2f mt %6.2f  cycles per wave64 instr per SIMD\n",
+                    kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles);
+        fflush(stdout);
     }
+}
+
+template <int OP>
+void runAll(unsigned* d, unsigned long long* dT, bool csv) {
+    if constexpr (OP < OP_COUNT) { runOp<OP>(d, dT, csv); runAll<OP + 1>(d, dT, csv); }
+}
+
+int main(int argc, char** argv) {
+    const bool csv = argc > 1 && !strcmp(argv[1], "csv");
+    unsigned* d; unsigned long long* dT;
+    hipMalloc(&d, 4096);
+    hipMalloc(&dT, 256 * 8 * 4 * sizeof(unsigned long long));
+    if (csv) printf("instruction,waves_per_simd,acc8_ev,acc8_mt,acc16_ev,acc16_mt,indep_ev,indep_mt\n");
+    runAll<0>(d, dT, csv);
     return 0;
 }
