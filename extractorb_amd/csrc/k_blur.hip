@@ -29,8 +29,10 @@ __device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
 // names the lane's item (a per-thread binary search would start every workgroup with eight dependent loads).
 __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items, const unsigned short* __restrict__ laneItem,
                                                int nLanes, const LevelGeom* __restrict__ lv,
-                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int f0) {
-    const int gl = blockIdx.x * 256 + threadIdx.x, f = f0 + blockIdx.y;
+                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int f0, int nFrames) {
+    int chunk, fr;
+    if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all row blocks of a frame on one XCD: their 6 halo rows hit its L2
+    const int gl = chunk * 256 + threadIdx.x, f = f0 + fr;
     if (gl >= nLanes) return;
     const BlurItem it = items[laneItem[gl]];      // host table: the (level, row block) this lane works on
     const LevelGeom g = lv[it.level];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items
 
 void launchBlur(hipStream_t st, const BlurItem* items, const unsigned short* laneItem, int nLanes, const LevelGeom* lv,
                 const uint8_t* pyr, uint8_t* blur, int f0, int B) {
-    hipLaunchKernelGGL(k_blur, dim3((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur, f0);
+    hipLaunchKernelGGL(k_blur, xcdGrid((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur, f0, B);
 }
 
 }  // namespace orbx

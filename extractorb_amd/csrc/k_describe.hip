@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                    const int* __restrict__ levelCount, const int* __restrict__ levelLap,
                                                    Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
                                                    int* __restrict__ nOut, int* __restrict__ monoOut,
-                                                   Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts, int f0) {
+                                                   Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts, int f0, int nFrames) {
     __shared__ __align__(16) uint8_t smem[2 * kDescWaves * kPatchLds];
     __shared__ __align__(16) unsigned wtab[2][16][8];   // [m10 weights | disc mask][|v|][dword of the aligned row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
-    const int f = f0 + blockIdx.y;
+    int chunk, fr;
+    if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all keypoints of a frame on one XCD: overlapping patches share its L2
+    const int f = f0 + fr;
     {   // weight words of row |v| = a, bytes k = 0..31 <-> u = k - 15
         const int which = tid >> 7, a = (tid >> 3) & 15, j = tid & 7;
         unsigned w = 0;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         wtab[which][a][j] = w;
     }
     __syncthreads();
-    const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kDescWaves + wave) * 2);   // wave-uniform
+    const int slot0 = __builtin_amdgcn_readfirstlane((chunk * kDescWaves + wave) * 2);   // wave-uniform
     const int slot = slot0 + half;
     // totals of this frame and the level this wave belongs to (scalar: slot0 is uniform)
     int total = 0, totalLap = 0, level = 0, seqBase = 0, lapBase = 0;
@@ -263,9 +265,9 @@ void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint
                     uint8_t* outD, int capacity, int* nOut, int* monoOut, Keypoint* outLevelK, int* outLevelCounts,
                     int f0, int B) {
     const int perBlock = 2 * kDescWaves;
-    hipLaunchKernelGGL(k_describe, dim3((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
+    hipLaunchKernelGGL(k_describe, xcdGrid((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
                        pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
-                       outLevelCounts, f0);
+                       outLevelCounts, f0, B);
 }
 static const int8_t kHostPattern[1024] = {
 #include "orbx_brief_pattern.inc"

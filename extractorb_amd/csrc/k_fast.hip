@@ -172,7 +172,7 @@ template <int TS, int ROWS, bool PREFILTER>
 __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0) {
+                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
     constexpr int DW = TS / 4;                        // dwords per tile row
@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword
     __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
-    const int ci = blockIdx.x * kFastWaves + wave, f = f0 + blockIdx.y;
+    int chunk, fr;
+    if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all cells of a frame on one XCD: the 6-px ROI overlap of neighbouring cells hits its L2
+    const int ci = chunk * kFastWaves + wave, f = f0 + fr;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
@@ -385,14 +387,14 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
                 bool prefilter, int f0, int B) {
-    const dim3 grid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
+    const dim3 grid = xcdGrid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
     if (maxRoiW <= 45 && maxRoiH <= 45) {
-        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0);
-        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0);
+        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
+        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
     } else {   // cells up to 63 px (the geometry code rejects larger ones)
-        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0);
-        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0);
+        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
+        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
     }
 }
 

@@ -203,16 +203,17 @@ __device__ __forceinline__ void copyTile(const SrcView& sv, const LevelGeom& g0,
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, LevelGeom g1, int tilesX0, int nTiles0,
                                                     int tilesX1, const ResizeX* __restrict__ xt, const ResizeX* __restrict__ yt,
-                                                    const TileFoot* __restrict__ foot, uint8_t* __restrict__ pyr, int ldsStride, int f0) {
+                                                    const TileFoot* __restrict__ foot, uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
-    int t = blockIdx.x;
+    int t, fr;
+    if (!xcdChunkFrame(nFrames, t, fr)) return;                      // all tiles of a frame on one XCD: the copy tile and the resize tiles that read the same source rows share its L2
     if (t < nTiles0) {
         const int tileY = t / tilesX0;
-        copyTile(img, g0, pyr, t - tileY * tilesX0, tileY, f0 + blockIdx.y);
+        copyTile(img, g0, pyr, t - tileY * tilesX0, tileY, f0 + fr);
     } else {
         t -= nTiles0;
         const int tileY = t / tilesX1;
-        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + blockIdx.y, tile, ldsStride);
+        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride);
     }
 }
 
@@ -220,13 +221,15 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt,
                                                  const ResizeX* __restrict__ yt, const TileFoot* __restrict__ foot,
-                                                 uint8_t* __restrict__ pyr, int ldsStride, int f0) {
+                                                 uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
     SrcView sv;
     sv.p = pyr + s.pyrOff + (long long)kEdge * s.pyrStride + kPadL;
     sv.stride = s.pyrStride; sv.frame = s.pyrFrameBytes; sv.readableCols = s.w + kEdge; sv.aligned = 1;
-    const int tileY = blockIdx.x / tilesX;
-    resizeTile<PACKED>(sv, d, xt, yt, foot[blockIdx.x], pyr, blockIdx.x - tileY * tilesX, tileY, f0 + blockIdx.y, tile, ldsStride);
+    int t, fr;
+    if (!xcdChunkFrame(nFrames, t, fr)) return;   // neighbouring tiles of a frame (overlapping source footprints) on one XCD
+    const int tileY = t / tilesX;
+    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,
@@ -237,17 +240,17 @@ void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long l
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
     const int n0 = tilesX0 * tilesY0, n1 = g1 ? tilesX1 * tilesY1 : 0;
     // + 16: the packed path reads three dwords from the first tap's dword, i.e. up to 8 bytes past a row's footprint
-    if (packed) hipLaunchKernelGGL(k_pyr_first<true>, dim3(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
-                                   g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0);
-    else hipLaunchKernelGGL(k_pyr_first<false>, dim3(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
-                            g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0);
+    if (packed) hipLaunchKernelGGL(k_pyr_first<true>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
+                                   g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
+    else hipLaunchKernelGGL(k_pyr_first<false>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
+                            g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
 }
 void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt,
                   const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {
-    if (packed) hipLaunchKernelGGL(k_resize<true>, dim3(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                                   tilesX, xt, yt, foot, pyr, ldsStride, f0);
-    else hipLaunchKernelGGL(k_resize<false>, dim3(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                            tilesX, xt, yt, foot, pyr, ldsStride, f0);
+    if (packed) hipLaunchKernelGGL(k_resize<true>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
+                                   tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
+    else hipLaunchKernelGGL(k_resize<false>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
+                            tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
 }
 
 }  // namespace orbx

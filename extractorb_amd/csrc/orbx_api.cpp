@@ -128,13 +128,11 @@ struct orbx_handle {
     float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
     unsigned* h_candStat = nullptr; // pinned copy of d_candCount
     hipEvent_t statEvent = nullptr;
-    // ORBX_SPLIT_BATCHES=1: a batch of >= kSplitBatch frames runs as two half-batches on two streams (fork / join with
-    // events): the kernels of one half overlap the other's (HBM-bound blur and copies under VALU-bound FAST, tails under
-    // heads; +2-4 % at 640x480).  Off by default so that one launch = one batch and per-kernel durations mean what they say;
-    // profiling always runs unsplit.
+    // the internal stream and the events of the two-half overlap (enqueueBatch)
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    bool splitBatches = false;
+    int splitMode = 1;                 // ORBX_SPLIT=0: never split a batch over the two streams
+    long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
     int statB = 0;
     // stereo matching (allocated on first use)
@@ -242,16 +240,16 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
 }
 
 struct Prof {
-    orbx_handle* h; int slot; hipEvent_t a = nullptr, b = nullptr;
-    Prof(orbx_handle* h_, int s) : h(h_), slot(s) {
+    orbx_handle* h; int slot; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Prof(orbx_handle* h_, int s, hipStream_t st_ = nullptr) : h(h_), slot(s), st(st_ ? st_ : h_->stream) {
         if (h->profiling) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, h->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~Prof() {
         if (h->profiling) {
-            (void)hipEventRecord(b, h->stream);
+            (void)hipEventRecord(b, st);
             h->pending.push_back(EventPair{a, b, slot});
         }
     }
@@ -299,28 +297,31 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         h->statPending = false;
     }
     const bool prefilter = h->fastMode == 1 || (h->fastMode < 0 && h->candDensity >= 0.f && h->candDensity < kPrefilterDensity);
-    // the launch sequence of frames [f0, f0 + Bn) on stream st
-    auto pipeline = [&](hipStream_t st, int f0, int Bn) -> int {
+    // the launch sequence of frames [f0, f0 + Bn) on stream st, in two parts: front = pyramid + blur (HBM / latency bound),
+    // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
+    auto front = [&](hipStream_t st, int f0, int Bn) {
         {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
-            Prof p(h, S_LEVEL0);
+            Prof p(h, S_LEVEL0, st);
             launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
                            g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
                            g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
         }
         for (int l = 2; l < g.nlevels; l++) {
-            Prof p(h, S_RESIZE);
+            Prof p(h, S_RESIZE, st);
             launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
                          h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                          g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
         }
-        { Prof p(h, S_BLUR); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, f0, Bn); }
+        { Prof p(h, S_BLUR, st); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, f0, Bn); }
+    };
+    auto back = [&](hipStream_t st, int f0, int Bn) {
         {
-            Prof p(h, S_FAST);
+            Prof p(h, S_FAST, st);
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn);
         }
         {
-            Prof p(h, S_OCTREE);
+            Prof p(h, S_OCTREE, st);
             // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
             // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
             int octT[kMaxLevels];
@@ -332,25 +333,35 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, f0, Bn);
         }
         {
-            Prof p(h, S_DESCRIBE);
+            Prof p(h, S_DESCRIBE, st);
             launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
                            h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
         }
-        return ORBX_OK;
     };
-    constexpr int kSplitBatch = 256;   // measured at 640x480: B = 256 +2 %, 384 +4 %, 512 +3 %; B = 128 (two 64-frame halves) -7 %
-    if (h->splitBatches && !h->profiling && B >= kSplitBatch) {
-        const int B0 = (B + 1) / 2;
+    // Overlap inside one call: a large batch runs as two half-batches side by side, one on the caller's stream and one on
+    // an internal stream (fork / join with events), so that kernels which leave vector-issue slots idle (memory or barrier
+    // latency: blur, copies, quad-tree) share the chip with kernels of the other half that fill them, and tails run under
+    // heads.  Measured (profiles/r02_split_sweep.md): +3 % at 512 x 640x480, +1.5 % at 256, -9 % at 128 frames (kernel tails
+    // of the smaller launches), so parts of fewer than h->splitMinPixels pyramid pixels are not made.  Staggering the halves
+    // (front of one under FAST of the other, events between the streams at every stage) and four parts were both slower.
+    // ORBX_SPLIT=0 turns it off; event profiling always runs unsplit so that one launch is one batch.
+    const bool split = h->splitMode > 0 && !h->profiling && B >= 2 && (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
+    if (!split) {
+        front(st, 0, B);
+        back(st, 0, B);
+    } else {
+        struct Join {      // the internal stream is always joined back into the caller's, also on an early error return
+            orbx_handle* h; hipStream_t st; bool armed = false;
+            ~Join() { if (armed) { (void)hipEventRecord(h->evJoin, h->aux); (void)hipStreamWaitEvent(st, h->evJoin, 0); } }
+        } join{h, st};
         HIP_TRY(h, hipEventRecord(h->evFork, st));
         HIP_TRY(h, hipStreamWaitEvent(h->aux, h->evFork, 0));
-        int rc = pipeline(st, 0, B0);
-        if (rc == ORBX_OK) rc = pipeline(h->aux, B0, B - B0);
-        HIP_TRY(h, hipEventRecord(h->evJoin, h->aux));
-        HIP_TRY(h, hipStreamWaitEvent(st, h->evJoin, 0));
-        if (rc != ORBX_OK) return rc;
-    } else {
-        const int rc = pipeline(st, 0, B);
-        if (rc != ORBX_OK) return rc;
+        join.armed = true;
+        const int B0 = (B + 1) / 2;
+        front(st, 0, B0);
+        back(st, 0, B0);
+        front(h->aux, B0, B - B0);
+        back(h->aux, B0, B - B0);
     }
     if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
@@ -517,7 +528,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
-    h->splitBatches = getenv("ORBX_SPLIT_BATCHES") != nullptr && atoi(getenv("ORBX_SPLIT_BATCHES")) != 0;
+    h->splitMode = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 1;
+    h->splitMinPixels = (long long)((getenv("ORBX_SPLIT_MIN_MPX") ? atof(getenv("ORBX_SPLIT_MIN_MPX")) : 120.0) * 1e6);
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024

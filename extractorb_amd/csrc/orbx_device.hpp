@@ -65,5 +65,21 @@ struct TileFoot { short fx0, nDw, fy0, nRows; };   // first source column (multi
 
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
 
+#ifdef __HIPCC__
+// XCD-aware launch shape for "chunks x frames" grids: grid = (8, chunks, ceil(frames / 8)).
+// Workgroups are dealt round-robin to the 8 XCDs by linear id (MI355X_MICROARCH.md, Workgroup dispatch): ids b and b + 8
+// share an XCD and its private 4-MiB L2.  With chunks fastest, the chunks of one frame are sprayed over all eight L2s, so
+// pixels that neighbouring chunks share (FAST ROI overlap, blur halo rows, overlapping keypoint patches, resize
+// footprints) are fetched from HBM once per XCD.  Here blockIdx.x (fastest) is the frame inside a group of eight, so every
+// chunk of a frame lands on the same XCD and the shared lines hit its L2.  No division in the kernel; the workgroups of
+// the last group that name a frame >= nFrames exit at once.  A speed choice only: results never depend on placement.
+static inline dim3 xcdGrid(int chunks, int nFrames) { return nFrames < 8 ? dim3(nFrames, chunks, 1) : dim3(8, chunks, (nFrames + 7) / 8); }
+__device__ __forceinline__ bool xcdChunkFrame(int nFrames, int& chunk, int& frame) {
+    chunk = blockIdx.y;
+    frame = gridDim.x * blockIdx.z + blockIdx.x;    // fewer than 8 frames: plain (frame, chunk) grid, chunks spread over all XCDs
+    return frame < nFrames;
+}
+#endif
+
 
 }  // namespace orbx
