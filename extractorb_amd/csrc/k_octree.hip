@@ -110,6 +110,10 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 // round trips, not by arithmetic, so a level whose sweeps are short (a 640x480 image: a few thousand keys) runs as
 // fast with 256 threads as with 1024 but then holds a quarter of a CU's thread slots: four times as many levels run
 // side by side.  Levels with tens of thousands of keys (1080p) still want 512 or 1024 threads.
+// OCT_W = waves per SIMD the variant is compiled for, i.e. its register budget: 8 -> 64 VGPRs (about 64 values live in
+// scratch, but 6 workgroups of 256 threads fit a CU: best when a large batch queues many more workgroups than fit the chip),
+// 4 -> 128 VGPRs, no scratch (best while every workgroup of the launch is resident anyway: small batches, one frame).
+#define OCT_W 8
 #define OCT_T 1024
 #define OCT_NAME(x) x##_1024
 #include "k_octree_body.inc"
@@ -125,6 +129,24 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
+#undef OCT_W
+#define OCT_W 4
+#define OCT_T 1024
+#define OCT_NAME(x) x##_1024r
+#include "k_octree_body.inc"
+#undef OCT_T
+#undef OCT_NAME
+#define OCT_T 256
+#define OCT_NAME(x) x##_256r
+#include "k_octree_body.inc"
+#undef OCT_T
+#undef OCT_NAME
+#define OCT_T 512
+#define OCT_NAME(x) x##_512r
+#include "k_octree_body.inc"
+#undef OCT_T
+#undef OCT_NAME
+#undef OCT_W
 
 #ifdef ORBX_OCT_STAMPS
 extern "C" int orbx_debug_oct_stamps(unsigned long long* out128) {
@@ -150,7 +172,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
                   const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
                   unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
-                  int M, int P, int R, int XT, const int* threadsOfLevel, int f0, int B) {
+                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B) {
     // consecutive levels with the same workgroup size share a launch; the smallest levels (many short workgroups) go
     // first so that the long workgroups of the large levels form the tail
     int hi = nlevels;
@@ -158,7 +180,8 @@ void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDe
         int lo = hi - 1;
         const int T = threadsOfLevel[lo];
         while (lo > 0 && threadsOfLevel[lo - 1] == T) lo--;
-        auto kern = T == 256 ? k_octree_256 : (T == 512 ? k_octree_512 : k_octree_1024);
+        auto kern = roomy ? (T == 256 ? k_octree_256r : (T == 512 ? k_octree_512r : k_octree_1024r))
+                          : (T == 256 ? k_octree_256 : (T == 512 ? k_octree_512 : k_octree_1024));
         hipLaunchKernelGGL(kern, dim3(B, hi - lo), dim3(T), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, cells, nCellsTotal,
                            candSeg, cellCount, cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap,
                            lapArea, M, P, R, XT, lo, f0);

@@ -25,7 +25,7 @@ void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const 
                 int, int, bool, int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, int, int);
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int, int);
 hipError_t uploadUmax(const int* umax16);
@@ -325,12 +325,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
             // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
             int octT[kMaxLevels];
-            const long long slots = 2048LL * h->numCUs, wgs = (long long)Bn * g.nlevels;
-            const int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : 0);
-            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT && !h->octThreadsForced ? residentT : h->octThreads[l];
+            // (the "resident" variants are compiled for 4 waves per SIMD = 128 VGPRs, no scratch: 1024 threads per CU-SIMD set)
+            const long long slots = 1024LL * h->numCUs, wgs = (long long)Bn * g.nlevels;   // threads resident at once at 4 waves per SIMD
+            int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : (wgs * 256 <= slots ? 256 : 0));
+            if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
+            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, f0, Bn);
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0, f0, Bn);
         }
         {
             Prof p(h, S_DESCRIBE, st);

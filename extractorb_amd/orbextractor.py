@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-_LIB = os.path.join(_PKG, "liborbx.so")
+_LIB = os.environ.get("ORBX_LIBRARY") or os.path.join(_PKG, "liborbx.so")   # ORBX_LIBRARY: another build of the same library (tuning experiments)
 _HEADER = os.path.join(_ROOT, "include", "orbx.h")
 
 # numpy mirror of cv::KeyPoint / orbx_keypoint (28 bytes)
@@ -43,6 +43,21 @@ def build_library(force=False):
         args.append("-B")
     subprocess.check_call(args)
     return _LIB
+
+
+def source_hash():
+    """Short hash of every source file liborbx.so is built from.  Counter files under profiles/ carry the hash of the
+    sources they were measured on; bench.py refuses (null) counters whose hash differs from the tree it runs in."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(_PKG, "csrc", "*.inc")) + glob.glob(os.path.join(_PKG, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(_PKG, "csrc", "Makefile")) + glob.glob(os.path.join(_ROOT, "include", "*")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def header_symbols():

@@ -7,6 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# one launch = one batch: the two-half overlap (default for large batches) is switched off, as in bench.py's own event-profiled pass
+export ORBX_SPLIT=0
+python3 -c "import sys; sys.path.insert(0, '$R'); import extractorb_amd as X; print(X.source_hash())" > $OUT/source_hash.txt
 CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- $CMD > $OUT/stats.log 2>&1 || exit 1
 echo "stats done"
