@@ -146,6 +146,13 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
+#define OCT_GLOBAL 1
+#define OCT_T 1024
+#define OCT_NAME(x) x##_1024g
+#include "k_octree_body.inc"
+#undef OCT_T
+#undef OCT_NAME
+#undef OCT_GLOBAL
 #undef OCT_W
 
 #ifdef ORBX_OCT_STAMPS
@@ -154,17 +161,16 @@ extern "C" int orbx_debug_oct_stamps(unsigned long long* out128) {
 }
 #endif
 
+// bytes of the node arrays of one workgroup (LDS, or a slice of the HBM arena of the _1024g variant); layout: k_octree_body.inc
 size_t octreeLdsBytes(int M, int P, int R, int XT) {
-    size_t b = 0;
-    b += 2 * (size_t)M * sizeof(short4);            // box
-    b += 2 * (size_t)M * sizeof(int);               // cnt
+    (void)P;                                        // the sort keys live in the idle node group (8 P <= 16 M)
+    const size_t tables = ((size_t)2 * XT + 7) & ~(size_t)7;
+    size_t b = 2 * std::max((size_t)16 * M, tables);    // two groups {box (8), cnt (4), ncode (4)} x M | sort keys | xcode, ycode
     b += 4 * (size_t)M * sizeof(int);               // childCnt / best
     b += 4 * (size_t)M * sizeof(unsigned short);    // mapChild
     b += (size_t)M * sizeof(unsigned short);        // mapKeep
     b += (size_t)M * sizeof(int);                   // fwd
     b += (size_t)M * sizeof(int);                   // keepIdx
-    b += std::max((size_t)P * sizeof(unsigned long long), (2 * (size_t)XT + 7) & ~(size_t)7);   // sortKey | xcode, ycode
-    b += 2 * (size_t)M * sizeof(unsigned);          // ncode
     b += (size_t)R * kHistPerRoot * sizeof(int);    // hist
     b += (size_t)R * kLeaves * sizeof(unsigned);    // leafBest | cell
     return b + 64;
@@ -172,7 +178,14 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
                   const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
                   unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
-                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B) {
+                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B, uint8_t* nodeArena) {
+    const size_t bytes = octreeLdsBytes(M, P, R, XT);
+    if (nodeArena) {      // node arrays in HBM: one launch, 1024 threads per (frame, level)
+        hipLaunchKernelGGL(k_octree_1024g, dim3(B, nlevels), dim3(1024), 0, st, lv, nlevels, cells, nCellsTotal, candSeg, cellCount,
+                           cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT, 0, f0,
+                           nodeArena, (unsigned long long)((bytes + 255) & ~(size_t)255));
+        return;
+    }
     // consecutive levels with the same workgroup size share a launch; the smallest levels (many short workgroups) go
     // first so that the long workgroups of the large levels form the tail
     int hi = nlevels;
@@ -182,9 +195,9 @@ void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDe
         while (lo > 0 && threadsOfLevel[lo - 1] == T) lo--;
         auto kern = roomy ? (T == 256 ? k_octree_256r : (T == 512 ? k_octree_512r : k_octree_1024r))
                           : (T == 256 ? k_octree_256 : (T == 512 ? k_octree_512 : k_octree_1024));
-        hipLaunchKernelGGL(kern, dim3(B, hi - lo), dim3(T), octreeLdsBytes(M, P, R, XT), st, lv, nlevels, cells, nCellsTotal,
+        hipLaunchKernelGGL(kern, dim3(B, hi - lo), dim3(T), bytes, st, lv, nlevels, cells, nCellsTotal,
                            candSeg, cellCount, cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap,
-                           lapArea, M, P, R, XT, lo, f0);
+                           lapArea, M, P, R, XT, lo, f0, (uint8_t*)nullptr, 0ull);
         hi = lo;
     }
 }

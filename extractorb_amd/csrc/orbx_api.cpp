@@ -25,7 +25,7 @@ void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const 
                 int, int, bool, int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int);
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int, int);
 hipError_t uploadUmax(const int* umax16);
@@ -100,6 +100,8 @@ struct orbx_handle {
     size_t laneCap = 0;
     int nBlurLanes = 0;
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
+    size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
+    uint8_t* d_octArena = nullptr;
     int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
     // outputs of the host path
     int outCap = 0;
@@ -113,6 +115,7 @@ struct orbx_handle {
     uint8_t* h_outD = nullptr;
     int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
     int lastB = 0;
+    int lastHostB = 0;           // frames whose results the handle itself holds (d_outK / h_nOut ...): set by the host-buffer path only
     int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
     bool pendingLevels = false;
     // FAST kernel choice.  Both variants give identical results; the one that first rejects pixels with a cheap exact
@@ -168,7 +171,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
-                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_rowOff, h->d_sadDist,
+                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->statEvent) (void)hipEventDestroy(h->statEvent);
@@ -196,6 +199,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // tables may still be in use by queued work
     h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
     h->lastB = 0;
+    h->lastHostB = 0;
     HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
     size_t xo = 0, yo = 0;
@@ -332,7 +336,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0, f0, Bn);
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0, f0, Bn, h->d_octArena);
         }
         {
             Prof p(h, S_DESCRIBE, st);
@@ -373,6 +377,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     }
     HIP_TRY(h, hipGetLastError());
     h->lastB = B;
+    h->lastHostB = 0;            // the caller's buffers hold this batch; orbx_extract_batch_begin sets it again for its own
     return ORBX_OK;
 }
 
@@ -487,10 +492,19 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->octR = 1;
     for (int l = 0; l < nlevels; l++) h->octR = mg.lv[l].nIni > h->octR ? mg.lv[l].nIni : h->octR;
     h->octXT = ((mg.lv[0].rectW > mg.lv[0].rectH ? mg.lv[0].rectW : mg.lv[0].rectH) + 15) / 16 * 16;
+    const int denseR = h->octR <= 7 ? h->octR : 0, denseXT = h->octR <= 7 ? h->octXT : 0;
     if (h->octR > 7 || octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) { h->octR = 0; h->octXT = 0; }
     if (octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) {
-        h->err = "orbx_create: per-level feature quota too large for the LDS-resident quad-tree (nfeatures <= ~9000)";
-        return bail(ORBX_ERR_UNSUPPORTED);
+        // per-level quotas in the thousands (the reference builds its initialisation extractor with 5 * nFeatures,
+        // Tracking.cc:774): the node arrays of a level no longer fit a CU's LDS; they move to an HBM arena, one slice per
+        // (frame, level) workgroup (k_octree_1024g), where size does not matter and the dense phase is available again
+        if (h->octM > 65535) { h->err = "orbx_create: more than 65535 quad-tree nodes per level"; return bail(ORBX_ERR_UNSUPPORTED); }
+        h->octR = denseR; h->octXT = denseXT;
+        h->octArenaSlice = (octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) + 255) & ~(size_t)255;
+        if ((double)h->octArenaSlice * max_batch * nlevels > 16e9) {
+            h->err = "orbx_create: quad-tree node arena for this nfeatures x max_batch exceeds 16 GB; lower max_batch";
+            return bail(ORBX_ERR_UNSUPPORTED);
+        }
     }
     h->outCap = mg.selPerFrame + 8 * nlevels;
 
@@ -506,6 +520,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_nodeOf, h->candEntries * sizeof(unsigned short)));
     CREATE_TRY(hipMalloc(&h->d_candCount, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_sel, h->selEntries * sizeof(uint2)));
+    if (h->octArenaSlice) CREATE_TRY(hipMalloc(&h->d_octArena, h->octArenaSlice * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_levelCount, sizeof(int) * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_levelLap, sizeof(int) * max_batch * nlevels));
     CREATE_TRY(hipMalloc(&h->d_lap, sizeof(int) * 2 * max_batch));
@@ -643,6 +658,7 @@ int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, 
         HIP_TRY(h, hipMemcpyAsync(h->h_outLevelCounts, h->d_outLevelCounts, sizeof(int) * B * h->nlevels, hipMemcpyDeviceToHost, st));
     }
     h->pendingB = B;
+    h->lastHostB = B;
     h->pendingLevels = want_levels != 0;
     return ORBX_OK;
 }
@@ -846,8 +862,19 @@ int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d
 int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
                            int* n_matched) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!u_right || !depth || !n_matched || capacity < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer or capacity < 1");
+    if (!u_right || !depth || !n_matched || capacity < 1 || n_pairs < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity < 1 or n_pairs < 1");
+    // the handle only holds results of the host-buffer path (orbx_extract / orbx_extract_batch / _begin + _end); after
+    // orbx_extract_batch_device the results live in the caller's buffers: use orbx_stereo_match_device there
+    if (h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "a batch is still in flight: call orbx_extract_batch_end first");
+    if (2 * n_pairs > h->lastHostB)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_stereo_match_last needs the 2*n_pairs frames of the last orbx_extract_batch call on this handle "
+                                              "(after orbx_extract_batch_device use orbx_stereo_match_device)");
     const int cap = h->outCap;
+    for (int p = 0; p < n_pairs; p++) {     // counts of the left eyes, copied to the host by that call
+        const int n = h->h_nOut[2 * p];
+        if (n < 0 || n > cap) return fail(h, ORBX_ERR_HIP, "corrupt keypoint count in the handle's staging (internal)");
+        if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity smaller than the left keypoint count");
+    }
     int rc = stereoEnsure(h, n_pairs, cap, h->geom.rows > 0 ? h->geom.rows : 1);
     if (rc != ORBX_OK) return rc;
     rc = stereoEnqueue(h, n_pairs, h->d_outK, h->d_outD, h->d_nOut, cap, bf, b, h->d_uRight, h->d_depth, h->d_nMatched);
@@ -858,8 +885,7 @@ int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float
     HIP_TRY(h, hipMemcpyAsync(n_matched, h->d_nMatched, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int p = 0; p < n_pairs; p++) {
-        const int n = h->h_nOut[2 * p];      // left keypoints of this pair, from the last orbx_extract_batch
-        if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity smaller than the left keypoint count");
+        const int n = h->h_nOut[2 * p];
         std::memcpy(u_right + (size_t)p * capacity, hu.data() + (size_t)p * cap, sizeof(float) * n);
         std::memcpy(depth + (size_t)p * capacity, hd.data() + (size_t)p * cap, sizeof(float) * n);
     }

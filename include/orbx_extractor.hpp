@@ -42,23 +42,36 @@ public:
 
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };   // inc/ORBextractor.h:48
 
-    // inc/ORBextractor.h:50-51.  max_* size the device arenas once; images may be smaller, never larger.
+    // inc/ORBextractor.h:50-51.  The reference takes images of any size; max_* only pre-size the device arenas (one
+    // allocation for the usual camera): a larger image makes operator() re-create them at the new size (Reserve()).
     BasicORBextractor(int nfeatures_, float scaleFactor_, int nlevels_, int iniThFAST_, int minThFAST_,
                       int max_width = 1920, int max_height = 1080, int device = -1)
         : nfeatures(nfeatures_), scaleFactor(scaleFactor_), nlevels(nlevels_), iniThFAST(iniThFAST_),
-          minThFAST(minThFAST_) {
-        int rc = orbx_create(&h_, nfeatures_, scaleFactor_, nlevels_, iniThFAST_, minThFAST_, max_width, max_height, 1, device);
-        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_create: ") + orbx_last_error(nullptr));
+          minThFAST(minThFAST_), device_(device) {
+        Reserve(max_width, max_height);
         mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
         mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
         mnFeaturesPerLevel.resize(nlevels); umax.resize(16);
         orbx_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                         mnFeaturesPerLevel.data(), umax.data());
         mvImagePyramid.resize(nlevels);
-        capacity_ = orbx_max_keypoints(h_);
-        kbuf_.resize(capacity_); lbuf_.resize(capacity_); dbuf_.resize((size_t)capacity_ * 32);
     }
     ~BasicORBextractor() { orbx_destroy(h_); }
+
+    // (Re-)creates the device arenas for images up to width x height (never shrinks).  Called by the constructor and by
+    // operator() when an image exceeds the current size; call it yourself to keep the allocation out of the first frame.
+    void Reserve(int width, int height) {
+        if (h_ && width <= maxW_ && height <= maxH_) return;
+        const int w = width > maxW_ ? width : maxW_, hgt = height > maxH_ ? height : maxH_;
+        orbx_handle* nh = nullptr;
+        int rc = orbx_create(&nh, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, w, hgt, 1, device_);
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_create: ") + orbx_last_error(nullptr));
+        orbx_destroy(h_);
+        h_ = nh; maxW_ = w; maxH_ = hgt;
+        capacity_ = orbx_max_keypoints(h_);
+        kbuf_.resize(capacity_); lbuf_.resize(capacity_); dbuf_.resize((size_t)capacity_ * 32);
+        pyramidStale_ = true; lastRows_ = lastCols_ = 0;
+    }
     BasicORBextractor(const BasicORBextractor&) = delete;
     BasicORBextractor& operator=(const BasicORBextractor&) = delete;
 
@@ -67,6 +80,7 @@ public:
                    std::vector<int>& vLappingArea, std::vector<std::vector<KeyPoint>>& allLevelsKeypoints) {
         if (Traits::empty(image)) return -1;                                     // :1083-1084
         if (!Traits::isU8C1(image)) throw std::invalid_argument("ORBextractor: image.type() != CV_8UC1");   // assert :1087
+        Reserve(Traits::cols(image), Traits::rows(image));                       // the reference has no size limit
         int n = 0, mono = 0;
         std::vector<int> counts(nlevels);
         int rc = orbx_extract(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image),
@@ -130,6 +144,7 @@ public:
 
 private:
     orbx_handle* h_ = nullptr;
+    int device_ = -1, maxW_ = 0, maxH_ = 0;
     int lastRows_ = 0, lastCols_ = 0;
     int capacity_ = 0;
     bool pyramidStale_ = true;
@@ -139,7 +154,9 @@ private:
 
 }  // namespace orbx
 
-#ifdef OPENCV_CORE_HPP   // real OpenCV was included before this header: bind the reference's names
+// real OpenCV was included before this header: bind the reference's names.  The include guard of <opencv2/core.hpp> is
+// OPENCV_CORE_HPP from 3.2 on and __OPENCV_CORE_HPP__ in 3.0 / 3.1; the reference pins only "OpenCV 3" (CMakeLists.txt:23)
+#if defined(OPENCV_CORE_HPP) || defined(__OPENCV_CORE_HPP__)
 namespace orbx {
 struct CvTraits {
     using KeyPoint = cv::KeyPoint;

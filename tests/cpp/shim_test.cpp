@@ -46,7 +46,10 @@ int main(int argc, char** argv) {
     std::fclose(f);
     try {
         using Extractor = orbx::BasicORBextractor<mini::Traits>;
-        Extractor* mpORBextractorLeft = new Extractor(nf, 1.2f, 8, 20, 7, cols, rows);
+        // ORBX_SHIM_TEST_SMALL_ARENAS: construct exactly as the reference does (five arguments, default arenas) so that a larger
+        // image has to grow them inside operator()
+        Extractor* mpORBextractorLeft = std::getenv("ORBX_SHIM_TEST_SMALL_ARENAS") ? new Extractor(nf, 1.2f, 8, 20, 7)
+                                                                                   : new Extractor(nf, 1.2f, 8, 20, 7, cols, rows);
         std::vector<mini::KeyPoint> mvKeys;
         mini::Mat mDescriptors;
         std::vector<int> vLapping = {std::atoi(argv[5]), std::atoi(argv[6])};

@@ -24,7 +24,9 @@ def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
         assert np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)), "border %d" % l
         if len(o.level_keypoints(l)):      # the reference only blurs levels that hold keypoints (:1122-1127)
             assert np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)), "blur level %d" % l
-        cg, co = sort_kps(ex.debug_candidates(l, frame)), sort_kps(o.candidates(l))
+        # k_fast's per-cell segments, read segment by segment, ARE vToDistributeKeys in the reference's order (cell row,
+        # cell column, then raster order inside the cell, ORBextractor.cc:797-864): compared without sorting
+        cg, co = ex.debug_candidates(l, frame), o.candidates(l)
         assert cg.tobytes() == co.tobytes(), "FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co))
         assert lvl_gpu[l].tobytes() == o.level_keypoints(l).tobytes(), "quad-tree/orientation level %d" % l
 
@@ -328,9 +330,12 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
 @pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True)])
 def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
-    # with ORBX_SPLIT_BATCHES=1 a batch of 256+ frames runs as two halves on two streams (odd B: unequal halves)
+    # a large batch runs as two halves on two streams (odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small
+    # frames count as large, ORBX_SPLIT=0 turns the overlap off
     if split:
-        monkeypatch.setenv("ORBX_SPLIT_BATCHES", "1")
+        monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
+    else:
+        monkeypatch.setenv("ORBX_SPLIT", "0")
     fr = synth.frames("textured", 40, B, 240, 320)
     ex = X.ORBextractor(500, max_width=320, max_height=240, max_batch=B)
     out = ex.extract_batch(fr)
@@ -340,6 +345,25 @@ def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B,
         assert_same_result(out[f][:3], (mono, k, d), "frame %d of %d" % (f, B))
     o, want = oracle_run(fr[B - 1], 500)
     assert_same_result(out[B - 1][:3], want, "last frame of %d vs oracle" % B)
+
+
+@pytest.mark.parametrize("shape,nf", [((480, 640), 10000), ((376, 1241), 10000), ((480, 640), 25000), ((480, 752), 6000)])
+def test_initialisation_extractor_quotas(shape, nf):
+    # the reference builds its monocular initialisation extractor with 5 * nFeatures (Tracking.cc:774): 5 x 2000 = 10000 for a
+    # KITTI-style settings file (1241x376: four quad-tree roots), 5 x 1200 = 6000 for EuRoC.  Per-level quotas in the thousands:
+    # the quad-tree's node arrays fill a CU's LDS (10000) or move to the HBM arena (25000)
+    rows, cols = shape
+    img = synth.frames("noise", 77, 1, rows, cols)[0]
+    o, want = oracle_run(img, nf)
+    ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=2)
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, "%s nf=%d" % (shape, nf))
+    assert len(k) > 0.9 * nf or nf > 20000          # noise frames fill the quota
+    tex = synth.frames("textured", 78, 2, rows, cols)                     # two frames per call: two arena slices
+    out = ex.extract_batch(tex)
+    for f in range(2):
+        assert_same_result(out[f][:3], oracle_run(tex[f], nf)[1], "textured %s nf=%d frame %d" % (shape, nf, f))
 
 
 def test_scale_factor_two_uses_the_byte_gather_resize():

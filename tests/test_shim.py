@@ -11,13 +11,17 @@ import extractorb_amd as X
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "shim_test")
+def _build(tmp_path, name="shim_test"):
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(X.library_path())
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "shim_test.cpp"), "-o", exe, "-L" + libdir, "-lorbx",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe, "-L" + libdir, "-lorbx",
                            "-Wl,-rpath," + libdir])
     return exe
+
+
+def test_thread_program_compiles(tmp_path):
+    assert os.path.exists(_build(tmp_path, "shim_threads_test"))
 
 
 def test_shim_compiles_and_links(tmp_path):
@@ -53,3 +57,46 @@ def test_shim_matches_oracle(tmp_path):
     assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
     assert counts.tolist() == [len(o.level_keypoints(l)) for l in range(8)]
     assert np.array_equal(l3, o.level(3))
+
+
+@pytest.mark.gpu
+def test_two_extractors_on_two_threads_match_oracle(tmp_path):
+    """Frame.cc:109-112: mpORBextractorLeft and mpORBextractorRight are called from two std::threads at once.  Two shim instances
+    (two handles, two streams), different images, 20 rounds: every round equals the first, and both eyes equal the oracle.
+    Both instances start with 320x240 arenas and grow to the 640x480 images inside their first call."""
+    import oracle_lib as O
+    from extractorb_amd import synth
+    exe = _build(tmp_path, "shim_threads_test")
+    left = synth.frames("textured", 31, 1, 480, 640)[0]
+    right = synth.frames("noise", 32, 1, 480, 640)[0]
+    (tmp_path / "l.gray").write_bytes(left.tobytes()); (tmp_path / "r.gray").write_bytes(right.tobytes())
+    out = tmp_path / "out.bin"
+    subprocess.check_call([exe, str(tmp_path / "l.gray"), str(tmp_path / "r.gray"), "480", "640", "1200", "20", str(out)])
+    raw = out.read_bytes()
+    p = 0
+    for img in (left, right):
+        mono, n = np.frombuffer(raw[p:p + 8], np.int32); p += 8
+        k = np.frombuffer(raw[p:p + 28 * n], X.KEYPOINT_DTYPE); p += 28 * n
+        d = np.frombuffer(raw[p:p + 32 * n], np.uint8).reshape(n, 32); p += 32 * n
+        wm, wk, wd = O.Oracle(1200).extract(img, (0, 0))
+        assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
+    assert p == len(raw)
+
+
+@pytest.mark.gpu
+def test_shim_grows_its_arenas(tmp_path):
+    """The reference's operator() takes any image size; the shim pre-sizes for 1920x1080 and re-creates its arenas for more."""
+    import oracle_lib as O
+    from extractorb_amd import synth
+    exe = _build(tmp_path)
+    img = synth.frames("textured", 3, 1, 1100, 2000)[0]              # larger than the default arenas in both dimensions
+    (tmp_path / "in.gray").write_bytes(img.tobytes())
+    out = tmp_path / "out.bin"
+    env = dict(os.environ, ORBX_SHIM_TEST_SMALL_ARENAS="1")           # shim_test then constructs with the default 1920x1080
+    subprocess.check_call([exe, str(tmp_path / "in.gray"), "1100", "2000", "1500", "0", "1000", str(out)], env=env)
+    raw = out.read_bytes()
+    mono, n = np.frombuffer(raw[:8], np.int32)
+    k = np.frombuffer(raw[8:8 + 28 * n], X.KEYPOINT_DTYPE)
+    d = np.frombuffer(raw[8 + 28 * n:8 + 60 * n], np.uint8).reshape(n, 32)
+    wm, wk, wd = O.Oracle(1500).extract(img, (0, 1000))
+    assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)

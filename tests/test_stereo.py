@@ -9,11 +9,29 @@ import extractorb_amd as X
 from extractorb_amd import synth
 
 
-def stereo_pair(disparity, seed=77, rows=480, cols=640, variant="textured"):
-    big = synth.VARIANTS[variant](seed, rows, cols + 2 * 40)
-    left = np.ascontiguousarray(big[:, 40:40 + cols])
-    right = np.ascontiguousarray(big[:, 40 + disparity:40 + disparity + cols])   # the right camera sees the scene shifted left
+def stereo_pair(disparity, seed=77, rows=480, cols=640, variant="textured", dy=0, noise=0):
+    """Left / right views cut from one wider scene.  dy: the right view sits dy rows lower (imperfect rectification: the
+    match of a left keypoint is then found through the +-2*scale row band of Frame.cc:826-840, not on its own row);
+    noise: independent per-eye sensor noise of that amplitude, so the two eyes never hold identical pixels."""
+    big = synth.VARIANTS[variant](seed, rows + 8, cols + 2 * 40)
+    left = np.ascontiguousarray(big[4:4 + rows, 40:40 + cols])
+    right = np.ascontiguousarray(big[4 + dy:4 + dy + rows, 40 + disparity:40 + disparity + cols])   # the right camera sees the scene shifted left
+    if noise:
+        rng = np.random.default_rng(seed * 7 + 1)
+        left = np.clip(left.astype(np.int16) + rng.integers(-noise, noise + 1, left.shape), 0, 255).astype(np.uint8)
+        right = np.clip(right.astype(np.int16) + rng.integers(-noise, noise + 1, right.shape), 0, 255).astype(np.uint8)
     return left, right
+
+
+@pytest.mark.parametrize("dy", [-2, -1, 1, 2])
+def test_oracle_matches_through_the_row_band(dy):
+    # a vertical offset of 1-2 px between the eyes plus per-eye noise: matches must come from neighbouring rows of the band
+    left, right = stereo_pair(15, dy=dy, noise=4)
+    kL, u, d, kept = oracle_stereo(left, right)
+    ok = u >= 0
+    assert kept == ok.sum() and kept > 60
+    est = kL["x"][ok] - u[ok]
+    assert abs(np.median(est) - 15) < 0.3
 
 
 def oracle_stereo(left, right, nf=1200, bf=40.0, b=0.1):
@@ -57,8 +75,11 @@ def test_oracle_respects_disparity_range():
 @pytest.mark.gpu
 @pytest.mark.parametrize("disp,variant,bf,b", [(12, "textured", 40.0, 0.1), (4, "noise", 40.0, 0.1), (37, "textured", 60.0, 0.5),
                                                (0, "textured", 40.0, 0.1), (25, "sparse", 40.0, 0.1)])
-def test_gpu_stereo_match_equals_oracle(disp, variant, bf, b):
-    left, right = stereo_pair(disp, variant=variant)
+@pytest.mark.parametrize("dy,noise", [(0, 0), (1, 3), (-2, 5), (2, 0)])
+def test_gpu_stereo_match_equals_oracle(disp, variant, bf, b, dy, noise):
+    if (dy, noise) != (0, 0) and variant == "sparse":
+        pytest.skip("offset cases run on the dense variants")
+    left, right = stereo_pair(disp, variant=variant, dy=dy, noise=noise)
     kL, u_o, d_o, kept_o = oracle_stereo(left, right, bf=bf, b=b)
     ex = X.ORBextractor(1200, max_batch=2)
     res = ex.extract_batch(np.stack([left, right]), lapping=(0, 0))
@@ -108,3 +129,17 @@ def test_gpu_stereo_argument_errors():
         ex.stereo_match_last(1, 40.0, 0.0)                 # b must be positive (maxD = bf/b)
     u, d, nm = ex.stereo_match_last(1, 40.0, 0.1)
     assert nm[0] > 100
+    # after the device-resident path the results live in the caller's buffers, not in the handle: _last must refuse
+    # (it used to read a stale keypoint count out of the handle's staging memory) and _device is the call to use
+    import torch
+    cap = ex.capacity
+    d_img = torch.from_numpy(np.stack([left, right])).cuda()
+    d_k = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda"); d_d = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(2, dtype=torch.int32, device="cuda"); d_m = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img, 2, 480, 640, d_k, d_d, d_n, d_m, cap, lapping=(0, 0))
+    ex.synchronize()
+    with pytest.raises(X.OrbxError):
+        ex.stereo_match_last(1, 40.0, 0.1)
+    ex.extract_batch(np.stack([left, right]), lapping=(0, 0))          # the host path makes it valid again
+    u2, d2, nm2 = ex.stereo_match_last(1, 40.0, 0.1)
+    assert nm2[0] == nm[0] and u2.tobytes() == u.tobytes()
