@@ -48,8 +48,12 @@ WORKLOADS = {
                         desc="640x480 BGR stream: cvtColor(BGR2GRAY) + extraction, 8 levels, 1000 features"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# integer / packed VALU issue: one wave64 instruction per 4 cycles per SIMD (16 lanes per clock) x 1024 SIMDs x 2.4 GHz;
-# tools/ubench/valu_rate.hip measures 4.11-4.2 cycles at the nominal clock (profiles/r01_valu_issue_rate.md)
+# Vector-instruction issue, half-rate class: one wave64 instruction per 4 cycles per SIMD x 1024 SIMDs x 2.4 GHz.  gfx950 has two
+# issue classes (profiles/r02_valu_issue_rate.md, tools/ubench/valu_rate.hip): v_fma_f32 / v_add_f32 / v_mul_f32 / v_add_u32 /
+# v_and_b32 / v_or_b32 / v_mov_b32 issue in ~2 cycles (the hardware guide's figure), everything these kernels are made of
+# (v_pk_minimum3_f16, v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_mad_u32_u24, packed-16 arithmetic, v_min/max, shifts) in ~4.
+# Pricing every instruction at 4 cycles is therefore an UPPER bound of the issue time (exact for an all-half-rate kernel);
+# `frac_lower` prices the kernel's full-rate share (static census of its ISA, tools/valu_census.py) at 2 cycles.
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
 
 
@@ -65,6 +69,7 @@ def main():
     ap.add_argument("--handles", type=int, default=1, help="extractor handles per GPU used round-robin, each on its own "
                     "HIP stream (two cameras / ping-pong batches: small kernels of one overlap big kernels of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures of the default line (host-to-host rate, 1080p)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -145,15 +150,22 @@ def main():
     gathered = None
     gather = distributed and not args.no_gather
     if gather and rank == 0:
-        gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(2)]
-    pending = [None]
+        gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(len(slabs))]
+    pending = [None] * len(slabs)      # the gather that last read slab k (and last wrote gathered[k])
     counter = [0]
 
     def step():
         k = counter[0] % len(slabs)
-        e_ = exs[counter[0] % nH]
+        j = counter[0] % nH
+        e_ = exs[j]
         counter[0] += 1
         b = slabs[k].data_ptr()
+        if pending[k] is not None:
+            # slab k is about to be overwritten by handle j on ITS stream: that stream, not torch's current one, has to wait
+            # for the gather that is still reading the slab
+            with torch.cuda.stream(streams[j]):
+                pending[k].wait()
+            pending[k] = None
         if color:
             e_.gray_from_color_device(B, d_color, rows, cols, color, False, d_img)     # Tracking.cc:991-993 (mbRGB = 0: BGR)
         e_.extract_batch_device(d_img, B, rows, cols, b + off_k, b + off_d, b + off_n, b + off_m, cap, lapping=wl["lapping"])
@@ -162,16 +174,16 @@ def main():
         if init_match:
             finish_and_match(e_, b)
         if gather:
-            if nH > 1:
-                stream.wait_stream(streams[(counter[0] - 1) % nH])   # the collective is ordered after the CURRENT stream
-            if pending[0] is not None:
-                pending[0].wait()          # the previous step's slab has arrived; its buffer may be overwritten next step
-            pending[0] = dist.gather(slabs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
+            if j != 0:
+                stream.wait_stream(streams[j])   # the collective is ordered after torch's CURRENT stream
+            # asynchronous: while this slab travels to rank 0 the next step already computes into the other slab
+            pending[k] = dist.gather(slabs[k], gathered[k] if rank == 0 else None, dst=0, async_op=True)
 
     def fence():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -218,27 +230,37 @@ def main():
         n_mean = float(n_host.mean())
         b_alg = ex.algorithmic_bytes(rows, cols, int(round(n_mean)))   # P0 + 2*S + 60*n_out per frame
         achieved = b_alg * B / (dom_avg_ms * 1e-3) / 1e9               # GB/s: algorithmic bytes of one launch / its duration
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
+        # PMC-derived figures of the dominant kernel (profiles/traffic.json, profiles/valu.json: rocprofv3 --pmc passes of this
+        # workload, published by tools/publish_profiles.py).  Each (workload, batch) entry carries the hash of the kernel
+        # sources it was measured on; counters of another build are not this kernel's: null.
+        src_hash = X.source_hash()
         default_variant = variant == WORKLOADS[args.workload]["variant"]   # the PMC files were collected on the default variant
-        if os.path.exists(tpath) and default_variant:
+
+        def pmc_entry(name):
+            path = os.path.join(ROOT, "profiles", name)
+            if not (os.path.exists(path) and default_variant):
+                return None
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(args.workload, {}).get(str(B), {}).get(dominant)
+                e = json.load(open(path)).get(args.workload, {}).get(str(B), {})
             except Exception:
-                traffic = None
+                return None
+            return e if e.get("_source_hash") == src_hash else None
+
+        traffic = None
+        te = pmc_entry("traffic.json")
+        if te:
+            traffic = te.get(dominant)
         valu = None
-        vpath = os.path.join(ROOT, "profiles", "valu.json")           # PMC SQ_INSTS_VALU per launch, if collected
-        if os.path.exists(vpath) and default_variant:
-            try:
-                vj = json.load(open(vpath)).get(args.workload, {}).get(str(B), {}).get(dominant)
-                if vj:
-                    g_instr = vj["SQ_INSTS_VALU"] / (dom_avg_ms * 1e-3) / 1e9
-                    valu = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
-                                peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
-                                note="the dominant kernel is bound by vector-instruction issue, not by HBM: this is its binding roofline")
-            except Exception:
-                valu = None
+        ve = pmc_entry("valu.json")
+        if ve and ve.get(dominant):
+            vj = ve[dominant]
+            g_instr = vj["SQ_INSTS_VALU"] / (dom_avg_ms * 1e-3) / 1e9
+            full = float(vj.get("full_rate_share", 0.0))          # static ISA census: share of 2-cycle-class instructions
+            valu = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
+                        peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
+                        full_rate_share=round(full, 3), frac_lower=round(g_instr * (1 - full / 2) / VALU_PEAK_GINSTR, 4),
+                        note="issue-slot occupancy of the dominant kernel: frac prices every instruction at the 4-cycle class "
+                             "(upper bound), frac_lower prices its full-rate share at 2 cycles; profiles/r02_valu_issue_rate.md")
         roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),
@@ -255,11 +277,61 @@ def main():
             sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=threads)
             n1 = 16 if rows * cols <= 640 * 480 else 3      # the reference runs one extractor on one thread (Frame.cc:419-427)
             sec1, _ = O.time_frames(cf[:n1], nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=1)
-            cpu = dict(value=round(sample / sec, 2), unit="frames/s", cores=threads, kind="port",
+            cpu = dict(value=round(sample / sec, 2), unit="frames/s", cores=os.cpu_count() or 1, threads=threads, kind="port",
                        single_thread_value=round(n1 / sec1, 2),
                        sample="%d %s frames %dx%d, one oracle extractor per thread, %.1f s wall (single thread: %d frames, %.1f s); "
-                              "scalar C++ restatement of ORBextractor.cc + OpenCV primitives (not OpenCV's SIMD build)"
+                              "scalar C++ -O3 restatement of ORBextractor.cc + OpenCV primitives (not OpenCV's SIMD build); cores = "
+                              "host cores of the box, threads = oracle threads used"
                               % (sample, variant, cols, rows, sec, n1, sec1))
+        extras = {}
+        if N == 1 and args.workload == "mono640" and not args.no_extras and not distributed:
+            # (a) PCIe-inclusive rate (SURVEY.md §8d "end-to-end"): pinned host frames in, host arrays out, two handles used alternately
+            #     so one batch's transfers overlap the other's kernels.  Never `value`.
+            Bh = min(B, 64)
+            hx = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=Bh, device=local_rank) for _ in range(2)]
+            pin = [X.pinned_empty((Bh, rows, cols)) for _ in range(2)]
+            for a in pin:
+                a[...] = frames[:Bh]
+            hx[0].extract_batch_begin(pin[0]); hx[1].extract_batch_begin(pin[1]); hx[0].extract_batch_end(); hx[1].extract_batch_end()
+            reps = 16
+            t1 = time.perf_counter()
+            hx[0].extract_batch_begin(pin[0], lapping=wl["lapping"])
+            for i in range(1, reps):
+                hx[i & 1].extract_batch_begin(pin[i & 1], lapping=wl["lapping"])
+                hx[(i - 1) & 1].extract_batch_end_view()
+            hx[(reps - 1) & 1].extract_batch_end_view()
+            dt = time.perf_counter() - t1
+            extras["host_to_host_fps"] = round(Bh * reps / dt, 1)
+            extras["host_to_host_note"] = ("pinned host frames -> H2D -> whole path -> D2H of keypoints+descriptors, %d frames per call, "
+                                           "two handles alternating (PCIe-inclusive; not `value`)" % Bh)
+            for a in pin:
+                X.pinned_free(a)
+            del hx
+            # (b) BASELINE.json configs[2] as a secondary figure: 1920x1080, 2000 features, device-resident, 64 frames per call
+            w2 = WORKLOADS["hd1080"]
+            B2 = 64
+            f2 = torch.from_numpy(synth.frames("noise", 0, 16, w2["rows"], w2["cols"])).cuda().repeat(B2 // 16, 1, 1).contiguous()
+            e2 = X.ORBextractor(w2["nfeatures"], 1.2, 8, 20, 7, max_width=w2["cols"], max_height=w2["rows"], max_batch=B2, device=local_rank)
+            e2.set_stream(stream.cuda_stream)
+            cap2 = min(e2.capacity, w2["nfeatures"] + 24)
+            l2 = sharding.slab_layout(B2, cap2)
+            s2 = torch.zeros(l2["bytes"], dtype=torch.uint8, device="cuda")
+            b2 = s2.data_ptr()
+            run2 = lambda: e2.extract_batch_device(f2, B2, w2["rows"], w2["cols"], b2 + l2["keypoints"], b2 + l2["descriptors"],
+                                                   b2 + l2["n"], b2 + l2["mono"], cap2, lapping=w2["lapping"])
+            for _ in range(3):
+                run2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                run2()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            n2 = float(s2[l2["n"]:l2["n"] + 4 * B2].cpu().numpy().view(np.int32).mean())
+            extras["hd1080_fps"] = round(B2 * 10 / dt, 1)
+            extras["hd1080_note"] = "1920x1080 x 2000 features (BASELINE.json configs[2]), %d noise frames per call, device-resident, %.0f keypoints per frame" % (B2, n2)
+            extras["hd1080_path_frac"] = round(B2 * 10 / dt * e2.algorithmic_bytes(w2["rows"], w2["cols"], int(round(n2))) / 1e9 / HBM_PEAK_GBS, 5)
+            del e2
         result = {
             "metric": "frames/sec (ORB extract, %dx%dx8-level x%d feat)" % (cols, rows, nf),
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -273,7 +345,7 @@ def main():
                        **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": extras or None,
         }
         print(json.dumps(result), flush=True)
     if distributed:

@@ -312,6 +312,21 @@ class ORBextractor:
         self._pending = None
         return [(int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(B)]
 
+    def extract_batch_end_view(self):
+        """Zero-copy form of extract_batch_end: waits, then returns numpy views (keypoints[B, cap], descriptors[B, cap, 32], n[B],
+        mono[B]) into the handle's pinned staging, valid until the next extract_batch_begin on this extractor."""
+        if getattr(self, "_pending", None) is None:
+            raise OrbxError(-2, "no batch in flight: call extract_batch_begin first")
+        B = self._pending[0]
+        vk, vd, vn, vm, vc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        self._check(self._L.orbx_extract_batch_end_view(self._h, C.byref(vk), C.byref(vd), C.byref(vc), C.byref(vn), C.byref(vm)))
+        self._pending = None
+        cap = vc.value
+        as_np = lambda ptr, nbytes: np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), np.uint8)
+        kps = as_np(vk, B * cap * 28).view(KEYPOINT_DTYPE).reshape(B, cap)
+        desc = as_np(vd, B * cap * 32).reshape(B, cap, 32)
+        return kps, desc, as_np(vn, 4 * B).view(np.int32), as_np(vm, 4 * B).view(np.int32)
+
     def extract_batch_device(self, d_images, n_frames, rows, cols, d_kps, d_desc, d_n, d_mono, capacity,
                              stride=None, frame_stride=None, lapping=None, d_level_kps=0, d_level_counts=0):
         """Device-pointer form (ints or objects with .data_ptr()); asynchronous on the handle's stream."""

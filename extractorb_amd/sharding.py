@@ -55,6 +55,8 @@ def unpack_slab(slab, frames_per_rank, capacity, n_valid=None, keypoint_dtype=No
     out = []
     for f in range(frames_per_rank if n_valid is None else n_valid):
         n = int(n_arr[f])
+        if not 0 <= n <= capacity:
+            raise ValueError("frame %d: keypoint count %d outside the slab capacity %d (corrupt or mismatched slab)" % (f, n, capacity))
         ko = lay["keypoints"] + f * capacity * 28
         do = lay["descriptors"] + f * capacity * 32
         k = slab[ko:ko + n * 28].copy().view(dt).reshape(-1)

@@ -1,0 +1,37 @@
+"""Bounded, seeded randomised parity sweep under -m gpu: tools/fuzz_parity.py's generator (random image sizes, feature counts,
+level counts, scale factors 1.1-2.0, thresholds, lapping areas, content), every stage and the final arrays against the oracle,
+under each kernel-variant switch.  The totals are written to gpurun_out/r02_fuzz_parity.json on the GPU box (copied to
+profiles/r02_fuzz_parity.md)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+# (environment switches, cases, seed): the switches are read by orbx_create
+CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THREADS": "512"}, 8, 103),
+           ({"ORBX_OCT_THREADS": "1024"}, 8, 104), ({"ORBX_FAST_PREFILTER": "0"}, 8, 105), ({"ORBX_FAST_PREFILTER": "1"}, 8, 106),
+           ({"ORBX_RESIZE_BYTEWISE": "1"}, 8, 107)]
+_totals = []
+
+
+@pytest.mark.parametrize("env,n,seed", CONFIGS, ids=[",".join("%s=%s" % kv for kv in c[0].items()) or "default" for c in CONFIGS])
+def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
+    import fuzz_parity
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    done, skipped, nkp, nbytes = fuzz_parity.run(n, seed)
+    assert done + skipped == n and done >= n // 2
+    _totals.append(dict(switches=env, seed=seed, drawn=n, bit_exact=done, rejected_geometries=skipped, keypoints=nkp,
+                        descriptor_bytes=nbytes))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(_totals, open(os.path.join(out, "r02_fuzz_parity.json"), "w"), indent=1)
+    except OSError:
+        pass

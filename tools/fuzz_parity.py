@@ -1,21 +1,18 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random image sizes, feature counts, pyramid parameters, thresholds, lapping areas
 and content, every stage and the final arrays compared with the oracle (the same checks as tests/test_gpu_parity.py).
-usage: fuzz_parity.py [n_cases] [seed]"""
+usage: fuzz_parity.py [n_cases] [seed]            (tests/test_gpu_fuzz.py runs a bounded sweep of the same generator under -m gpu)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 import numpy as np
-import extractorb_amd as X
-from extractorb_amd import synth
-from helpers import assert_same_result
-from test_gpu_parity import oracle_run, check_stages
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-done = skipped = 0
-t0 = time.time()
-for t in range(n_cases):
+
+def draw_case(rng, t):
+    """One random geometry + content; pure function of the generator state."""
+    from extractorb_amd import synth
     rows, cols = int(rng.integers(200, 900)), int(rng.integers(200, 1400))
     nf = int(rng.integers(30, 4000))
     nlevels = int(rng.integers(1, 10))
@@ -27,17 +24,41 @@ for t in range(n_cases):
     if rng.random() < 0.3:       # blobs of saturated / flat content
         y, x = int(rng.integers(0, rows - 60)), int(rng.integers(0, cols - 60))
         img = img.copy(); img[y:y + 60, x:x + 60] = int(rng.choice([0, 255, 128]))
-    try:
-        ex = X.ORBextractor(nf, sf, nlevels, ini, mn, max_width=cols, max_height=rows)
-    except X.OrbxError as e:
-        skipped += 1
-        continue
-    o, want = oracle_run(img, nf, lap, nlevels, sf, ini, mn)
-    mono, k, d, lvl = ex(img, None, lap)
-    what = "case %d: %dx%d nf=%d levels=%d sf=%.1f th=%d/%d %s lap=%s" % (t, cols, rows, nf, nlevels, sf, ini, mn, variant, lap)
-    check_stages(ex, o, lvl, nlevels)
-    assert_same_result((mono, k, d), want, what)
-    done += 1
-    if done % 10 == 0:
-        print("%d cases ok (%d rejected geometries), %.0f s" % (done, skipped, time.time() - t0), flush=True)
-print("fuzz parity: %d cases bit-exact, %d geometries rejected by orbx_create, %.0f s" % (done, skipped, time.time() - t0))
+    return dict(rows=rows, cols=cols, nf=nf, nlevels=nlevels, sf=sf, ini=ini, mn=mn, variant=variant, lap=lap, img=img)
+
+
+def run(n_cases, seed, progress=False):
+    """Returns (bit-exact cases, geometries rejected by orbx_create, keypoints compared, descriptor bytes compared)."""
+    import extractorb_amd as X
+    from helpers import assert_same_result
+    from test_gpu_parity import oracle_run, check_stages
+    rng = np.random.default_rng(seed)
+    done = skipped = nkp = 0
+    t0 = time.time()
+    for t in range(n_cases):
+        c = draw_case(rng, t)
+        try:
+            ex = X.ORBextractor(c["nf"], c["sf"], c["nlevels"], c["ini"], c["mn"], max_width=c["cols"], max_height=c["rows"])
+        except X.OrbxError:
+            skipped += 1          # a pyramid level narrower than one FAST cell etc.: the reference has undefined behaviour there
+            continue
+        o, want = oracle_run(c["img"], c["nf"], c["lap"], c["nlevels"], c["sf"], c["ini"], c["mn"])
+        mono, k, d, lvl = ex(c["img"], None, c["lap"])
+        what = "seed %d case %d: %dx%d nf=%d levels=%d sf=%.1f th=%d/%d %s lap=%s" % (
+            seed, t, c["cols"], c["rows"], c["nf"], c["nlevels"], c["sf"], c["ini"], c["mn"], c["variant"], c["lap"])
+        check_stages(ex, o, lvl, c["nlevels"])
+        assert_same_result((mono, k, d), want, what)
+        done += 1
+        nkp += len(k)
+        if progress and done % 10 == 0:
+            print("%d cases ok (%d rejected geometries), %.0f s" % (done, skipped, time.time() - t0), flush=True)
+    return done, skipped, nkp, nkp * 32
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    done, skipped, nkp, nbytes = run(n, seed, progress=True)
+    print("fuzz parity: %d cases bit-exact (%d keypoints, %d descriptor bytes), %d geometries rejected by orbx_create, %.0f s"
+          % (done, skipped, nkp, nbytes, time.time() - t0))

@@ -71,5 +71,76 @@ def main():
         print(case, "n=%d mono=%d" % (len(k), mono), counts.tolist(), ncand.tolist())
 
 
+def from_opencv():
+    """`make_golden.py --from-opencv`: for a maintainer on a machine WITH OpenCV 3.x (this image has none).
+
+    Runs the seven OpenCV primitives the reference calls through the real cv2 on seeded inputs, compares
+    each with the oracle's restatement, prints the first mismatch per primitive, and writes tests/golden/opencv_pins.npz
+    (inputs + cv2's outputs + cv2.__version__).  tests/test_oracle_golden.py::test_oracle_equals_opencv_pins then checks the
+    oracle against that file on every run: this is what turns "parity unpinned" into a pinned oracle.
+
+    Check first, in this order (the three semantics a version change of OpenCV could move):
+      1. 8-bit INTER_LINEAR resize: 11-bit coefficients, (b*(h>>4))>>16 vertical rounding            (A.1, all 3.x/4.x generic paths)
+      2. 7x7 sigma-2 GaussianBlur taps {18,34,49,55,49,34,18} (sum 257): 3.0-3.4.x; builds from 4.1 on renormalise to 256  (A.2)
+      3. undistortPoints: 5 fixed-point iterations in double                                            (3.x; 4.x iterates to a criterion)
+    """
+    import cv2
+    rng = np.random.default_rng(20261004)
+    pins, bad = {"opencv_version": np.array(cv2.__version__)}, []
+    img = rng.integers(0, 256, (333, 517), dtype=np.uint8)
+    smooth = cv2.GaussianBlur(rng.integers(0, 256, (480, 640), dtype=np.uint8), (9, 9), 3)
+    # A.1 resize: the pyramid's own ratios (level l from level l-1, cvRound sizes)
+    for i, (src, (dw, dh)) in enumerate([(img, (431, 278)), (smooth, (533, 400)), (smooth[:400, :533], (444, 333)), (img, (258, 166))]):
+        want = cv2.resize(src, (dw, dh), interpolation=cv2.INTER_LINEAR)
+        pins["resize_src_%d" % i], pins["resize_dst_%d" % i] = src, want
+        if not np.array_equal(O.resize_linear(src, dw, dh), want):
+            bad.append("resize case %d: %d pixels differ" % (i, int((O.resize_linear(src, dw, dh) != want).sum())))
+    # A.2 blur
+    for i, src in enumerate([img, smooth, np.full((64, 80), 255, np.uint8)]):
+        want = cv2.GaussianBlur(src, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+        pins["blur_src_%d" % i], pins["blur_dst_%d" % i] = src, want
+        if not np.array_equal(O.gaussian_blur7(src), want):
+            bad.append("GaussianBlur case %d: %d pixels differ (taps renormalised to 256 in this OpenCV?)" % (i, int((O.gaussian_blur7(src) != want).sum())))
+    # A.3 FAST 9/16 with NMS on cell-sized ROIs and on a whole image, thresholds 20 and 7
+    for i, (src, th) in enumerate([(img[40:77, 100:137], 20), (img[40:77, 100:137], 7), (smooth, 20), (smooth, 7), (img, 20)]):
+        det = cv2.FastFeatureDetector_create(threshold=th, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
+        kps = det.detect(np.ascontiguousarray(src))
+        want = np.array([(k.pt[0], k.pt[1], k.response) for k in kps], np.float32).reshape(-1, 3)
+        got = O.fast(np.ascontiguousarray(src), th, True)
+        g3 = np.stack([got["x"], got["y"], got["response"]], 1).astype(np.float32) if len(got) else np.zeros((0, 3), np.float32)
+        pins["fast_src_%d" % i], pins["fast_th_%d" % i], pins["fast_out_%d" % i] = np.ascontiguousarray(src), np.array(th), want
+        if g3.shape != want.shape or not np.array_equal(g3, want):
+            bad.append("FAST case %d (threshold %d): %d vs %d keypoints or different order/response" % (i, th, len(g3), len(want)))
+    # A.4 border
+    want = cv2.copyMakeBorder(img, 19, 19, 19, 19, cv2.BORDER_REFLECT_101)
+    pins["border_src"], pins["border_dst"] = img, want
+    if not np.array_equal(np.pad(img, 19, mode="reflect"), want):
+        bad.append("copyMakeBorder REFLECT_101 differs from np.pad(reflect)")
+    # A.5 fastAtan2 on integer moments (every |m| < 2.9e6 is exact in float)
+    y = rng.integers(-2900000, 2900000, 100000).astype(np.float32); x = rng.integers(-2900000, 2900000, 100000).astype(np.float32)
+    want = np.array([cv2.fastAtan2(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+    pins["atan_y"], pins["atan_x"], pins["atan_out"] = y, x, want
+    if not np.array_equal(O.fast_atan2(y, x), want):
+        bad.append("fastAtan2: %d of %d angles differ" % (int((O.fast_atan2(y, x) != want).sum()), len(y)))
+    # undistortPoints (Frame::UndistortKeyPoints, src/Frame.cc:748-782) with EuRoC's camera
+    cam = O.camera(458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+    pts = (rng.random((2000, 1, 2)) * np.array([752, 480])).astype(np.float32)
+    K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1]], np.float32)
+    want = cv2.undistortPoints(pts, K, cam[4:8].astype(np.float32), None, K).reshape(-1, 2)
+    kin = np.zeros(len(pts), O.KEYPOINT_DTYPE); kin["x"], kin["y"] = pts[:, 0, 0], pts[:, 0, 1]
+    un, _, _ = O.frame_finish(cam, kin, O.image_bounds(cam, 752, 480))
+    pins["undist_cam"], pins["undist_in"], pins["undist_out"] = cam, pts.reshape(-1, 2), want
+    if not (np.array_equal(un["x"], want[:, 0]) and np.array_equal(un["y"], want[:, 1])):
+        bad.append("undistortPoints: %d of %d points differ (max %.3g px)" % (
+            int(((un["x"] != want[:, 0]) | (un["y"] != want[:, 1])).sum()), len(pts),
+            float(max(np.abs(un["x"] - want[:, 0]).max(), np.abs(un["y"] - want[:, 1]).max()))))
+    np.savez_compressed(os.path.join(OUT, "opencv_pins.npz"), **pins)
+    print("OpenCV %s: wrote %s" % (cv2.__version__, os.path.join(OUT, "opencv_pins.npz")))
+    for b in bad:
+        print("MISMATCH:", b)
+    print("oracle == OpenCV on every primitive" if not bad else "%d primitive(s) differ: see above" % len(bad))
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(from_opencv() if "--from-opencv" in sys.argv[1:] else main())
