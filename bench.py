@@ -43,6 +43,10 @@ WORKLOADS = {
     "mono640_init": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", init_match=True,
                          desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
                               "AssignFeaturesToGrid + SearchForInitialization(frame i, frame i+1)"),
+    # configs[1] + Frame finishing + ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) of consecutive frames (§8f-2, TrackWithMotionModel)
+    "mono640_track": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", track=True,
+                          desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
+                               "AssignFeaturesToGrid + SearchByProjection(frame i+1, frame i, th=15) with every keypoint holding a MapPoint"),
     # the caller's side: BGR frames as Tracking::GrabImageMonocular receives them, cvtColor(BGR2GRAY) on the device, then configs[1]
     "mono640_bgr": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", color=3,
                         desc="640x480 BGR stream: cvtColor(BGR2GRAY) + extraction, 8 levels, 1000 features"),
@@ -141,6 +145,30 @@ def main():
         d_prev = torch.zeros((B - 1, cap, 2), dtype=torch.float32, device="cuda")
         d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda"); d_nm12 = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
 
+    track = bool(wl.get("track"))
+    if track:
+        cam = X.camera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+        bounds = X.compute_image_bounds(cam, cols, rows)
+        d_un = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_goff = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda"); d_gidx = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+        d_nin = torch.zeros(B, dtype=torch.int32, device="cuda")
+        d_mpf = torch.full((B, cap), 3, dtype=torch.uint8, device="cuda")          # every keypoint holds a MapPoint with observations
+        d_world = torch.zeros((B, cap, 3), dtype=torch.float32, device="cuda")     # filled after the priming step (below)
+        Zp = 5.0
+        poses_h = np.zeros((B, 3, 4), np.float32)
+        poses_h[:, 0, 0] = poses_h[:, 1, 1] = poses_h[:, 2, 2] = 1.0
+        poses_h[:, 0, 3] = -np.arange(B, dtype=np.float32) * Zp / 500.0              # frame f looks at the scene shifted by f px
+        d_poses = torch.from_numpy(poses_h).cuda()
+        d_q = torch.zeros((B - 1, cap, 8), dtype=torch.float32, device="cuda")
+        d_mt = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda"); d_nmt = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+
+    def finish_and_track(e_, b):
+        e_.frame_finish_device(B, b + off_k, b + off_n, cap, cam, bounds, d_un, d_goff, d_gidx, d_nin)
+        e_.project_last_frame_device(B - 1, (0, 1), (1, 1), b + off_k, d_un, b + off_n, cap, d_mpf, d_world, d_poses, cam, bounds, 40.0, 0.08,
+                                     15.0, True, d_q)
+        e_.search_by_projection_device(B - 1, (1, 1), d_q, b + off_d, (0, 1), None, cap, d_un, b + off_d, b + off_n, cap, d_goff, d_gidx, bounds,
+                                       None, None, False, 0.9, True, d_mt, d_nmt)
+
     def finish_and_match(e_, b):
         e_.frame_finish_device(B, b + off_k, b + off_n, cap, cam, bounds, d_un, d_goff, d_gidx, d_nin)
         d_prev.copy_(d_un[:B - 1, :, :2])               # Tracking.cc:2029-2031: vbPrevMatched = F1.mvKeysUn[i].pt
@@ -173,6 +201,8 @@ def main():
             e_.stereo_match_device(B // 2, b + off_k, b + off_d, b + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
         if init_match:
             finish_and_match(e_, b)
+        if track:
+            finish_and_track(e_, b)
         if gather:
             if j != 0:
                 stream.wait_stream(streams[j])   # the collective is ordered after torch's CURRENT stream
@@ -193,6 +223,12 @@ def main():
     # builds RCCL's point-to-point channels (seconds at N = 8); --warmup 0 must not put either into the timed region
     step()
     fence()
+    if track:      # MapPoints: every keypoint of frame f back-projected to the plane z = Zp, in world (= frame 0 camera) coordinates
+        un = d_un.view(B, cap, 7)
+        d_world[:, :, 0] = (un[:, :, 0] - 320.0) / 500.0 * Zp + torch.arange(B, device="cuda", dtype=torch.float32)[:, None] * (Zp / 500.0)
+        d_world[:, :, 1] = (un[:, :, 1] - 240.0) / 500.0 * Zp
+        d_world[:, :, 2] = Zp
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -221,6 +257,8 @@ def main():
                 ex.stereo_match_device(B // 2, base + off_k, base + off_d, base + off_n, cap, 40.0, 0.1, d_u, d_z, d_nm)
             if init_match:
                 finish_and_match(ex, base)
+            if track:
+                finish_and_track(ex, base)
         prof = ex.profile_read()
         ex.profile(False)
         kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
@@ -343,6 +381,7 @@ def main():
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
                        **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
+                       **({"mean_projection_matches_per_pair": round(float(d_nmt.float().mean().item()), 1)} if track else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": extras or None,

@@ -47,6 +47,22 @@ struct InitMatchParams {
 size_t initMatchLdsBytes(int capacity);
 void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
                       float*, int*, int*, int);
+struct ProjQuery { float u, v, ur, radius; int minLevel, maxLevel, flags; float angle; };
+struct ProjectParams {
+    float fx, fy, cx, cy, minX, maxX, minY, maxY;
+    float scale[kMaxLevels];
+    float mbf, mb, th;
+    int mono, capacity, lastFirst, lastStep, curFirst, curStep;
+};
+struct ProjSearchParams {
+    float minX, minY, wInv, hInv, nnRatio;
+    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep;
+};
+size_t projSearchLdsBytes(int capacity);
+void launchProjectLast(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const float*, const float*, const ProjectParams&,
+                       ProjQuery*, int);
+void launchSearchProj(hipStream_t, const ProjQuery*, const uint8_t*, const int*, const Keypoint*, const uint8_t*, const int*, const int*,
+                      const int*, const float*, uint8_t*, const ProjSearchParams&, int*, int*, int);
 struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, frame; float factor, mbf; };
 void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
@@ -56,13 +72,14 @@ void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 using namespace orbx;
 
 static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
+static_assert(sizeof(orbx_proj_query) == sizeof(ProjQuery), "orbx_proj_query layout");
 
 namespace {
 constexpr float kPrefilterDensity = 0.02f;   // candidates per pixel below which the prefilter variant of k_fast is faster
 enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_FRAME };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
-                                            "k_stereo_rows+match+filter", "k_frame_finish+k_search_init"};
+                                            "k_stereo_rows+match+filter", "k_frame_finish+k_search_init+k_search_proj"};
 thread_local std::string g_createError;
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -1014,6 +1031,60 @@ int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame
         Prof pr(h, S_FRAME);
         launchSearchInit(h->stream, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off, d_grid_idx, p, d_prev_matched, d_matches12,
                          d_n_matches, n_pairs);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_project_last_frame_device(orbx_handle* h, int n_pairs, int last_first, int last_step, int cur_first, int cur_step,
+                                   const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un, const int* d_n_out, int capacity,
+                                   const uint8_t* d_mp_flags, const float* d_world, const float* d_poses, const orbx_camera* cam,
+                                   const float* bounds4, float mbf, float mb, float th, int mono, orbx_proj_query* d_queries) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_kps || !d_kps_un || !d_n_out || !d_mp_flags || !d_world || !d_poses || !cam || !bounds4 || !d_queries || capacity < 1 || n_pairs < 1 ||
+        n_pairs > 65535 || last_first < 0 || cur_first < 0 || last_step < 0 || cur_step < 0 || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1, more than 65535 pairs, negative frame index/step or empty bounds");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ProjectParams p;
+    p.fx = cam->fx; p.fy = cam->fy; p.cx = cam->cx; p.cy = cam->cy;
+    p.minX = bounds4[0]; p.maxX = bounds4[1]; p.minY = bounds4[2]; p.maxY = bounds4[3];
+    for (int l = 0; l < kMaxLevels; l++) p.scale[l] = l < h->nlevels ? h->tabs.scale[l] : h->tabs.scale[h->nlevels - 1];   // CurrentFrame.mvScaleFactors
+    p.mbf = mbf; p.mb = mb; p.th = th; p.mono = mono != 0; p.capacity = capacity;
+    p.lastFirst = last_first; p.lastStep = last_step; p.curFirst = cur_first; p.curStep = cur_step;
+    {
+        Prof pr(h, S_FRAME);
+        launchProjectLast(h->stream, (const Keypoint*)d_kps, (const Keypoint*)d_kps_un, d_n_out, d_mp_flags, d_world, d_poses, p, (ProjQuery*)d_queries, n_pairs);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first, int cur_step, const orbx_proj_query* d_queries,
+                                     const uint8_t* d_query_desc, int desc_first, int desc_step, const int* d_n_queries, int query_capacity,
+                                     const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int* d_n_out, int capacity,
+                                     const int* d_grid_off, const int* d_grid_idx, const float* bounds4, const float* d_u_right,
+                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int check_orientation, int* d_matches,
+                                     int* d_n_matches) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!d_queries || !d_query_desc || !d_kps_un || !d_desc || !d_n_out || !d_grid_off || !d_grid_idx || !bounds4 || !d_matches || !d_n_matches ||
+        capacity < 1 || query_capacity < 1 || n_pairs < 1 || cur_first < 0 || cur_step < 0 || desc_first < 0 || desc_step < 0 ||
+        !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/query_capacity/n_pairs < 1, negative frame index/step or empty bounds");
+    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
+    if (projSearchLdsBytes(capacity) > 160 * 1024 - 512)
+        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (64 bytes per keypoint, 160 KB per CU)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ProjSearchParams p;
+    p.minX = bounds4[0]; p.minY = bounds4[2];
+    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
+    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
+    p.nnRatio = nn_ratio; p.ratioMode = ratio_mode != 0; p.checkOrientation = check_orientation != 0;
+    p.capacity = capacity; p.queryCapacity = query_capacity; p.curFirst = cur_first; p.curStep = cur_step;
+    p.descFirst = desc_first; p.descStep = desc_step;
+    {
+        Prof pr(h, S_FRAME);
+        launchSearchProj(h->stream, (const ProjQuery*)d_queries, d_query_desc, d_n_queries, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off,
+                         d_grid_idx, d_u_right, d_occupied, p, d_matches, d_n_matches, n_pairs);
     }
     HIP_TRY(h, hipGetLastError());
     return ORBX_OK;

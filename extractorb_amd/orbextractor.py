@@ -107,6 +107,10 @@ def load_library():
                                             C.c_int, vp, vp, vp, vp]
     L.orbx_get_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, ip, ip]
     L.orbx_stereo_match_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+    L.orbx_project_last_frame_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp,
+                                                 C.c_float, C.c_float, C.c_float, C.c_int, vp]
+    L.orbx_search_by_projection_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int,
+                                                   vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -377,6 +381,29 @@ class ORBextractor:
             self._h, n_pairs, frames1[0], frames1[1], frames2[0], frames2[1], dp(d_kps_un), dp(d_desc), dp(d_n), capacity,
             dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_prev_matched), window, nnratio, int(check_orientation),
             dp(d_matches12), dp(d_n_matches)))
+
+    def project_last_frame_device(self, n_pairs, last, cur, d_kps, d_kps_un, d_n, capacity, d_mp_flags, d_world, d_poses, cam, bounds,
+                                  mbf, mb, th, mono, d_queries):
+        """Front half of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference src/ORBmatcher.cc:1961-2023);
+        last / cur = (first, step) of the last / current frame index of pair p."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        cam = np.ascontiguousarray(cam, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
+        self._check(self._L.orbx_project_last_frame_device(self._h, n_pairs, last[0], last[1], cur[0], cur[1], dp(d_kps), dp(d_kps_un), dp(d_n),
+                                                           capacity, dp(d_mp_flags), dp(d_world), dp(d_poses), _ptr(cam), _ptr(bounds),
+                                                           mbf, mb, th, int(mono), dp(d_queries)))
+
+    def search_by_projection_device(self, n_pairs, cur, d_queries, d_query_desc, desc_blocks, d_n_queries, query_capacity, d_kps_un, d_desc,
+                                    d_n, capacity, d_grid_off, d_grid_idx, bounds, d_u_right, d_occupied, ratio_mode, nnratio,
+                                    check_orientation, d_matches, d_n_matches):
+        """ORBmatcher::SearchByProjection, the search (reference src/ORBmatcher.cc:2025-2175 / :44-135); cur and desc_blocks = (first, step)."""
+        def dp(x):
+            return C.c_void_p(0 if x is None else (x.data_ptr() if hasattr(x, "data_ptr") else int(x)))
+        bounds = np.ascontiguousarray(bounds, np.float32)
+        self._check(self._L.orbx_search_by_projection_device(
+            self._h, n_pairs, cur[0], cur[1], dp(d_queries), dp(d_query_desc), desc_blocks[0], desc_blocks[1], dp(d_n_queries), query_capacity,
+            dp(d_kps_un), dp(d_desc), dp(d_n), capacity, dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_u_right), dp(d_occupied),
+            int(ratio_mode), nnratio, int(check_orientation), dp(d_matches), dp(d_n_matches)))
 
     def stereo_from_rgbd_device(self, n_frames, d_kps, d_kps_un, d_n, capacity, d_depth, depth_is_u16, rows, cols, depth_map_factor, mbf,
                                 d_u_right, d_depth_out, depth_stride_bytes=None, depth_frame_stride_bytes=None):

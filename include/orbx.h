@@ -220,6 +220,53 @@ int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame
                                           const float* bounds4, float* d_prev_matched, int window_size, float nn_ratio,
                                           int check_orientation, int* d_matches12, int* d_n_matches);
 
+/* ---- next row (second half): ORBmatcher::SearchByProjection ---------------------------------------
+ * For Nleft == -1 frames (monocular, rectified stereo, RGB-D).  MapPoints, poses and frustum tests belong to the tracker and
+ * the map (out of scope), so they enter as plain arrays.  One search request per MapPoint: */
+typedef struct orbx_proj_query {
+    float u, v;          /* projected position in the current frame: uv (ORBmatcher.cc:2003) / MapPoint::mTrackProjX, mTrackProjY (:58) */
+    float ur;            /* predicted right-eye column: uv.x - mbf*invzc (:2043) / mTrackProjXR (:70); used only where mvuRight > 0 */
+    float radius;        /* window half-size: th*mvScaleFactors[octave] (:2014) / RadiusByViewingCos(cos)[*th]*mvScaleFactors[level] (:52-58) */
+    int32_t min_level, max_level;   /* GetFeaturesInArea's level range: (oct-1, oct+1) | (oct, -1) | (0, oct) (:2018-2023) / (level-1, level) (:58) */
+    int32_t flags;       /* bit 0: search this request; bit 1: its MapPoint has Observations() > 0 (it then closes the keypoint it takes) */
+    float angle;         /* LastFrame.mvKeysUn[i].angle for the rotation histogram (:2067); unused in ratio mode */
+} orbx_proj_query;
+
+/* Front half of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1961-2023, 2043): for pair p the
+ * keypoints of frame last_first + p*last_step that hold a MapPoint are projected into frame cur_first + p*cur_step.
+ *   d_kps / d_kps_un    : mvKeys (octave) / mvKeysUn (angle) of all frames          d_n_out : N of all frames
+ *   d_mp_flags[f*capacity + i] : bit 0 = LastFrame.mvpMapPoints[i] != NULL && !mvbOutlier[i], bit 1 = Observations() > 0
+ *   d_world[(f*capacity + i)*3]: MapPoint::GetWorldPos()
+ *   d_poses[f*12]       : Frame::mTcw, rows 0..2 (3x4, row-major) of every frame
+ *   cam (fx, fy, cx, cy): Pinhole::project;  bounds4: mnMinX, mnMaxX, mnMinY, mnMaxY;  mbf, mb: Frame::mbf, mb;  th, mono as passed
+ *   d_queries[p*capacity + i]  : out, one request per keypoint of the last frame (flags = 0 where the reference `continue`s)
+ * Asynchronous on the handle's stream. */
+int orbx_project_last_frame_device(orbx_handle* h, int n_pairs, int last_first, int last_step, int cur_first, int cur_step,
+                                   const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un, const int* d_n_out, int capacity,
+                                   const uint8_t* d_mp_flags, const float* d_world, const float* d_poses, const orbx_camera* cam,
+                                   const float* bounds4, float mbf, float mb, float th, int mono, orbx_proj_query* d_queries);
+
+/* The search itself, for n_pairs frames cur_first + p*cur_step of one device-resident batch.
+ *   ratio_mode 0: SearchByProjection(CurrentFrame, LastFrame, ...) (src/ORBmatcher.cc:2025-2175): best candidate, TH_HIGH = 100, rotation
+ *                 histogram when check_orientation;
+ *   ratio_mode 1: SearchByProjection(F, vpMapPoints, th, ...) (src/ORBmatcher.cc:44-135): best and second best, the ratio nn_ratio applies
+ *                 only when both lie on the same pyramid level; the caller passes only MapPoints with mbTrackInView that are not bad and
+ *                 pass the far-point test (:50-59), in vpMapPoints order.
+ *   d_queries[p*query_capacity + i], d_n_queries[p] (NULL: query_capacity requests per frame, unused ones have flags = 0)
+ *   d_query_desc[((desc_first + p*desc_step)*query_capacity + i)*32] : MapPoint::GetDescriptor() of request i (desc_first / desc_step index
+ *                 blocks of query_capacity descriptors: for frame-to-frame matching the last frames' blocks of a per-frame array)
+ *   d_kps_un, d_desc, d_n_out, d_grid_off, d_grid_idx : mvKeysUn, mDescriptors, N, mGrid of all frames (orbx_frame_finish_device)
+ *   d_u_right[f*capacity + i] : mvuRight of all frames, or NULL (monocular)
+ *   d_occupied[p*capacity + i] : in/out or NULL (= all free): the keypoint already holds a MapPoint with Observations() > 0
+ *   d_matches[p*capacity + i]  : out, request whose MapPoint the keypoint holds afterwards, -1 = none;  d_n_matches[p] : the return value
+ * Asynchronous on the handle's stream. */
+int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first, int cur_step, const orbx_proj_query* d_queries,
+                                     const uint8_t* d_query_desc, int desc_first, int desc_step, const int* d_n_queries, int query_capacity,
+                                     const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int* d_n_out, int capacity,
+                                     const int* d_grid_off, const int* d_grid_idx, const float* bounds4, const float* d_u_right,
+                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int check_orientation, int* d_matches,
+                                     int* d_n_matches);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

@@ -1063,6 +1063,125 @@ int oracle_features_in_area(const void* kpsUn, const int* gridOff, const int* gr
     return (int)v.size();
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Next" row (second half): ORBmatcher::SearchByProjection.
+//   (a) frame-to-frame, Tracking::TrackWithMotionModel: src/ORBmatcher.cc:1961-2177
+//   (b) map-to-frame,   Tracking::SearchLocalPoints:     src/ORBmatcher.cc:44-267
+// Both for Nleft == -1 (monocular, rectified stereo, RGB-D: one descriptor set per frame); the Nleft != -1 branches belong to the
+// fisheye-stereo rig (KannalaBrandt8), whose camera model is out of scope.  MapPoints, poses and frustum
+// results come from the tracker and the map (out of scope), so they enter as plain arrays.
+// cv::Mat arithmetic restated: `Rcw*x3Dw+tcw` is ONE cv::gemm (MatExpr folds A*B+C): every element accumulates its three products
+// in double, adds the double of tcw, and rounds to float once (OpenCV 3.x GEMMSingleMul<float,double>).  OpenCV is absent from this
+// image, so this too is "parity unpinned" (DESIGN.md §2).
+// ---------------------------------------------------------------------------------------------
+static void gemm3(const float* A /*3x3 row-major, row stride sa*/, int sa, bool transA, const float* b, double alpha, const float* c, float* out) {
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)(transA ? A[k * sa + r] : A[r * sa + k]) * (double)b[k];
+        out[r] = (float)(s * alpha + (c ? (double)c[r] : 0.0));
+    }
+}
+
+struct ProjQuery { float u, v, ur, radius; int minLevel, maxLevel, flags; float angle; };   // == orbx_proj_query (32 bytes)
+
+// The per-keypoint front half of (a): :1989-2016 (+ the stereo prediction of :2043).  flags bit0 = search this one, bit1 = its
+// MapPoint has Observations() > 0 (a later candidate check, :2035-2037, skips keypoints such a point already holds).
+// mpFlags: bit0 = LastFrame.mvpMapPoints[i] != NULL && !LastFrame.mvbOutlier[i], bit1 = Observations() > 0.
+void oracle_project_last_frame(const void* kpsLast_, const void* kpsUnLast_, int NL, const uint8_t* mpFlags, const float* world,
+                               const float* Tcw /*3x4*/, const float* Tlw /*3x4*/, const float* cam4 /*fx fy cx cy*/, const float* bounds,
+                               const float* scaleFactors, float mbf, float mb, float th, int bMono, void* queries_) {
+    const KeyPoint* kL = (const KeyPoint*)kpsLast_;
+    const KeyPoint* kUnL = (const KeyPoint*)kpsUnLast_;
+    ProjQuery* q = (ProjQuery*)queries_;
+    const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]}, tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+    float twc[3], tlc[3];
+    gemm3(Tcw, 4, true, tcw, -1.0, nullptr, twc);            // twc = -Rcw.t()*tcw   (:1975)
+    gemm3(Tlw, 4, false, twc, 1.0, tlw, tlc);                // tlc = Rlw*twc+tlw    (:1980)
+    const bool bForward = tlc[2] > mb && !bMono;             // :1982-1983
+    const bool bBackward = -tlc[2] > mb && !bMono;
+    for (int i = 0; i < NL; i++) {
+        q[i] = ProjQuery{0, 0, 0, 0, 0, 0, 0, 0};
+        if (!(mpFlags[i] & 1)) continue;                     // :1987-1990
+        float x3Dc[3];
+        gemm3(Tcw, 4, false, world + 3 * i, 1.0, tcw, x3Dc); // :1994
+        const float invzc = (float)(1.0 / x3Dc[2]);          // :1998 (double division, float variable)
+        if (invzc < 0) continue;
+        const float u = cam4[0] * x3Dc[0] / x3Dc[2] + cam4[2], v = cam4[1] * x3Dc[1] / x3Dc[2] + cam4[3];   // Pinhole::project (CameraModels/Pinhole.cpp)
+        if (u < bounds[0] || u > bounds[1]) continue;        // :2005-2008
+        if (v < bounds[2] || v > bounds[3]) continue;
+        const int nLastOctave = kL[i].octave;                // :2010
+        q[i].u = u; q[i].v = v;
+        q[i].radius = th * scaleFactors[nLastOctave];        // :2014
+        q[i].ur = u - mbf * invzc;                           // :2043
+        if (bForward) { q[i].minLevel = nLastOctave; q[i].maxLevel = -1; }               // :2018-2023
+        else if (bBackward) { q[i].minLevel = 0; q[i].maxLevel = nLastOctave; }
+        else { q[i].minLevel = nLastOctave - 1; q[i].maxLevel = nLastOctave + 1; }
+        q[i].angle = kUnL[i].angle;                          // kpLF = LastFrame.mvKeysUn[i] (:2067)
+        q[i].flags = 1 | (mpFlags[i] & 2);
+    }
+}
+
+// The search half, shared by (a) and (b).  ratioMode 0 = (a): best candidate only, TH_HIGH (:2028-2062), rotation histogram
+// (:2064-2080, :2155-2175).  ratioMode 1 = (b): best + second with the level rule and mfNNratio (:85-132), no histogram.
+// occupied[i2] (in/out, may be NULL = all free): CurrentFrame.mvpMapPoints[i2] is set and has Observations() > 0.
+// matches[i2] (out): index of the query whose MapPoint the keypoint ends up holding, -1 = none.  Returns nmatches.
+int oracle_search_by_projection(const void* queries_, const uint8_t* qdesc, int NQ, const void* kpsUn_, const uint8_t* desc, int N,
+                                const int* gridOff, const int* gridIdx, const float* bounds, const float* uRight, uint8_t* occupied,
+                                int ratioMode, float nnratio, int checkOrientation, int* matches) {
+    const ProjQuery* q = (const ProjQuery*)queries_;
+    const KeyPoint* kUn = (const KeyPoint*)kpsUn_;
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    std::vector<uint8_t> occ(N, 0);
+    if (occupied) occ.assign(occupied, occupied + N);
+    int nmatches = 0;
+    for (int i = 0; i < N; i++) matches[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < NQ; i++) {
+        if (!(q[i].flags & 1)) continue;
+        const float radius = q[i].radius;
+        const std::vector<size_t> vIndices = getFeaturesInArea(kUn, gridOff, gridIdx, bounds, q[i].u, q[i].v, radius, q[i].minLevel, q[i].maxLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = qdesc + (size_t)i * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (occ[idx]) continue;                                              // :64-66 / :2035-2037
+            if (uRight && uRight[idx] > 0) {                                     // :68-73 / :2039-2046
+                const float er = std::fabs(q[i].ur - uRight[idx]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptorDistance(dMP, desc + idx * 32);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kUn[idx].octave; bestIdx = (int)idx; }
+            else if (ratioMode && dist < bestDist2) { bestLevel2 = kUn[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (ratioMode && bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;          // :102-104
+            matches[bestIdx] = i;                                                // F.mvpMapPoints[bestIdx] = pMP
+            if (q[i].flags & 2) occ[bestIdx] = 1;                                // the point now sitting there has observations
+            else occ[bestIdx] = 0;                                               // ... or has none (a temporal stereo point): later queries may take the keypoint over
+            nmatches++;
+            if (!ratioMode && checkOrientation) {
+                float rot = q[i].angle - kUn[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    if (!ratioMode && checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx : rotHist[i]) { matches[idx] = -1; occ[idx] = 0; nmatches--; }   // :2166-2170: mvpMapPoints[idx] = NULL (no check that it
+                                                                                        // is still set: the count may be decremented twice)
+        }
+    }
+    if (occupied) std::copy(occ.begin(), occ.end(), occupied);
+    return nmatches;
+}
+
 // cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8-bit images as Tracking::GrabImage* calls it
 // (src/Tracking.cc:915-941, 985-1001).  OpenCV 3.4 generic path: 14-bit fixed point with R2Y = 4899, G2Y = 9617,
 // B2Y = 1868 and CV_DESCALE's rounding; alpha ignored.

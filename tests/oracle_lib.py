@@ -75,6 +75,10 @@ def lib():
         L.oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
         L.oracle_features_in_area.restype = C.c_int
         L.oracle_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
+        L.oracle_project_last_frame.restype = None
+        L.oracle_project_last_frame.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, vp]
+        L.oracle_search_by_projection.restype = C.c_int
+        L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
         L.oracle_stereo_from_rgbd.restype = None
         L.oracle_stereo_from_rgbd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_float, vp, vp]
         L.oracle_gray_from_color.restype = None
@@ -217,6 +221,41 @@ def search_for_initialization(kps_un1, desc1, kps_un2, desc2, grid_off2, grid_id
                                                _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(prev), window, nnratio,
                                                int(check_orientation), _ptr(m12))
     return n, m12[:len(k1)].copy(), prev
+
+
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("flags", "<i4"), ("angle", "<f4")])
+assert PROJ_QUERY_DTYPE.itemsize == 32
+
+
+def project_last_frame(kps_last, kps_un_last, mp_flags, world, Tcw, Tlw, cam, bounds, scale_factors, mbf, mb, th, mono):
+    """Front half of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference src/ORBmatcher.cc:1961-2023):
+    one search request per keypoint of the last frame.  Tcw / Tlw: 3x4 poses of the current / last frame."""
+    kl = np.ascontiguousarray(kps_last, KEYPOINT_DTYPE); ku = np.ascontiguousarray(kps_un_last, KEYPOINT_DTYPE)
+    q = np.zeros(max(len(kl), 1), PROJ_QUERY_DTYPE)
+    cam4 = np.ascontiguousarray(np.asarray(cam, np.float32)[:4])
+    lib().oracle_project_last_frame(_ptr(kl), _ptr(ku), len(kl), _ptr(np.ascontiguousarray(mp_flags, np.uint8)),
+                                    _ptr(np.ascontiguousarray(world, np.float32)), _ptr(np.ascontiguousarray(Tcw, np.float32)),
+                                    _ptr(np.ascontiguousarray(Tlw, np.float32)), _ptr(cam4), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                    _ptr(np.ascontiguousarray(scale_factors, np.float32)), mbf, mb, th, int(mono), _ptr(q))
+    return q[:len(kl)].copy()
+
+
+def search_by_projection(queries, qdesc, kps_un, desc, grid_off, grid_idx, bounds, u_right=None, occupied=None, ratio_mode=False,
+                         nnratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchByProjection, the search half (reference src/ORBmatcher.cc:2025-2175 with ratio_mode False, :60-135 with True).
+    Returns (nmatches, matches[N] = request index per keypoint or -1, occupied[N] afterwards)."""
+    q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); ku = np.ascontiguousarray(kps_un, KEYPOINT_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8); d = np.ascontiguousarray(desc, np.uint8)
+    N = len(ku)
+    m = np.zeros(max(N, 1), np.int32)
+    occ = np.zeros(max(N, 1), np.uint8) if occupied is None else np.ascontiguousarray(occupied, np.uint8).copy()
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    gi = np.ascontiguousarray(grid_idx, np.int32) if len(grid_idx) else np.zeros(1, np.int32)
+    n = lib().oracle_search_by_projection(_ptr(q), _ptr(qd), len(q), _ptr(ku), _ptr(d), N, _ptr(np.ascontiguousarray(grid_off, np.int32)), _ptr(gi),
+                                          _ptr(np.ascontiguousarray(bounds, np.float32)), None if ur is None else _ptr(ur), _ptr(occ),
+                                          int(ratio_mode), nnratio, int(check_orientation), _ptr(m))
+    return n, m[:N].copy(), occ[:N].copy()
 
 
 def stereo_from_rgbd(kps, kps_un, depth, factor, mbf):
