@@ -17,7 +17,8 @@
 
 namespace orbx {
 
-constexpr int kBlurRows = kBlurBlockRows;   // output rows per lane
+// output rows per lane: kBlurBlockRows (32) for throughput, kBlurBlockRowsSmall for small batches, where the grid cannot fill the
+// chip anyway and a lane's chain of dependent row loads (ROWS + 6 of them) is the kernel's duration
 
 __device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
     // lo = pixels x-3..x, hi = pixels x+1..x+4 (the last one weighted 0)
@@ -27,6 +28,7 @@ __device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
 
 // items: one per (level, row block); lanes of the whole grid.x enumerate (item, column group) pairs; laneItem[lane]
 // names the lane's item (a per-thread binary search would start every workgroup with eight dependent loads).
+template <int kBlurRows>
 __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items, const unsigned short* __restrict__ laneItem,
                                                int nLanes, const LevelGeom* __restrict__ lv,
                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int f0, int nFrames) {
@@ -78,9 +80,12 @@ __global__ __launch_bounds__(256) void k_blur(const BlurItem* __restrict__ items
     }
 }
 
-void launchBlur(hipStream_t st, const BlurItem* items, const unsigned short* laneItem, int nLanes, const LevelGeom* lv,
+void launchBlur(hipStream_t st, const BlurItem* items, const unsigned short* laneItem, int nLanes, int blockRows, const LevelGeom* lv,
                 const uint8_t* pyr, uint8_t* blur, int f0, int B) {
-    hipLaunchKernelGGL(k_blur, xcdGrid((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur, f0, B);
+    if (blockRows == kBlurBlockRows)
+        hipLaunchKernelGGL(k_blur<kBlurBlockRows>, xcdGrid((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur, f0, B);
+    else
+        hipLaunchKernelGGL(k_blur<kBlurBlockRowsSmall>, xcdGrid((nLanes + 255) / 256, B), dim3(256), 0, st, items, laneItem, nLanes, lv, pyr, blur, f0, B);
 }
 
 }  // namespace orbx

@@ -20,7 +20,7 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
-void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
+void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
@@ -112,10 +112,11 @@ struct orbx_handle {
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
-    BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel
-    unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid
+    BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
+    unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
     size_t laneCap = 0;
-    int nBlurLanes = 0;
+    int nBlurLanes[2] = {0, 0};
+    size_t blurItemOff[2] = {0, 0}, blurLaneOff[2] = {0, 0};
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
     uint8_t* d_octArena = nullptr;
@@ -235,21 +236,27 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
         fo += g.foot[l].size();
     }
-    std::vector<BlurItem> tiles;
-    std::vector<unsigned short> laneItem;
-    int lanes = 0;
-    for (int l = 0; l < g.nlevels; l++)
-        for (int y0 = 0; y0 < g.lv[l].h; y0 += kBlurBlockRows) {
-            laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)tiles.size());
-            tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
-            lanes += (g.lv[l].w + 3) / 4;
+    {   // blur tables for both row-block sizes
+        std::vector<BlurItem> tiles;
+        std::vector<unsigned short> laneItem;
+        const int blockRows[2] = {kBlurBlockRows, kBlurBlockRowsSmall};
+        for (int v = 0; v < 2; v++) {
+            const size_t t0 = tiles.size(), l0 = laneItem.size();
+            int lanes = 0;
+            for (int l = 0; l < g.nlevels; l++)
+                for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
+                    laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)(tiles.size() - t0));
+                    tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
+                    lanes += (g.lv[l].w + 3) / 4;
+                }
+            tiles[t0].count = (int)(tiles.size() - t0);
+            if (tiles.size() - t0 > 65535) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
+            h->nBlurLanes[v] = lanes; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0;
         }
-    tiles[0].count = (int)tiles.size();
-    if (tiles.size() > h->tileCap || tiles.size() > 65535 || laneItem.size() > h->laneCap)
-        return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
-    HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size(), hipMemcpyHostToDevice));
-    h->nBlurLanes = lanes;
+        if (tiles.size() > h->tileCap || laneItem.size() > h->laneCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
+        HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size(), hipMemcpyHostToDevice));
+    }
     {
         const long long px = (long long)g.lv[0].w * g.lv[0].h;
         int T = px <= 500000 ? 256 : (px <= 1200000 ? 512 : 1024);   // measured: 640x480 -> 256, 1280x720 -> 512, 1920x1080 -> 1024 (512 equal)
@@ -333,7 +340,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                          g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
         }
-        { Prof p(h, S_BLUR, st); launchBlur(st, h->d_tiles, h->d_laneItem, h->nBlurLanes, h->d_lv, h->d_pyr, h->d_blur, f0, Bn); }
+        {   // throughput form (32-row blocks) once the grid fills the chip several times over, else the short-chain form
+            Prof p(h, S_BLUR, st);
+            const int v = (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1;      // two waves per SIMD of 32-row lanes
+            launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v ? kBlurBlockRowsSmall : kBlurBlockRows,
+                       h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+        }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) {
         {
@@ -498,8 +510,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->selEntries = (size_t)(mg.selPerFrame + 8 * nlevels) * max_batch;
     h->cellCap = roomy(mg.cells.size());
     h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
-    h->tileCap = roomy((size_t)((max_width + 63) / 64 + 1) * ((max_height + 31) / 32 + 1) * nlevels);
-    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * ((max_height + 31) / 32 + 1) * nlevels);
+    h->tileCap = roomy((size_t)((max_height + 31) / 32 + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 2) * nlevels);
+    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * ((max_height + 31) / 32 + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 2) * nlevels);
     // quad-tree LDS: M nodes (multiple of 8), P = next power of two for the bitonic sort
     int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
     M = (M + 7) / 8 * 8;

@@ -58,6 +58,10 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
 static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
 
 constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (plus a 6-row halo)
+#ifndef ORBX_BLUR_SMALL_ROWS
+#define ORBX_BLUR_SMALL_ROWS 8
+#endif
+constexpr int kBlurBlockRowsSmall = ORBX_BLUR_SMALL_ROWS;   // ... in small batches (latency, not throughput)
 constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
 
 // Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
