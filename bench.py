@@ -47,6 +47,9 @@ WORKLOADS = {
     "mono640_track": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", track=True,
                           desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + UndistortKeyPoints/"
                                "AssignFeaturesToGrid + SearchByProjection(frame i+1, frame i, th=15) with every keypoint holding a MapPoint"),
+    # configs[1] + Frame::ComputeBoW (§8f-4) with a synthetic vocabulary of ORBvoc.txt's shape (k = 10, L = 6: 1 111 111 nodes, 10^6 words)
+    "mono640_bow": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", bow=True,
+                        desc="640x480 mono stream, 8 levels, 1000 features: extraction + ComputeBoW (synthetic 10^6-word vocabulary, levelsup 4)"),
     # the caller's side: BGR frames as Tracking::GrabImageMonocular receives them, cvtColor(BGR2GRAY) on the device, then configs[1]
     "mono640_bgr": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", color=3,
                         desc="640x480 BGR stream: cvtColor(BGR2GRAY) + extraction, 8 levels, 1000 features"),
@@ -145,6 +148,24 @@ def main():
         d_prev = torch.zeros((B - 1, cap, 2), dtype=torch.float32, device="cuda")
         d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda"); d_nm12 = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
 
+    bow = bool(wl.get("bow"))
+    if bow:
+        # a random full tree in loader order (level by level): node n's children are 10*n + 1 .. 10*n + 10
+        nn = (10 ** 7 - 1) // 9
+        vrng = np.random.default_rng(7)
+        par = np.maximum((np.arange(nn, dtype=np.int64) - 1) // 10, 0).astype(np.int32)
+        leaf = (np.arange(nn) >= (10 ** 6 - 1) // 9).astype(np.uint8)
+        voc = X.Vocabulary(arrays=dict(k=10, L=6, scoring=0, weighting=0, parent=par, is_leaf=leaf,
+                                       desc=vrng.integers(0, 256, (nn, 32), dtype=np.uint8), weight=np.where(leaf > 0, vrng.uniform(0.5, 9.0, nn), 0.0)),
+                           device=local_rank)
+        d_wid = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_ww = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
+        d_nw = torch.zeros(B, dtype=torch.int32, device="cuda")
+        d_fn = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_fi = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+        d_nfv = torch.zeros(B, dtype=torch.int32, device="cuda")
+
+    def compute_bow(e_, b):
+        e_.compute_bow_device(voc, B, b + off_d, b + off_n, cap, d_wid, d_ww, d_nw, d_fn, d_fi, d_nfv, levels_up=4)
+
     track = bool(wl.get("track"))
     if track:
         cam = X.camera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
@@ -203,6 +224,8 @@ def main():
             finish_and_match(e_, b)
         if track:
             finish_and_track(e_, b)
+        if bow:
+            compute_bow(e_, b)
         if gather:
             if j != 0:
                 stream.wait_stream(streams[j])   # the collective is ordered after torch's CURRENT stream
@@ -259,6 +282,8 @@ def main():
                 finish_and_match(ex, base)
             if track:
                 finish_and_track(ex, base)
+            if bow:
+                compute_bow(ex, base)
         prof = ex.profile_read()
         ex.profile(False)
         kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
@@ -382,6 +407,7 @@ def main():
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
                        **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
                        **({"mean_projection_matches_per_pair": round(float(d_nmt.float().mean().item()), 1)} if track else {}),
+                       **({"mean_words_per_frame": round(float(d_nw.float().mean().item()), 1)} if bow else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": extras or None,

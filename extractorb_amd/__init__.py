@@ -9,8 +9,8 @@ extractor without the built library or without a HIP device raises.
 """
 from .orbextractor import (KEYPOINT_DTYPE, ORBextractor, OrbxError, build_library, library_path, load_library,
                            compute_tables, compute_level_sizes, compute_cell_grid, header_symbols, camera,
-                           compute_image_bounds, pinned_empty, pinned_free, source_hash)
+                           compute_image_bounds, pinned_empty, pinned_free, source_hash, Vocabulary)
 
 __all__ = ["KEYPOINT_DTYPE", "ORBextractor", "OrbxError", "build_library", "library_path", "load_library",
-           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols", "camera", "compute_image_bounds", "pinned_empty", "pinned_free", "source_hash"]
+           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols", "camera", "compute_image_bounds", "pinned_empty", "pinned_free", "source_hash", "Vocabulary"]
 __version__ = "0.1.0"

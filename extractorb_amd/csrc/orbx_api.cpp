@@ -63,6 +63,12 @@ void launchProjectLast(hipStream_t, const Keypoint*, const Keypoint*, const int*
                        ProjQuery*, int);
 void launchSearchProj(hipStream_t, const ProjQuery*, const uint8_t*, const int*, const Keypoint*, const uint8_t*, const int*, const int*,
                       const int*, const float*, uint8_t*, const ProjSearchParams&, int*, int*, int);
+struct VocabDevice {
+    const int* childOff; const int* childList; const uint32_t* desc; const double* weight; const uint32_t* wordId;
+    int nNodes, k, L, scoring, weighting;
+};
+void launchBow(hipStream_t, const VocabDevice&, const uint8_t*, const int*, int, int, uint32_t*, double*, uint32_t*, uint32_t*, double*, int*,
+               uint32_t*, uint32_t*, int*, int);
 struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, frame; float factor, mbf; };
 void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
@@ -156,6 +162,10 @@ struct orbx_handle {
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
     int statB = 0;
+    // ComputeBoW scratch (allocated on first use): per-feature word id / weight / node
+    size_t bowEntries = 0;
+    uint32_t *d_bowWord = nullptr, *d_bowNode = nullptr;
+    double* d_bowWeight = nullptr;
     // stereo matching (allocated on first use)
     int stereoPairs = 0, stereoCap = 0, stereoRows = 0;
     int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
@@ -189,7 +199,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
-                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_rowOff, h->d_sadDist,
+                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->statEvent) (void)hipEventDestroy(h->statEvent);
@@ -1097,6 +1107,136 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
         Prof pr(h, S_FRAME);
         launchSearchProj(h->stream, (const ProjQuery*)d_queries, d_query_desc, d_n_queries, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off,
                          d_grid_idx, d_u_right, d_occupied, p, d_matches, d_n_matches, n_pairs);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+
+}  // extern "C"
+
+struct orbx_vocabulary {
+    int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, nNodes = 0, nWords = 0;
+    int *d_childOff = nullptr, *d_childList = nullptr;
+    uint32_t *d_desc = nullptr, *d_wordId = nullptr;
+    double* d_weight = nullptr;
+};
+
+extern "C" {
+
+void orbx_vocabulary_destroy(orbx_vocabulary* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    void* dev[] = {v->d_childOff, v->d_childList, v->d_desc, v->d_wordId, v->d_weight};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    delete v;
+}
+
+int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int weighting, int n_nodes, const int* parent,
+                           const uint8_t* is_leaf, const uint8_t* desc, const double* weight, int device) {
+    if (!out) return ORBX_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3 ||      // TemplatedVocabulary.h:1359
+        n_nodes < 2 || !parent || !is_leaf || !desc || !weight) {
+        g_createError = "orbx_vocabulary_create: bad argument (0<=k<=20, 1<=L<=10, scoring 0..5, weighting 0..3, at least a root and one node)";
+        return ORBX_ERR_BAD_ARGUMENT;
+    }
+    // children in node order (m_nodes[pid].children.push_back(nid), :1392), word ids to the leaves in node order (:1409-1415)
+    std::vector<int> cnt(n_nodes + 1, 0), off(n_nodes + 1, 0), list(n_nodes - 1);
+    for (int n = 1; n < n_nodes; n++) {
+        if (parent[n] < 0 || parent[n] >= n) { g_createError = "orbx_vocabulary_create: parent[n] must name an earlier node"; return ORBX_ERR_BAD_ARGUMENT; }
+        cnt[parent[n]]++;
+    }
+    for (int n = 0; n < n_nodes; n++) off[n + 1] = off[n] + cnt[n];
+    std::vector<int> fill(off.begin(), off.end() - 1);
+    for (int n = 1; n < n_nodes; n++) list[fill[parent[n]]++] = n;
+    std::vector<uint32_t> wid(n_nodes, 0);
+    int words = 0;
+    for (int n = 1; n < n_nodes; n++) {
+        if (is_leaf[n]) { if (cnt[n]) { g_createError = "orbx_vocabulary_create: a leaf with children"; return ORBX_ERR_BAD_ARGUMENT; } wid[n] = (uint32_t)words++; }
+        else if (!cnt[n]) { g_createError = "orbx_vocabulary_create: an inner node without children (the reference would treat it as a word without an id)"; return ORBX_ERR_BAD_ARGUMENT; }
+    }
+    if (!cnt[0]) { g_createError = "orbx_vocabulary_create: the root has no children"; return ORBX_ERR_BAD_ARGUMENT; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_createError = "orbx_vocabulary_create: no HIP device (this library has no CPU path)"; return ORBX_ERR_NO_DEVICE; }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return ORBX_ERR_HIP;
+    if (device >= ndev) { g_createError = "orbx_vocabulary_create: device index out of range"; return ORBX_ERR_BAD_ARGUMENT; }
+    orbx_vocabulary* v = new orbx_vocabulary();
+    v->device = device; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->nNodes = n_nodes; v->nWords = words;
+    auto up = [&](void** d, const void* src, size_t bytes) {
+        return hipMalloc(d, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
+    };
+    std::vector<double> w0(weight, weight + n_nodes);
+    if (hipSetDevice(device) != hipSuccess || !up((void**)&v->d_childOff, off.data(), sizeof(int) * (n_nodes + 1)) ||
+        !up((void**)&v->d_childList, list.data(), sizeof(int) * list.size()) || !up((void**)&v->d_desc, desc, (size_t)n_nodes * 32) ||
+        !up((void**)&v->d_wordId, wid.data(), sizeof(uint32_t) * n_nodes) || !up((void**)&v->d_weight, w0.data(), sizeof(double) * n_nodes)) {
+        g_createError = "orbx_vocabulary_create: device allocation or copy failed";
+        orbx_vocabulary_destroy(v);
+        return ORBX_ERR_HIP;
+    }
+    *out = v;
+    return ORBX_OK;
+}
+
+int orbx_vocabulary_load_text(orbx_vocabulary** out, const char* path, int device) {
+    if (!out) return ORBX_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    FILE* f = path ? std::fopen(path, "r") : nullptr;
+    if (!f) { g_createError = "orbx_vocabulary_load_text: cannot open the file"; return ORBX_ERR_BAD_ARGUMENT; }
+    int k = 0, L = 0, n1 = 0, n2 = 0;
+    if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4) { std::fclose(f); g_createError = "orbx_vocabulary_load_text: bad header"; return ORBX_ERR_BAD_ARGUMENT; }
+    std::vector<int> parent(1, 0);
+    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    for (;;) {      // one node per line: parent, is-leaf, FORB::L = 32 descriptor bytes, weight (TemplatedVocabulary.h:1378-1419)
+        int pid = 0, isLeaf = 0;
+        if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+        uint8_t d[32];
+        bool ok = true;
+        for (int i = 0; i < 32 && ok; i++) { int b = 0; ok = std::fscanf(f, "%d", &b) == 1; d[i] = (uint8_t)b; }
+        double w = 0;
+        if (!ok || std::fscanf(f, "%lf", &w) != 1) { std::fclose(f); g_createError = "orbx_vocabulary_load_text: truncated node line"; return ORBX_ERR_BAD_ARGUMENT; }
+        parent.push_back(pid); leaf.push_back(isLeaf > 0); weight.push_back(w);
+        desc.insert(desc.end(), d, d + 32);
+    }
+    std::fclose(f);
+    return orbx_vocabulary_create(out, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), device);
+}
+
+int orbx_vocabulary_info(const orbx_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words) {
+    if (!v) return ORBX_ERR_BAD_ARGUMENT;
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    if (n_nodes) *n_nodes = v->nNodes;
+    if (n_words) *n_words = v->nWords;
+    return ORBX_OK;
+}
+
+int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_frames, const uint8_t* d_desc, const int* d_n_out, int capacity,
+                            int levels_up, uint32_t* d_word_ids, double* d_word_weights, int* d_n_words, uint32_t* d_feat_nodes,
+                            uint32_t* d_feat_idx, int* d_n_feat) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!v || !d_desc || !d_n_out || !d_word_ids || !d_word_weights || !d_n_words || !d_feat_nodes || !d_feat_idx || !d_n_feat || capacity < 1 ||
+        n_frames < 1 || n_frames > 65535)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames < 1 or more than 65535 frames");
+    if (v->device != h->device) return fail(h, ORBX_ERR_BAD_ARGUMENT, "the vocabulary lives on another device than the handle");
+    if (capacity > 16384) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 16384 keypoints per frame (the per-frame sort runs in LDS)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t need = (size_t)n_frames * capacity;
+    if (need > h->bowEntries) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        void* old[] = {h->d_bowWord, h->d_bowNode, h->d_bowWeight};
+        for (void* p : old) if (p) (void)hipFree(p);
+        h->d_bowWord = h->d_bowNode = nullptr; h->d_bowWeight = nullptr; h->bowEntries = 0;
+        HIP_TRY(h, hipMalloc(&h->d_bowWord, need * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc(&h->d_bowNode, need * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc(&h->d_bowWeight, need * sizeof(double)));
+        h->bowEntries = need;
+    }
+    VocabDevice V{v->d_childOff, v->d_childList, v->d_desc, v->d_weight, v->d_wordId, v->nNodes, v->k, v->L, v->scoring, v->weighting};
+    {
+        Prof pr(h, S_FRAME);
+        launchBow(h->stream, V, d_desc, d_n_out, capacity, levels_up, h->d_bowWord, h->d_bowWeight, h->d_bowNode, d_word_ids, d_word_weights, d_n_words,
+                  d_feat_nodes, d_feat_idx, d_n_feat, n_frames);
     }
     HIP_TRY(h, hipGetLastError());
     return ORBX_OK;

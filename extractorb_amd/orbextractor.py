@@ -60,6 +60,37 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+class Vocabulary:
+    """DBoW2 ORB vocabulary on the device (reference inc/ORBVocabulary.h; System.cc:81-82 loads ORBvoc.txt once per process)."""
+
+    def __init__(self, path=None, arrays=None, device=-1):
+        self._L = load_library()
+        self._v = C.c_void_p()
+        if path is not None:
+            rc = self._L.orbx_vocabulary_load_text(C.byref(self._v), str(path).encode(), device)
+        else:
+            a = arrays
+            par = np.ascontiguousarray(a["parent"], np.int32); leaf = np.ascontiguousarray(a["is_leaf"], np.uint8)
+            d = np.ascontiguousarray(a["desc"], np.uint8); w = np.ascontiguousarray(a["weight"], np.float64)
+            rc = self._L.orbx_vocabulary_create(C.byref(self._v), a["k"], a["L"], a["scoring"], a["weighting"], len(par), _ptr(par), _ptr(leaf),
+                                                _ptr(d), _ptr(w), device)
+        if rc != ORBX_OK:
+            raise OrbxError(rc, (self._L.orbx_last_error(None) or b"").decode())
+
+    def info(self):
+        k, L, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._L.orbx_vocabulary_info(self._v, C.byref(k), C.byref(L), C.byref(n), C.byref(w))
+        return dict(k=k.value, L=L.value, n_nodes=n.value, n_words=w.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_v", None):
+                self._L.orbx_vocabulary_destroy(self._v)
+                self._v = None
+        except Exception:
+            pass
+
+
 def header_symbols():
     """Names of every function include/orbx.h declares."""
     text = open(_HEADER).read()
@@ -111,6 +142,12 @@ def load_library():
                                                  C.c_float, C.c_float, C.c_float, C.c_int, vp]
     L.orbx_search_by_projection_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int,
                                                    vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+    L.orbx_vocabulary_load_text.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int]
+    L.orbx_vocabulary_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int]
+    L.orbx_vocabulary_destroy.argtypes = [vp]
+    L.orbx_vocabulary_destroy.restype = None
+    L.orbx_vocabulary_info.argtypes = [vp, ip, ip, ip, ip]
+    L.orbx_compute_bow_device.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -404,6 +441,14 @@ class ORBextractor:
             self._h, n_pairs, cur[0], cur[1], dp(d_queries), dp(d_query_desc), desc_blocks[0], desc_blocks[1], dp(d_n_queries), query_capacity,
             dp(d_kps_un), dp(d_desc), dp(d_n), capacity, dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_u_right), dp(d_occupied),
             int(ratio_mode), nnratio, int(check_orientation), dp(d_matches), dp(d_n_matches)))
+
+    def compute_bow_device(self, vocab, n_frames, d_desc, d_n, capacity, d_word_ids, d_word_weights, d_n_words, d_feat_nodes, d_feat_idx,
+                           d_n_feat, levels_up=4):
+        """Frame::ComputeBoW (reference src/Frame.cc:739-746) for n_frames device-resident frames."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self._L.orbx_compute_bow_device(self._h, vocab._v, n_frames, dp(d_desc), dp(d_n), capacity, levels_up, dp(d_word_ids),
+                                                    dp(d_word_weights), dp(d_n_words), dp(d_feat_nodes), dp(d_feat_idx), dp(d_n_feat)))
 
     def stereo_from_rgbd_device(self, n_frames, d_kps, d_kps_un, d_n, capacity, d_depth, depth_is_u16, rows, cols, depth_map_factor, mbf,
                                 d_u_right, d_depth_out, depth_stride_bytes=None, depth_frame_stride_bytes=None):

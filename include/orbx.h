@@ -267,6 +267,30 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
                                      uint8_t* d_occupied, int ratio_mode, float nn_ratio, int check_orientation, int* d_matches,
                                      int* d_n_matches);
 
+/* ---- next row: Frame::ComputeBoW (src/Frame.cc:739-746) --------------------------------------------------
+ * = DBoW2::TemplatedVocabulary<FORB>::transform(features, BowVector, FeatureVector, levelsup = 4)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1196, 1218-1262; BowVector.cpp:34-83; FeatureVector.cpp:31-46).
+ * The vocabulary is an object of its own (System.cc:81-82 loads one per process and shares it between all frames). */
+typedef struct orbx_vocabulary orbx_vocabulary;
+/* Replaces ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1423): the ORBvoc.txt format ("k L scoring weighting", then one
+ * node per line: parent, is-leaf, 32 descriptor bytes, weight).  device < 0: current HIP device.  Errors: ORBX_ERR_BAD_ARGUMENT (file). */
+int orbx_vocabulary_load_text(orbx_vocabulary** out, const char* path, int device);
+/* The same from arrays: node 0 is the root, node n >= 1 has parent[n] < n, is_leaf[n], desc[n*32 ..], weight[n]; word ids are given to the
+ * leaves in node order, children are listed in node order (both as the loader does).  scoring: 0 L1_NORM .. 5 DOT_PRODUCT; weighting:
+ * 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (BowVector.h:39-56). */
+int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int weighting, int n_nodes, const int* parent,
+                           const uint8_t* is_leaf, const uint8_t* desc, const double* weight, int device);
+void orbx_vocabulary_destroy(orbx_vocabulary* v);
+int orbx_vocabulary_info(const orbx_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words);
+/* mBowVec / mFeatVec of n_frames device-resident frames (d_desc, d_n_out: mDescriptors, N of orbx_extract_batch_device):
+ *   d_word_ids[f*capacity + j], d_word_weights[f*capacity + j], d_n_words[f] : the BowVector (std::map<WordId, WordValue>) in key order
+ *   d_feat_nodes[f*capacity + j], d_feat_idx[f*capacity + j], d_n_feat[f]    : the FeatureVector (std::map<NodeId, vector<unsigned>>)
+ *                                                                               flattened in (node, feature index) order
+ * Asynchronous on the handle's stream; the vocabulary must live on the handle's device. */
+int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_frames, const uint8_t* d_desc, const int* d_n_out, int capacity,
+                            int levels_up, uint32_t* d_word_ids, double* d_word_weights, int* d_n_words, uint32_t* d_feat_nodes,
+                            uint32_t* d_feat_idx, int* d_n_feat);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

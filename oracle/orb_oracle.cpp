@@ -30,6 +30,7 @@
 #include <list>
 #include <thread>
 #include <utility>
+#include <map>
 #include <vector>
 
 namespace {
@@ -1180,6 +1181,83 @@ int oracle_search_by_projection(const void* queries_, const uint8_t* qdesc, int 
     }
     if (occupied) std::copy(occ.begin(), occ.end(), occupied);
     return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// "Next" row: Frame::ComputeBoW (src/Frame.cc:739-746) = DBoW2::TemplatedVocabulary<FORB>::transform with
+// levelsup = 4, restated from the DBoW2 sources vendored with the reference (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1196
+// and 1218-1262, BowVector.cpp:34-83, FeatureVector.cpp:31-46, FORB.cpp distance).  The vocabulary arrives as the arrays the text
+// loader builds (:1338-1423): node n >= 1 with parent[n] < n, children in node order, word ids to the leaves in node order.
+// Vocabulary/ORBvoc.txt itself is absent from the reference (.MISSING_LARGE_BLOBS:1); the tests use synthetic trees.
+// ---------------------------------------------------------------------------------------------
+struct OracleVocab {
+    int k, L, scoring, weighting;
+    std::vector<std::vector<int>> children;
+    std::vector<const uint8_t*> desc;
+    std::vector<double> weight;
+    std::vector<unsigned> wordId;
+};
+
+// returns the number of words; wordIds / wordWeights hold the BowVector in key order; fvNodes / fvIdx the FeatureVector flattened in
+// (node, feature) order with *nFeat entries
+int oracle_compute_bow(int k, int L, int scoring, int weighting, int nNodes, const int* parent, const uint8_t* isLeaf, const uint8_t* nodeDesc,
+                       const double* weight, const uint8_t* desc, int N, int levelsup, unsigned* wordIds, double* wordWeights,
+                       unsigned* fvNodes, unsigned* fvIdx, int* nFeat) {
+    OracleVocab V{k, L, scoring, weighting, {}, {}, {}, {}};
+    V.children.resize(nNodes); V.desc.resize(nNodes); V.weight.assign(weight, weight + nNodes); V.wordId.assign(nNodes, 0);
+    unsigned words = 0;
+    for (int n = 0; n < nNodes; n++) {
+        V.desc[n] = nodeDesc + (size_t)n * 32;
+        if (n > 0) { V.children[parent[n]].push_back(n); if (isLeaf[n]) V.wordId[n] = words++; }
+    }
+    std::map<unsigned, double> v;                              // BowVector
+    std::map<unsigned, std::vector<unsigned>> fv;              // FeatureVector
+    const bool must = scoring != 5;                            // ScoringObject.h:74-89: every scoring but DOT_PRODUCT normalises ...
+    const bool l2 = scoring == 1;                              // ... L2_NORM with L2, the others with L1
+    for (int i = 0; i < N; i++) {
+        // transform(feature, word_id, weight, nid, levelsup)  (:1218-1262)
+        const uint8_t* feature = desc + (size_t)i * 32;
+        const int nid_level = L - levelsup;
+        unsigned nid = 0;                                      // root if nid_level <= 0 (:1227); the reference leaves it unset when the
+                                                               // leaf is shallower than nid_level (never in a full tree): 0 here
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const std::vector<int>& nodes = V.children[final_id];
+            final_id = nodes[0];
+            double best_d = (double)descriptorDistance(feature, V.desc[final_id]);
+            for (size_t c = 1; c < nodes.size(); c++) {
+                const double d = (double)descriptorDistance(feature, V.desc[nodes[c]]);
+                if (d < best_d) { best_d = d; final_id = nodes[c]; }
+            }
+            if (current_level == nid_level) nid = (unsigned)final_id;
+        } while (!V.children[final_id].empty());
+        const unsigned id = V.wordId[final_id];
+        const double w = V.weight[final_id];
+        if (w > 0) {                                           // not stopped (:1161, :1187)
+            if (weighting == 0 || weighting == 1) {            // TF_IDF, TF: BowVector::addWeight
+                auto it = v.find(id);
+                if (it != v.end()) it->second += w; else v[id] = w;
+            } else if (!v.count(id)) v[id] = w;                // IDF, BINARY: addIfNotExist
+            fv[nid].push_back((unsigned)i);
+        }
+    }
+    if ((weighting == 0 || weighting == 1) && !v.empty() && !must) {      // :1170-1176
+        const double nd = (double)v.size();
+        for (auto& e : v) e.second /= nd;
+    }
+    if (must) {                                                // BowVector::normalize (BowVector.cpp:62-83)
+        double norm = 0.0;
+        if (!l2) for (auto& e : v) norm += std::fabs(e.second);
+        else { for (auto& e : v) norm += e.second * e.second; norm = std::sqrt(norm); }
+        if (norm > 0.0) for (auto& e : v) e.second /= norm;
+    }
+    int nw = 0;
+    for (auto& e : v) { wordIds[nw] = e.first; wordWeights[nw] = e.second; nw++; }
+    int nf = 0;
+    for (auto& e : fv) for (unsigned i : e.second) { fvNodes[nf] = e.first; fvIdx[nf] = i; nf++; }
+    *nFeat = nf;
+    return nw;
 }
 
 // cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8-bit images as Tracking::GrabImage* calls it

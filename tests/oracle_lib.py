@@ -79,6 +79,8 @@ def lib():
         L.oracle_project_last_frame.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, vp]
         L.oracle_search_by_projection.restype = C.c_int
         L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
+        L.oracle_compute_bow.restype = C.c_int
+        L.oracle_compute_bow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, ip]
         L.oracle_stereo_from_rgbd.restype = None
         L.oracle_stereo_from_rgbd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_float, vp, vp]
         L.oracle_gray_from_color.restype = None
@@ -256,6 +258,21 @@ def search_by_projection(queries, qdesc, kps_un, desc, grid_off, grid_idx, bound
                                           _ptr(np.ascontiguousarray(bounds, np.float32)), None if ur is None else _ptr(ur), _ptr(occ),
                                           int(ratio_mode), nnratio, int(check_orientation), _ptr(m))
     return n, m[:N].copy(), occ[:N].copy()
+
+
+def compute_bow(vocab, desc, levelsup=4):
+    """Frame::ComputeBoW (reference src/Frame.cc:739-746; DBoW2 TemplatedVocabulary::transform).  vocab: dict with k, L, scoring, weighting,
+    parent[n], is_leaf[n], desc[n,32], weight[n].  Returns (word_ids, word_weights, fv_nodes, fv_idx)."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    N = len(d)
+    wid = np.zeros(max(N, 1), np.uint32); ww = np.zeros(max(N, 1), np.float64)
+    fn = np.zeros(max(N, 1), np.uint32); fi = np.zeros(max(N, 1), np.uint32)
+    nf = C.c_int()
+    nw = lib().oracle_compute_bow(vocab["k"], vocab["L"], vocab["scoring"], vocab["weighting"], len(vocab["parent"]),
+                                  _ptr(np.ascontiguousarray(vocab["parent"], np.int32)), _ptr(np.ascontiguousarray(vocab["is_leaf"], np.uint8)),
+                                  _ptr(np.ascontiguousarray(vocab["desc"], np.uint8)), _ptr(np.ascontiguousarray(vocab["weight"], np.float64)),
+                                  _ptr(d), N, levelsup, _ptr(wid), _ptr(ww), _ptr(fn), _ptr(fi), C.byref(nf))
+    return wid[:nw].copy(), ww[:nw].copy(), fn[:nf.value].copy(), fi[:nf.value].copy()
 
 
 def stereo_from_rgbd(kps, kps_un, depth, factor, mbf):

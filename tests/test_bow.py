@@ -1,0 +1,219 @@
+"""Frame::ComputeBoW (reference src/Frame.cc:739-746) = DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector,
+FeatureVector, 4) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1196, 1218-1262).  Vocabulary/ORBvoc.txt is absent from the
+reference (.MISSING_LARGE_BLOBS:1), so the vocabularies here are synthetic trees written in the same text format (:1338-1423).
+CPU: the oracle against an independent numpy/dict statement; GPU: orbx_compute_bow_device against the oracle, bit-exact doubles."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import extractorb_amd as X
+from extractorb_amd import synth
+
+
+def make_vocab(rng, k=10, L=3, scoring=0, weighting=0, ragged=False, stop_frac=0.05):
+    """A random tree in loader order: node n >= 1 has parent[n] < n.  Built level by level like the file ORB-SLAM ships: children of a node
+    are consecutive.  ragged: some inner nodes have fewer than k children and some branches end early (leaves above level L)."""
+    parent, leaf, level = [0], [0], [0]
+    frontier = [0]
+    for lv in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            nk = k if not ragged else int(rng.integers(2, k + 1))
+            for _ in range(nk):
+                n = len(parent)
+                is_leaf = lv == L or (ragged and lv >= 2 and rng.random() < 0.2)
+                parent.append(p); leaf.append(int(is_leaf)); level.append(lv)
+                if not is_leaf:
+                    nxt.append(n)
+        frontier = nxt
+    n = len(parent)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    weight = np.where(np.array(leaf) > 0, rng.uniform(0.1, 9.0, n), 0.0)
+    weight[(rng.random(n) < stop_frac) & (np.array(leaf) > 0)] = 0.0           # stopped words (stopWords(), :289)
+    # make siblings with IDENTICAL descriptors exist: distance ties must go to the first child
+    for p in range(0, n, 37):
+        kids = [c for c in range(1, n) if parent[c] == p]
+        if len(kids) >= 3:
+            desc[kids[2]] = desc[kids[0]]
+    return dict(k=k, L=L, scoring=scoring, weighting=weighting, parent=np.array(parent, np.int32), is_leaf=np.array(leaf, np.uint8),
+                desc=desc, weight=weight.astype(np.float64), level=np.array(level))
+
+
+def write_text(v, path):
+    """TemplatedVocabulary::saveToTextFile's format (:1427-1456): header, then one line per node."""
+    with open(path, "w") as f:
+        f.write("%d %d  %d %d\n" % (v["k"], v["L"], v["scoring"], v["weighting"]))
+        for n in range(1, len(v["parent"])):
+            f.write("%d %d %s %r\n" % (v["parent"][n], v["is_leaf"][n], " ".join(str(int(b)) for b in v["desc"][n]), float(v["weight"][n])))
+
+
+def brute_bow(v, desc, levelsup):
+    n = len(v["parent"])
+    children = [[] for _ in range(n)]
+    word, words = {}, 0
+    for c in range(1, n):
+        children[v["parent"][c]].append(c)
+        if v["is_leaf"][c]:
+            word[c] = words; words += 1
+    bits = np.unpackbits(v["desc"], axis=1)
+    bow, fv = {}, {}
+    for i, d in enumerate(desc):
+        db = np.unpackbits(d)
+        node, lv, nid = 0, 0, 0
+        while children[node]:
+            lv += 1
+            dist = [(int((db != bits[c]).sum()), j) for j, c in enumerate(children[node])]
+            node = children[node][min(dist)[1]]
+            if lv == v["L"] - levelsup:
+                nid = node
+        w = float(v["weight"][node])
+        if w > 0:
+            if v["weighting"] in (0, 1):
+                bow[word[node]] = bow[word[node]] + w if word[node] in bow else w
+            else:
+                bow.setdefault(word[node], w)
+            fv.setdefault(nid, []).append(i)
+    keys = sorted(bow)
+    vals = [bow[k] for k in keys]
+    if v["scoring"] == 5:
+        if v["weighting"] in (0, 1) and keys:
+            vals = [x / float(len(keys)) for x in vals]
+    else:
+        norm = 0.0
+        for x in vals:
+            norm = norm + (x * x if v["scoring"] == 1 else abs(x))
+        if v["scoring"] == 1:
+            norm = float(np.sqrt(norm))
+        if norm > 0:
+            vals = [x / norm for x in vals]
+    fn = [k for k in sorted(fv) for _ in fv[k]]
+    fi = [i for k in sorted(fv) for i in fv[k]]
+    return keys, vals, fn, fi
+
+
+CONFIGS = [dict(k=10, L=3), dict(k=10, L=5, levelsup=4, small=True), dict(k=4, L=4, ragged=True), dict(k=20, L=2), dict(k=10, L=3, scoring=1, weighting=1),
+           dict(k=10, L=3, scoring=5, weighting=0), dict(k=6, L=3, scoring=0, weighting=2), dict(k=6, L=3, scoring=5, weighting=3), dict(k=3, L=6, levelsup=4)]
+
+
+def _vocab_for(cfg, rng):
+    k, L = cfg["k"], cfg["L"]
+    if cfg.get("small"):          # k^L would be 100 000 leaves: keep the depth, prune the width below level 2
+        return make_vocab(rng, k=k, L=L, ragged=True, scoring=cfg.get("scoring", 0), weighting=cfg.get("weighting", 0))
+    return make_vocab(rng, k=k, L=L, ragged=cfg.get("ragged", False), scoring=cfg.get("scoring", 0), weighting=cfg.get("weighting", 0))
+
+
+def _descriptors(v, rng, n):
+    """Descriptors near random vocabulary nodes (so words repeat inside a frame) plus pure noise."""
+    leaves = np.nonzero(v["is_leaf"])[0]
+    d = v["desc"][rng.choice(leaves, n)].copy()
+    d[: n // 3] = v["desc"][rng.choice(leaves[: max(4, len(leaves) // 50)], n // 3)]      # a few hot words
+    flip = rng.integers(0, 256, (n, 6))
+    for i in range(n):
+        for b in flip[i, : rng.integers(0, 7)]:
+            d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    d[-n // 10:] = rng.integers(0, 256, (n // 10, 32), dtype=np.uint8)
+    return d
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
+def test_oracle_bow_equals_independent_statement(cfg):
+    rng = np.random.default_rng(hash(str(cfg)) % 2 ** 31)
+    v = _vocab_for(cfg, rng)
+    d = _descriptors(v, rng, 400)
+    lu = cfg.get("levelsup", min(4, v["L"] - 1))
+    wid, ww, fn, fi = O.compute_bow(v, d, lu)
+    keys, vals, bfn, bfi = brute_bow(v, d, lu)
+    assert wid.tolist() == keys and fn.tolist() == bfn and fi.tolist() == bfi
+    assert ww.tolist() == vals                               # same doubles: same order of additions
+    assert len(keys) > 20 and len(fi) > 300
+    if v["scoring"] == 0:
+        assert abs(ww.sum() - 1.0) < 1e-12                   # L1-normalised
+
+
+def test_bow_of_real_descriptors_groups_features_by_node():
+    rng = np.random.default_rng(3)
+    v = make_vocab(rng, k=10, L=3)
+    _, k, d = O.Oracle(1000).extract(synth.frames("textured", 5, 1, 480, 640)[0])
+    wid, ww, fn, fi = O.compute_bow(v, d, 2)                 # nodes of level L - 2 = 1: the root's children
+    assert set(fn.tolist()) <= set(range(1, 11)) and sorted(fi.tolist()) == sorted(set(fi.tolist()))
+    assert (np.diff(wid.astype(np.int64)) > 0).all() and (ww > 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
+def test_gpu_bow_equals_oracle(cfg, tmp_path):
+    import torch
+    rng = np.random.default_rng(hash(str(cfg)) % 2 ** 31 + 1)
+    v = _vocab_for(cfg, rng)
+    lu = cfg.get("levelsup", min(4, v["L"] - 1))
+    path = tmp_path / "voc.txt"
+    write_text(v, path)
+    voc = X.Vocabulary(path=path)                            # the text loader (ORBVocabulary::loadFromTextFile)
+    info = voc.info()
+    assert info["n_nodes"] == len(v["parent"]) and info["n_words"] == int(v["is_leaf"].sum()) and info["k"] == v["k"] and info["L"] == v["L"]
+    B, cap = 3, 1100
+    ns = [1000, 1, 640]
+    desc = np.zeros((B, cap, 32), np.uint8)
+    for f in range(B):
+        desc[f, :ns[f]] = _descriptors(v, rng, max(ns[f], 30))[:ns[f]]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_wid = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_ww = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
+    d_nw = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_fn = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_fi = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    d_nf = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex = X.ORBextractor(1000)
+    for voc_obj in (voc, X.Vocabulary(arrays=v)):            # text loader and array constructor give the same tree
+        ex.compute_bow_device(voc_obj, B, dev(desc), dev(np.array(ns, np.int32)), cap, d_wid, d_ww, d_nw, d_fn, d_fi, d_nf, levels_up=lu)
+        ex.synchronize()
+        for f in range(B):
+            wid, ww, fn, fi = O.compute_bow(v, desc[f, :ns[f]], lu)
+            nw, nf = int(d_nw[f]), int(d_nf[f])
+            assert nw == len(wid) and nf == len(fi), "frame %d" % f
+            assert d_wid[f, :nw].cpu().numpy().astype(np.uint32).tolist() == wid.tolist()
+            assert d_ww[f, :nw].cpu().numpy().tobytes() == ww.tobytes(), "frame %d: weights differ (order of additions?)" % f
+            assert d_fn[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fn.tolist()
+            assert d_fi[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fi.tolist()
+
+
+@pytest.mark.gpu
+def test_gpu_bow_on_extracted_frames():
+    """ComputeBoW fed straight from the extraction's device buffers (the Frame constructor's order: ExtractORB, then ComputeBoW on demand)."""
+    import torch
+    rng = np.random.default_rng(8)
+    v = make_vocab(rng, k=10, L=4, ragged=True)
+    voc = X.Vocabulary(arrays=v)
+    B = 4
+    fr = synth.frames("textured", 60, B, 480, 640)
+    ex = X.ORBextractor(1000, max_batch=B)
+    cap = ex.capacity
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_m = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(torch.from_numpy(fr).cuda(), B, 480, 640, d_k, d_d, d_n, d_m, cap)
+    d_wid = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_ww = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
+    d_nw = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_fn = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_fi = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    d_nf = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.compute_bow_device(voc, B, d_d, d_n, cap, d_wid, d_ww, d_nw, d_fn, d_fi, d_nf, levels_up=2)
+    ex.synchronize()
+    for f in range(B):
+        _, k, d = O.Oracle(1000).extract(fr[f])
+        wid, ww, fn, fi = O.compute_bow(v, d, 2)
+        nw, nf = int(d_nw[f]), int(d_nf[f])
+        assert nw == len(wid) and d_ww[f, :nw].cpu().numpy().tobytes() == ww.tobytes()
+        assert d_wid[f, :nw].cpu().numpy().astype(np.uint32).tolist() == wid.tolist()
+        assert d_fn[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fn.tolist() and d_fi[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fi.tolist()
+
+
+def test_vocabulary_errors(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(X.OrbxError):
+            X.Vocabulary(path=tmp_path / "missing.txt")
+        return
+    with pytest.raises(X.OrbxError):
+        X.Vocabulary(path=tmp_path / "missing.txt")
+    bad = dict(k=10, L=3, scoring=0, weighting=0, parent=np.array([0, 0, 5], np.int32), is_leaf=np.array([0, 1, 1], np.uint8),
+               desc=np.zeros((3, 32), np.uint8), weight=np.ones(3))
+    with pytest.raises(X.OrbxError):
+        X.Vocabulary(arrays=bad)                             # parent after child
