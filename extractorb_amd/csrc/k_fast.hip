@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "orbx_device.hpp"
+#include "k_blur_body.hpp"
 
 namespace orbx {
 
@@ -167,12 +168,18 @@ __device__ __forceinline__ void waveLdsSync() {
     asm volatile("" ::: "memory");
 }
 
-// TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.
-template <int TS, int ROWS, bool PREFILTER>
+// What the fused form needs to run the blur's lanes behind the FAST cells (small batches: the two kernels are independent, both only
+// read the pyramid, and a launch costs ~6 us of latency whatever its size)
+struct BlurTail { const BlurItem* items; const unsigned short* laneItem; int nLanes; uint8_t* blur; int fastChunks; };
+
+// TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.  FUSE_BLUR: chunks past tail.fastChunks run
+// blur lanes (short-chain form) instead of FAST cells.
+template <int TS, int ROWS, bool PREFILTER, bool FUSE_BLUR = false>
 __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames) {
+                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
+                                               BlurTail tail) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
     constexpr int DW = TS / 4;                        // dwords per tile row
@@ -186,6 +193,12 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
     int chunk, fr;
     if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all cells of a frame on one XCD: the 6-px ROI overlap of neighbouring cells hits its L2
+    if constexpr (FUSE_BLUR) {
+        if (chunk >= tail.fastChunks) {                // workgroup-uniform
+            blurLanes<kBlurBlockRowsSmall>(tail.items, tail.laneItem, tail.nLanes, lv, pyr, tail.blur, chunk - tail.fastChunks, f0 + fr);
+            return;
+        }
+    }
     const int ci = chunk * kFastWaves + wave, f = f0 + fr;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
     const CellDesc c = cells[ci];
@@ -386,17 +399,28 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
-                bool prefilter, int f0, int B) {
-    const dim3 grid = xcdGrid((nCells + kFastWaves - 1) / kFastWaves, B), block(256);
+                bool prefilter, int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur) {
+    const int fastChunks = (nCells + kFastWaves - 1) / kFastWaves;
+    const dim3 block(256);
+    BlurTail tail{blurItems, blurLaneItem, blurLanes, blur, fastChunks};
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
     if (maxRoiW <= 45 && maxRoiH <= 45) {
-        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
-        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
+        if (blurItems) {      // small batch: the blur's lanes ride in the same launch
+            const dim3 grid = xcdGrid(fastChunks + (blurLanes + 255) / 256, B);
+            if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+            else hipLaunchKernelGGL((k_fast<48, 45, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+            return;
+        }
+        const dim3 grid = xcdGrid(fastChunks, B);
+        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
     } else {   // cells up to 63 px (the geometry code rejects larger ones)
-        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
-        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B);
+        const dim3 grid = xcdGrid(fastChunks, B);
+        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
     }
 }
+bool fastCanCarryBlur(int maxRoiW, int maxRoiH) { return maxRoiW <= 45 && maxRoiH <= 45; }
 
 // Create-time check of the assumption the packed passes rest on: v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_sub_u16
 // behave as integer min3 / max3 / subtract on u16 halves holding 0..255 (FP16 denormals preserved).  One wave; lane l

@@ -22,7 +22,8 @@ void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, con
                   uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, bool, int, int);
+                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*);
+bool fastCanCarryBlur(int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
                   unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*);
@@ -159,6 +160,7 @@ struct orbx_handle {
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     int splitMode = 1;                 // ORBX_SPLIT=0: never split a batch over the two streams
+    bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
     int statB = 0;
@@ -337,6 +339,8 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     const bool prefilter = h->fastMode == 1 || (h->fastMode < 0 && h->candDensity >= 0.f && h->candDensity < kPrefilterDensity);
     // the launch sequence of frames [f0, f0 + Bn) on stream st, in two parts: front = pyramid + blur (HBM / latency bound),
     // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
+    auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
+    auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
     auto front = [&](hipStream_t st, int f0, int Bn) {
         {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
             Prof p(h, S_LEVEL0, st);
@@ -350,9 +354,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                          g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
         }
-        {   // throughput form (32-row blocks) once the grid fills the chip several times over, else the short-chain form
+        // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
+        // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
+        if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
-            const int v = (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1;      // two waves per SIMD of 32-row lanes
+            const int v = blurVariant(Bn);
             launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v ? kBlurBlockRowsSmall : kBlurBlockRows,
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
         }
@@ -360,8 +366,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     auto back = [&](hipStream_t st, int f0, int Bn) {
         {
             Prof p(h, S_FAST, st);
+            const bool carry = blurRidesWithFast(Bn);
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
-                       h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn);
+                       h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
+                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur);
         }
         {
             Prof p(h, S_OCTREE, st);
@@ -585,6 +593,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 1;
+    h->fuseSmall = !(getenv("ORBX_FUSE_SMALL") && atoi(getenv("ORBX_FUSE_SMALL")) == 0);
     h->splitMinPixels = (long long)((getenv("ORBX_SPLIT_MIN_MPX") ? atof(getenv("ORBX_SPLIT_MIN_MPX")) : 120.0) * 1e6);
     if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
