@@ -113,19 +113,24 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 // OCT_W = waves per SIMD the variant is compiled for, i.e. its register budget: 8 -> 64 VGPRs (about 64 values live in
 // scratch, but 6 workgroups of 256 threads fit a CU: best when a large batch queues many more workgroups than fit the chip),
 // 4 -> 128 VGPRs, no scratch (best while every workgroup of the launch is resident anyway: small batches, one frame).
+// Queued variants (large batches): 1024 and 512 threads are compiled for 8 waves per SIMD (64 VGPRs: two 1024-thread or four
+// 512-thread workgroups per CU), 256 threads for 6 (80 VGPRs, fewer values in scratch; LDS allows six such workgroups per CU
+// anyway): 179 -> 169 us per 512 frames at 640x480; the same budget on the 1024-thread variant halves its residency (1080p: 282 -> 310 us).
 #define OCT_W 8
 #define OCT_T 1024
 #define OCT_NAME(x) x##_1024
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
-#define OCT_T 256
-#define OCT_NAME(x) x##_256
+#define OCT_T 512
+#define OCT_NAME(x) x##_512
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
-#define OCT_T 512
-#define OCT_NAME(x) x##_512
+#undef OCT_W
+#define OCT_W 6
+#define OCT_T 256
+#define OCT_NAME(x) x##_256
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
