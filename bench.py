@@ -271,9 +271,7 @@ def main():
     result = None
     if rank == 0:
         # ---- per-kernel durations, HIP events on the handle's stream (separate, untimed pass) ----
-        ex.profile(True)
-        psteps = max(3, min(args.steps, 20))
-        for _ in range(psteps):
+        def profiled_step():
             ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
                                     lapping=wl["lapping"])
             if match:
@@ -284,6 +282,13 @@ def main():
                 finish_and_track(ex, base)
             if bow:
                 compute_bow(ex, base)
+
+        ex.profile(True)
+        profiled_step()          # the profiled form can launch kernels the timed form never did (unsplit, unfused): load them untimed
+        ex.profile(True)         # (resets the slots)
+        psteps = max(3, min(args.steps, 20))
+        for _ in range(psteps):
+            profiled_step()
         prof = ex.profile_read()
         ex.profile(False)
         kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # one launch = one batch: the two-half overlap (default for large batches) is switched off, as in bench.py's own event-profiled pass
 export ORBX_SPLIT=0
 python3 -c "import sys; sys.path.insert(0, '$R'); import extractorb_amd as X; print(X.source_hash())" > $OUT/source_hash.txt
-CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
+CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- $CMD > $OUT/stats.log 2>&1 || exit 1
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1 || exit 1

@@ -8,7 +8,7 @@ desc = sys.argv[4] if len(sys.argv) > 4 else "state " + tag
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag + ("_" + workload if workload != "mono640" else ""))
 stem = os.path.join(ROOT, "profiles", "%s_%s_b%s" % (tag, workload, batch))      # tag carries the round: r02_final ...
 tool = os.path.join(ROOT, "tools", "summarize_profile.py")
-cmd = "ORBX_SPLIT=0 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline" + ("" if workload == "mono640" else " --workload " + workload)
+cmd = "ORBX_SPLIT=0 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras" + ("" if workload == "mono640" else " --workload " + workload)
 subprocess.check_call(["cp", os.path.join(src, "kernel_stats.csv"), stem + "_kernel_stats.csv"])
 subprocess.check_call([sys.executable, tool, "stats", os.path.join(src, "kernel_stats.csv"), stem + "_kernel_stats.md",
                        "rocprofv3 --kernel-trace --stats - %s (%s, %s frames per launch)" % (desc, workload, batch),
