@@ -23,14 +23,16 @@ enum Op {
     OP_DOT4_U32_U8, OP_MAD_U32_U24, OP_ADD_U32, OP_AND_B32, OP_LSHLREV_B32, OP_MUL_LO_U32,
     OP_FMA_F32, OP_ADD_F32, OP_MAX3_F32, OP_PK_FMA_F32, OP_CVT_F32_UBYTE0, OP_PK_ADD_F16, OP_MOV_B32,
     OP_SAT_PK_U8_I16, OP_MIN_U32_SDWA, OP_LSHL_OR_B32, OP_ADD3_U32, OP_MUL_U32_U24, OP_OR_B32, OP_CNDMASK, OP_DOT2_U32_U16, OP_MUL_HI_U32_U24,
-    OP_MUL_F32, OP_RNDNE_F32, OP_CVT_I32_F32, OP_FMA_F64, OP_ADD_F64, OP_MBCNT_LO, OP_MOV_DPP, OP_MAX_F32, OP_SUB_U32, OP_LSHL_ADD_U32, OP_COUNT
+    OP_MUL_F32, OP_RNDNE_F32, OP_CVT_I32_F32, OP_FMA_F64, OP_ADD_F64, OP_MBCNT_LO, OP_MOV_DPP, OP_MAX_F32, OP_SUB_U32, OP_LSHL_ADD_U32,
+    OP_MAD_U64_U32, OP_LSHL_ADD_U64, OP_MUL_F64, OP_LSHRREV_B64, OP_MUL_I32_I24, OP_RCP_F32, OP_CVT_F64_F32, OP_CVT_F32_F64, OP_DIV_FIXUP_F32, OP_BCNT, OP_CMP_CNDMASK, OP_COUNT
 };
 static const char* kNames[OP_COUNT] = {
     "v_min3_u32", "v_pk_minimum3_f16", "v_pk_min_u16", "v_perm_b32", "v_min_u32", "v_pk_sub_u16", "v_bfe_u32", "v_alignbyte_b32",
     "v_dot4_u32_u8", "v_mad_u32_u24", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_mul_lo_u32",
     "v_fma_f32", "v_add_f32", "v_max3_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_pk_add_f16", "v_mov_b32",
     "v_sat_pk_u8_i16", "v_min_u32_sdwa(WORD_1)", "v_lshl_or_b32", "v_add3_u32", "v_mul_u32_u24", "v_or_b32", "v_cndmask_b32", "v_dot2_u32_u16", "v_mul_hi_u32_u24",
-    "v_mul_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_fma_f64", "v_add_f64", "v_mbcnt_lo_u32_b32", "v_mov_b32_dpp(quad_perm)", "v_max_f32", "v_sub_u32", "v_lshl_add_u32"};
+    "v_mul_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_fma_f64", "v_add_f64", "v_mbcnt_lo_u32_b32", "v_mov_b32_dpp(quad_perm)", "v_max_f32", "v_sub_u32", "v_lshl_add_u32",
+    "v_mad_u64_u32", "v_lshl_add_u64", "v_mul_f64", "v_lshrrev_b64", "v_mul_i32_i24", "v_rcp_f32", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_div_fixup_f32", "v_bcnt_u32_b32", "v_cmp_lt_u32+v_cndmask_b32 (pair)"};
 
 // DEP: 1 = the instruction reads its own destination (accumulator chain), 0 = destination is write-only
 template <int OP, int DEP>
@@ -127,6 +129,38 @@ __device__ __forceinline__ void one(unsigned& a, unsigned long long& a2, unsigne
     else if constexpr (OP == OP_SUB_U32) { I2("v_sub_u32") }
     else if constexpr (OP == OP_LSHL_ADD_U32) {
         if (DEP) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b)); else asm volatile("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(a) : "v"(b), "v"(c));
+    }
+    else if constexpr (OP == OP_MAD_U64_U32) {
+        if (DEP) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(a2) : "v"(b), "v"(c) : "s20", "s21");
+        else asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %3" : "=v"(a2) : "v"(b), "v"(c), "v"(b2) : "s20", "s21");
+    }
+    else if constexpr (OP == OP_LSHL_ADD_U64) {
+        if (DEP) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(a2) : "v"(b2)); else asm volatile("v_lshl_add_u64 %0, %1, 1, %1" : "=v"(a2) : "v"(b2));
+    }
+    else if constexpr (OP == OP_MUL_F64) {
+        if (DEP) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a2) : "v"(b2)); else asm volatile("v_mul_f64 %0, %1, %1" : "=v"(a2) : "v"(b2));
+    }
+    else if constexpr (OP == OP_LSHRREV_B64) {
+        if (DEP) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(a2)); else asm volatile("v_lshrrev_b64 %0, 1, %1" : "=v"(a2) : "v"(b2));
+    }
+    else if constexpr (OP == OP_MUL_I32_I24) { I2("v_mul_i32_i24") }
+    else if constexpr (OP == OP_RCP_F32) {
+        if (DEP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a)); else asm volatile("v_rcp_f32 %0, %1" : "=v"(a) : "v"(b));
+    }
+    else if constexpr (OP == OP_CVT_F64_F32) {
+        asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a2) : "v"(DEP ? (unsigned)a2 : b));
+    }
+    else if constexpr (OP == OP_CVT_F32_F64) {
+        asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a) : "v"(b2));
+        if (DEP) a2 ^= a;
+    }
+    else if constexpr (OP == OP_DIV_FIXUP_F32) { I3("v_div_fixup_f32") }
+    else if constexpr (OP == OP_BCNT) {
+        if (DEP) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a) : "v"(b)); else asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a) : "v"(b), "v"(c));
+    }
+    else if constexpr (OP == OP_CMP_CNDMASK) {      // a compare that writes vcc and the select that reads it: two instructions per count
+        if (DEP) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");
+        else asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(a) : "v"(b), "v"(c) : "vcc");
     }
 #undef I3
 #undef I2
