@@ -16,7 +16,7 @@ L = X.load_library()
 buf = np.zeros(128, np.uint64)
 L.orbx_debug_oct_stamps(buf.ctypes.data_as(C.c_void_p))
 n = int(buf[0])
-names = {0: "start", 1: "roots+sweep0", 2: "node-level(ph1)", 3: "node-level(ph2)", 4: "build", 5: "sweep(if any)", 6: "final", 7: "tables", 8: "sweep0", 9: "pyramid"}
+names = {0: "start", 1: "count pyramid + first size", 2: "node-level(ph1)", 3: "node-level(ph2)", 4: "build", 5: "sweep(if any)", 6: "final", 7: "scan+roots+tables", 8: "sweep0", 9: "pyramid"}
 prev = None
 for i in range(n):
     t, sid = int(buf[1 + i]) >> 8, int(buf[1 + i]) & 0xff
