@@ -232,6 +232,152 @@ __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int ti
     resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
 }
 
+// ---- small batches: levels 2.. in ONE launch --------------------------------------------------------------------------------
+// The level-by-level chain costs one launch (~6 us of latency, whatever its size) per level.  While a batch cannot fill the chip
+// anyway, every 64-byte x 16-row tile of every level >= 2 is instead computed by one workgroup straight from level 1 (which
+// k_pyr_first has just written): it loads the region of level 1 it depends on into LDS and re-derives, level by level, the interior
+// pixels of the levels in between (host-computed rectangles, ChainTile::region), ping-ponging between two LDS buffers; the last step
+// writes the tile with its REFLECT_101 border bytes.  Every intermediate pixel goes through the same rounded u8 arithmetic as in the
+// chain of launches, so the levels are bit-identical; the redundant work (a level-7 tile recomputes ~30 k pixels for its 1 k) is
+// irrelevant at these batch sizes.  640x480, one frame: six launches of 6 us -> one of ~11 us.
+
+__device__ __forceinline__ unsigned resizePixel(const uint8_t* r0, const uint8_t* r1, int c0, int c1, int a0, int a1, int b0, int b1) {
+    const int h0 = __mul24(r0[c0], a0) + __mul24(r0[c1], a1);
+    const int h1 = __mul24(r1[c0], a0) + __mul24(r1[c1], a1);
+    return (unsigned)(((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2);
+}
+
+#ifdef ORBX_CHAIN_STAMPS
+__device__ unsigned long long g_chainStamps[32];
+#define CSTAMP(i) do { if (tid == 0 && t == (int)gridDim.y - 1) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chainStamps), sizeof(unsigned long long) * 32); }
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
+constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
+
+__global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
+                                                             const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
+                                                             uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    __shared__ ResizeX coef[kChainCoefMax];
+    int t, fr;
+    if (!xcdChunkFrame(nFrames, t, fr)) return;
+    const int f = f0 + fr, tid = threadIdx.x;
+    CSTAMP(0);
+    // (the tile record and the level table stay in memory and are read through wave-uniform loads: a by-value copy indexed by the
+    // step number would live in scratch)
+    const ChainTile& ct = tiles[t];
+    const int level = ct.level;
+    uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // region j lives in buf[j & 1]
+    const LevelGeom d = lv[level];
+    const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
+    // ---- every load of the tile is issued up front: level 1's region (aligned dwords from the bordered buffer) and the coefficient
+    //      records of ALL steps (x records of step j at coef[xo_j ..], y records behind them): fetched step by step, each step would
+    //      start with an L2 round trip ----
+    {
+        const LevelGeom g1 = lv[1];
+        const ChainRegion r = ct.region[1];
+        const int nDw = r.w >> 2;
+        const uint8_t* src = pyr + g1.pyrOff + (long long)f * g1.pyrFrameBytes + (long long)(kEdge + r.y0) * g1.pyrStride + kPadL + r.x0;
+        unsigned* dst = (unsigned*)buf[1];
+        const int c = min(tid & 63, nDw - 1), y0 = tid >> 6;
+        constexpr int kRowsPerThread = kChainMaxH / (kChainThreads / 64);
+        unsigned w[kRowsPerThread];
+#pragma unroll
+        for (int i = 0; i < kRowsPerThread; i++)
+            w[i] = *(const unsigned*)(src + (unsigned)(min(y0 + (kChainThreads / 64) * i, r.h - 1) * g1.pyrStride + 4 * c));
+        // coefficient records: the steps' records form one flat list (x records of step j, then its y records, step after step;
+        // step `level` is the tile itself); a thread fetches entries tid, tid + T, ... — all loads are issued before the first
+        // result is stored, whichever step an entry belongs to
+        constexpr int kPerThread = (kChainCoefMax + kChainThreads - 1) / kChainThreads;
+        ResizeX cv[kPerThread];
+        int off = 0;
+        for (int j = 2; j <= level; j++) {                  // thread-uniform walk over the steps
+            const int nx = j < level ? ct.region[j].w : 4 * kChainTileDw, ny = j < level ? ct.region[j].h : kChainTileRows;
+            const int rx0 = j < level ? ct.region[j].x0 : 0, ry0 = j < level ? ct.region[j].y0 : 0;
+            const ResizeX *xt = rxAll + lv[j].rxOff, *yt = ryAll + lv[j].ryOff;
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) {
+                const int i = tid + k * kChainThreads - off;
+                if (i >= 0 && i < nx + ny) {
+                    if (j < level) cv[k] = i < nx ? xt[rx0 + i] : yt[ry0 + i - nx];
+                    else if (i < nx) {
+                        int bx = 4 * ct.tileX * kChainTileDw + i - (kPadL - kEdge);
+                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);            // bytes of a dword outside the bordered row are padding
+                        cv[k] = xt[reflect101(bx - kEdge, d.w)];
+                    } else cv[k] = yt[reflect101(min(ct.tileY * kChainTileRows + i - nx, d.pyrRows - 1) - kEdge, d.h)];
+                }
+            }
+            off += nx + ny;
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++)
+            if (tid + k * kChainThreads < off) coef[tid + k * kChainThreads] = cv[k];
+#pragma unroll
+        for (int i = 0; i < kRowsPerThread; i++)
+            if ((tid & 63) < nDw && y0 + (kChainThreads / 64) * i < r.h) dst[(y0 + (kChainThreads / 64) * i) * nDw + c] = w[i];
+    }
+    __syncthreads();
+    CSTAMP(1);
+    // ---- the levels in between: interior pixels only ----
+    int off = 0;
+    for (int j = 2; j < level; j++) {
+        const ChainRegion rs = ct.region[j - 1], rd = ct.region[j];
+        const int ss = (rs.w + 3) & ~3, ds = (rd.w + 3) & ~3;
+        const uint8_t* S = buf[(j - 1) & 1];
+        uint8_t* D = buf[j & 1];
+        const ResizeX *cxs = coef + off, *cys = cxs + rd.w;
+        // a thread owns four adjacent columns (their coefficients stay in registers) and walks down every eighth row: sixteen
+        // independent byte reads per step instead of a pixel-by-pixel chain of LDS round trips; one dword store per step
+        const int x4 = 4 * (tid & 63);
+        if (x4 < rd.w) {
+            ResizeX cx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cx[k] = cxs[min(x4 + k, rd.w - 1)];
+#pragma unroll 2
+            for (int y = tid >> 6; y < rd.h; y += kChainThreads / 64) {
+                const ResizeX cy = cys[y];
+                const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
+                const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
+                unsigned o = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o |= resizePixel(r0, r1, cx[k].sx0, cx[k].sx1, cx[k].a0, cx[k].a1, cy.a0, cy.a1) << (8 * k);
+                *(unsigned*)(D + y * ds + x4) = o;      // (columns past the region's width are padding of the 4-aligned stride)
+            }
+        }
+        off += rd.w + rd.h;
+        __syncthreads();
+        CSTAMP(j);
+    }
+    // ---- the tile itself: bordered bytes, the border mirrors the interior (copyMakeBorder REFLECT_101 fused) ----
+    if (tid < kChainTileDw * kChainTileRows) {
+        const ChainRegion rs = ct.region[level - 1];
+        const int ss = (rs.w + 3) & ~3;
+        const uint8_t* S = buf[(level - 1) & 1];
+        const ResizeX *cxs = coef + off, *cys = cxs + 4 * kChainTileDw;
+        const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col, row = ct.tileY * kChainTileRows + (tid >> 4);
+        if (dw < nd && row < d.pyrRows) {
+            const ResizeX cy = cys[tid >> 4];
+            const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
+            const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
+            unsigned o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const ResizeX cx = cxs[4 * col + k];
+                o |= resizePixel(r0, r1, cx.sx0, cx.sx1, cx.a0, cx.a1, cy.a0, cy.a1) << (8 * k);
+            }
+            *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + 4 * dw) = o;
+        }
+    }
+    CSTAMP(level);
+}
+
+void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,
+                   uint8_t* pyr, int ldsBytes, int bufEvenBytes, int f0, int B) {
+    hipLaunchKernelGGL(k_pyr_rest, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+}
+
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,
                     const LevelGeom* g1, int tilesX0, int tilesY0, int tilesX1, int tilesY1, const ResizeX* xt,
                     const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {

@@ -20,6 +20,7 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
+void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*);
@@ -117,6 +118,9 @@ struct orbx_handle {
     LevelGeom* d_lv = nullptr;
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
+    ChainTile* d_chain = nullptr;       // tiles of the small-batch pyramid kernel
+    size_t chainCap = 0;
+    bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
@@ -200,7 +204,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -230,17 +234,18 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
     h->lastB = 0;
     h->lastHostB = 0;
-    HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
     size_t xo = 0, yo = 0;
     for (int l = 1; l < g.nlevels; l++) {
         h->rxOff[l] = xo; h->ryOff[l] = yo;
+        g.lv[l].rxOff = (int)xo; g.lv[l].ryOff = (int)yo;
         if (xo + g.rx[l].size() > h->rxCap || yo + g.ry[l].size() > h->rxCap)
             return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "resize tables do not fit");
         HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
         xo += g.rx[l].size(); yo += g.ry[l].size();
     }
+    HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
     size_t fo = 0;
     for (int l = 1; l < g.nlevels; l++) {
         h->footOff[l] = fo;
@@ -248,6 +253,8 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
         fo += g.foot[l].size();
     }
+    if (g.chain.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
+    if (!g.chain.empty()) HIP_TRY(h, hipMemcpy(h->d_chain, g.chain.data(), sizeof(ChainTile) * g.chain.size(), hipMemcpyHostToDevice));
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
@@ -348,11 +355,20 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                            g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
                            g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
         }
-        for (int l = 2; l < g.nlevels; l++) {
+        // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above), or - while the batch
+        // cannot fill the chip anyway - ONE launch in which every tile re-derives what it needs of the levels in between (k_pyr_rest)
+        const bool chain = h->pyrChain && g.nlevels > 2 && !g.chain.empty() && g.chainFits && g.chainLdsBytes <= 60 * 1024 &&
+                           (long long)g.chain.size() * Bn <= 12LL * h->numCUs;
+        if (chain) {
             Prof p(h, S_RESIZE, st);
-            launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
-                         h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
-                         g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
+            launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, f0, Bn);
+        } else {
+            for (int l = 2; l < g.nlevels; l++) {
+                Prof p(h, S_RESIZE, st);
+                launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
+                             h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
+                             g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
+            }
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
@@ -577,6 +593,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
     CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurItem) * h->tileCap));
     CREATE_TRY(hipMalloc(&h->d_laneItem, sizeof(unsigned short) * h->laneCap));
+    h->chainCap = roomy((size_t)(((max_width + 38 + 32 + 63) / 64 + 1) * ((max_height + 38 + 15) / 16 + 1)) * nlevels);
+    CREATE_TRY(hipMalloc(&h->d_chain, sizeof(ChainTile) * h->chainCap));
+    h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_TRY(hipMalloc(&h->d_foot, sizeof(TileFoot) * h->footCap));
     const size_t oc = (size_t)h->outCap * max_batch;

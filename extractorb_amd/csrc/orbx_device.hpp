@@ -44,6 +44,7 @@ struct LevelGeom {
     float scale;              // mvScaleFactor[level]
     int patchSize;            // keypoint size written to the output
     int cellFirst, cellCount; // this level's cells inside the per-frame cell table
+    int rxOff, ryOff;         // this level's resize coefficient records inside the handle's x / y tables (level >= 1)
 };
 
 struct CellDesc {             // one FAST cell == one cv::FAST call of the reference (ORBextractor.cc:818-819)
@@ -68,6 +69,15 @@ constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of 
 struct TileFoot { short fx0, nDw, fy0, nRows; };   // first source column (multiple of 4), dwords per row, first row, rows
 
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
+
+// Small-batch pyramid (k_pyr_rest): one 64-byte x 16-row tile of the bordered level `level` (>= 2) is computed by ONE workgroup straight
+// from level 1, re-deriving in LDS the interior pixels of the levels in between that it depends on.  region[j] (1 <= j < level) is the
+// rectangle of level j's interior the tile needs: x0 (a multiple of 4 for j = 1), y0, width, height.
+constexpr int kChainTileDw = 16;     // dword columns per tile
+constexpr int kChainTileRows = 16;
+constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
+struct ChainRegion { short x0, y0, w, h; };
+struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };
 
 #ifdef __HIPCC__
 // XCD-aware launch shape for "chunks x frames" grids: grid = (8, chunks, ceil(frames / 8)).
