@@ -129,21 +129,41 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
             sel[j] = 0x0C000C00u | (unsigned)(c0[j] - lo) | ((unsigned)(c1[j] - lo) << 16);
             wt[j] = u16x2{(unsigned short)a0[j], (unsigned short)a1[j]};
         }
-#pragma unroll 2
-        for (int r = 0; r < kPyrRows; r++) {
-            const unsigned* r0 = (const unsigned*)(tile + __mul24(cy[r].sx0 - fy0, ldsStride) + base);
-            const unsigned* r1 = (const unsigned*)(tile + __mul24(cy[r].sx1 - fy0, ldsStride) + base);
-            const unsigned b0 = (unsigned)cy[r].a0 << 12, b1 = (unsigned)cy[r].a1 << 12;
-            const unsigned p0 = r0[0], p1 = r0[1], p2 = r0[2], q0 = r1[0], q1 = r1[1], q2 = r1[2];
+        // Horizontal pass of ONE source row for the thread's four pixels (masked for the vertical pass's >> 4).  Consecutive destination
+        // rows share source rows (at scale 1.2 eight destination rows use ten distinct source rows, not sixteen), and the rows a
+        // destination row uses are the same for the whole wave (a wave = one row group), so the choice "reuse / compute" is a scalar
+        // branch: the horizontal pass runs once per distinct source row.
+        auto hrow = [&](int srow, unsigned (&h)[4]) {
+            const unsigned* rp = (const unsigned*)(tile + __mul24(srow - fy0, ldsStride) + base);
+            const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];
             const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
-            const unsigned Q0 = __builtin_amdgcn_alignbyte(q1, q0, sh), Q1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[j])), wt[j], 0u, false) & ~15u;
+        };
+        unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
+        int have0 = -1 << 20, have1 = -1 << 20;              // source rows held in H0 / H1
+#pragma unroll
+        for (int r = 0; r < kPyrRows; r++) {
+            const int s0 = __builtin_amdgcn_readfirstlane((int)cy[r].sx0), s1 = __builtin_amdgcn_readfirstlane((int)cy[r].sx1);
+            if (s0 != have0) {
+                if (s0 == have1) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) H0[j] = H1[j];
+                } else hrow(s0, H0);
+                have0 = s0;
+            }
+            if (s1 != have1) {
+                if (s1 == have0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) H1[j] = H0[j];
+                } else hrow(s1, H1);
+                have1 = s1;
+            }
+            const unsigned b0 = (unsigned)cy[r].a0 << 12, b1 = (unsigned)cy[r].a1 << 12;
             unsigned t[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[j])), wt[j], 0u, false);
-                const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(Q1, Q0, sel[j])), wt[j], 0u, false);
-                t[j] = mulHi24(b0, h0 & ~15u) + mulHi24(b1, h1 & ~15u) + 2u;
-            }
+            for (int j = 0; j < 4; j++) t[j] = mulHi24(b0, H0[j]) + mulHi24(b1, H1[j]) + 2u;
             const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
             if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);
         }

@@ -121,6 +121,7 @@ struct orbx_handle {
     ChainTile* d_chain = nullptr;       // tiles of the small-batch pyramid kernel
     size_t chainCap = 0;
     bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
+    long long pyrChainWgs = 0;          // ORBX_PYR_CHAIN_WGS: largest k_pyr_rest grid (workgroups) still preferred to the per-level launches
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
@@ -358,7 +359,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above), or - while the batch
         // cannot fill the chip anyway - ONE launch in which every tile re-derives what it needs of the levels in between (k_pyr_rest)
         const bool chain = h->pyrChain && g.nlevels > 2 && !g.chain.empty() && g.chainFits && g.chainLdsBytes <= 60 * 1024 &&
-                           (long long)g.chain.size() * Bn <= 12LL * h->numCUs;
+                           (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 12LL * h->numCUs);
         if (chain) {
             Prof p(h, S_RESIZE, st);
             launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, f0, Bn);
@@ -596,6 +597,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->chainCap = roomy((size_t)(((max_width + 38 + 32 + 63) / 64 + 1) * ((max_height + 38 + 15) / 16 + 1)) * nlevels);
     CREATE_TRY(hipMalloc(&h->d_chain, sizeof(ChainTile) * h->chainCap));
     h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
+    h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 12 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_TRY(hipMalloc(&h->d_foot, sizeof(TileFoot) * h->footCap));
     const size_t oc = (size_t)h->outCap * max_batch;
