@@ -1,7 +1,9 @@
 // k_project.hip — "next" row SURVEY.md §8f-2, second half: ORBmatcher::SearchByProjection on device-resident frames.
 //   (a) frame-to-frame, Tracking::TrackWithMotionModel   reference src/ORBmatcher.cc:1961-2177
 //   (b) map-to-frame,   Tracking::SearchLocalPoints       reference src/ORBmatcher.cc:44-267
-// both for Nleft == -1 (one descriptor set per frame: monocular, rectified stereo, RGB-D), with Frame::GetFeaturesInArea
+//   (c) keyframe-to-frame, Tracking::Relocalization        reference src/ORBmatcher.cc:2179-2300 (the search of (a) with the caller's
+//       distance bound ORBdist, every keypoint that already holds a MapPoint closed, no stereo column test)
+// all for Nleft == -1 (one descriptor set per frame: monocular, rectified stereo, RGB-D), with Frame::GetFeaturesInArea
 // (src/Frame.cc:655-724), ORBmatcher::DescriptorDistance (:2349-2365), ComputeThreeMaxima (:2303-2344) and Pinhole::project
 // (src/CameraModels/Pinhole.cpp:30-33).
 //
@@ -39,12 +41,12 @@ struct ProjectParams {
 
 struct ProjSearchParams {
     float minX, minY, wInv, hInv, nnRatio;
-    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep;
+    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep, maxDist;
 };
 
 namespace {
 constexpr int kCols = 64, kRows = 48, kCells = kCols * kRows;
-constexpr int kThHigh = 100, kHistoLength = 30;          // ORBmatcher.cc:36-38
+constexpr int kHistoLength = 30;                          // ORBmatcher.cc:38 (the distance bound, TH_HIGH = 100 or the caller's ORBdist, is a parameter)
 constexpr int kNoneKey = (256 << 16) | 0xFFFF;            // bestDist = 256, no position
 constexpr int kThreads = 256, kWaves = kThreads / 64;
 
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
             }
             parity ^= 1;
             const int bestDist = bkey >> 16, bs = bkey & 0xFFFF;
-            if (bestDist <= kThHigh) {                                                                         // :98 / :2058
+            if (bestDist <= p.maxDist) {                                                                       // :98 / :2058 / :2246
                 bool accept = true;
                 if (p.ratioMode) {      // only when best and second lie on the same level does the ratio apply (:100-104)
                     const int bestDist2 = bsecond >> 16;

@@ -58,7 +58,7 @@ struct ProjectParams {
 };
 struct ProjSearchParams {
     float minX, minY, wInv, hInv, nnRatio;
-    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep;
+    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep, maxDist;
 };
 size_t projSearchLdsBytes(int capacity);
 void launchProjectLast(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const float*, const float*, const ProjectParams&,
@@ -1115,11 +1115,11 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
                                      const uint8_t* d_query_desc, int desc_first, int desc_step, const int* d_n_queries, int query_capacity,
                                      const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int* d_n_out, int capacity,
                                      const int* d_grid_off, const int* d_grid_idx, const float* bounds4, const float* d_u_right,
-                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int check_orientation, int* d_matches,
-                                     int* d_n_matches) {
+                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int max_distance, int check_orientation,
+                                     int* d_matches, int* d_n_matches) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
     if (!d_queries || !d_query_desc || !d_kps_un || !d_desc || !d_n_out || !d_grid_off || !d_grid_idx || !bounds4 || !d_matches || !d_n_matches ||
-        capacity < 1 || query_capacity < 1 || n_pairs < 1 || cur_first < 0 || cur_step < 0 || desc_first < 0 || desc_step < 0 ||
+        capacity < 1 || query_capacity < 1 || n_pairs < 1 || cur_first < 0 || cur_step < 0 || desc_first < 0 || desc_step < 0 || max_distance < 0 ||
         !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/query_capacity/n_pairs < 1, negative frame index/step or empty bounds");
     if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
@@ -1132,7 +1132,7 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
     p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
     p.nnRatio = nn_ratio; p.ratioMode = ratio_mode != 0; p.checkOrientation = check_orientation != 0;
     p.capacity = capacity; p.queryCapacity = query_capacity; p.curFirst = cur_first; p.curStep = cur_step;
-    p.descFirst = desc_first; p.descStep = desc_step;
+    p.descFirst = desc_first; p.descStep = desc_step; p.maxDist = max_distance < 255 ? max_distance : 255;
     {
         Prof pr(h, S_FRAME);
         launchSearchProj(h->stream, (const ProjQuery*)d_queries, d_query_desc, d_n_queries, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off,

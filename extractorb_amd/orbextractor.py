@@ -141,7 +141,7 @@ def load_library():
     L.orbx_project_last_frame_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp,
                                                  C.c_float, C.c_float, C.c_float, C.c_int, vp]
     L.orbx_search_by_projection_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int,
-                                                   vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+                                                   vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
     L.orbx_vocabulary_load_text.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int]
     L.orbx_vocabulary_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int]
     L.orbx_vocabulary_destroy.argtypes = [vp]
@@ -432,7 +432,7 @@ class ORBextractor:
 
     def search_by_projection_device(self, n_pairs, cur, d_queries, d_query_desc, desc_blocks, d_n_queries, query_capacity, d_kps_un, d_desc,
                                     d_n, capacity, d_grid_off, d_grid_idx, bounds, d_u_right, d_occupied, ratio_mode, nnratio,
-                                    check_orientation, d_matches, d_n_matches):
+                                    check_orientation, d_matches, d_n_matches, max_distance=100):
         """ORBmatcher::SearchByProjection, the search (reference src/ORBmatcher.cc:2025-2175 / :44-135); cur and desc_blocks = (first, step)."""
         def dp(x):
             return C.c_void_p(0 if x is None else (x.data_ptr() if hasattr(x, "data_ptr") else int(x)))
@@ -440,7 +440,7 @@ class ORBextractor:
         self._check(self._L.orbx_search_by_projection_device(
             self._h, n_pairs, cur[0], cur[1], dp(d_queries), dp(d_query_desc), desc_blocks[0], desc_blocks[1], dp(d_n_queries), query_capacity,
             dp(d_kps_un), dp(d_desc), dp(d_n), capacity, dp(d_grid_off), dp(d_grid_idx), _ptr(bounds), dp(d_u_right), dp(d_occupied),
-            int(ratio_mode), nnratio, int(check_orientation), dp(d_matches), dp(d_n_matches)))
+            int(ratio_mode), nnratio, max_distance, int(check_orientation), dp(d_matches), dp(d_n_matches)))
 
     def compute_bow_device(self, vocab, n_frames, d_desc, d_n, capacity, d_word_ids, d_word_weights, d_n_words, d_feat_nodes, d_feat_idx,
                            d_n_feat, levels_up=4):

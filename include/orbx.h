@@ -249,6 +249,10 @@ int orbx_project_last_frame_device(orbx_handle* h, int n_pairs, int last_first, 
 /* The search itself, for n_pairs frames cur_first + p*cur_step of one device-resident batch.
  *   ratio_mode 0: SearchByProjection(CurrentFrame, LastFrame, ...) (src/ORBmatcher.cc:2025-2175): best candidate, TH_HIGH = 100, rotation
  *                 histogram when check_orientation;
+ *                 With max_distance = ORBdist, d_occupied = "mvpMapPoints[i2] != NULL", every request's flags bit 1 set and d_u_right = NULL
+ *                 this is also SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:2179-2300, Relocalization):
+ *                 the caller projects pKF's MapPoints (:2200-2226: bounds, distance invariance, PredictScale) into requests.
+ *   max_distance: the acceptance bound on the best descriptor distance: ORBmatcher::TH_HIGH = 100 for the first two forms (:98, :2058)
  *   ratio_mode 1: SearchByProjection(F, vpMapPoints, th, ...) (src/ORBmatcher.cc:44-135): best and second best, the ratio nn_ratio applies
  *                 only when both lie on the same pyramid level; the caller passes only MapPoints with mbTrackInView that are not bad and
  *                 pass the far-point test (:50-59), in vpMapPoints order.
@@ -264,8 +268,8 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
                                      const uint8_t* d_query_desc, int desc_first, int desc_step, const int* d_n_queries, int query_capacity,
                                      const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int* d_n_out, int capacity,
                                      const int* d_grid_off, const int* d_grid_idx, const float* bounds4, const float* d_u_right,
-                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int check_orientation, int* d_matches,
-                                     int* d_n_matches);
+                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int max_distance, int check_orientation,
+                                     int* d_matches, int* d_n_matches);
 
 /* ---- next row: Frame::ComputeBoW (src/Frame.cc:739-746) --------------------------------------------------
  * = DBoW2::TemplatedVocabulary<FORB>::transform(features, BowVector, FeatureVector, levelsup = 4)

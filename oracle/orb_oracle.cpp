@@ -1122,16 +1122,19 @@ void oracle_project_last_frame(const void* kpsLast_, const void* kpsUnLast_, int
     }
 }
 
+// (c) SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:2179-2300, Tracking::Relocalization) is the search
+// of (a) with maxDistance = ORBdist, occupied = "CurrentFrame.mvpMapPoints[i2] != NULL" (:2238-2239: any MapPoint closes a keypoint, so every
+// request carries flags bit 1), no stereo column test; its projection (:2200-2226) reads MapPoint state and stays with the caller.
 // The search half, shared by (a) and (b).  ratioMode 0 = (a): best candidate only, TH_HIGH (:2028-2062), rotation histogram
 // (:2064-2080, :2155-2175).  ratioMode 1 = (b): best + second with the level rule and mfNNratio (:85-132), no histogram.
 // occupied[i2] (in/out, may be NULL = all free): CurrentFrame.mvpMapPoints[i2] is set and has Observations() > 0.
 // matches[i2] (out): index of the query whose MapPoint the keypoint ends up holding, -1 = none.  Returns nmatches.
 int oracle_search_by_projection(const void* queries_, const uint8_t* qdesc, int NQ, const void* kpsUn_, const uint8_t* desc, int N,
                                 const int* gridOff, const int* gridIdx, const float* bounds, const float* uRight, uint8_t* occupied,
-                                int ratioMode, float nnratio, int checkOrientation, int* matches) {
+                                int ratioMode, float nnratio, int maxDistance, int checkOrientation, int* matches) {
     const ProjQuery* q = (const ProjQuery*)queries_;
     const KeyPoint* kUn = (const KeyPoint*)kpsUn_;
-    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    const int TH_HIGH = maxDistance, HISTO_LENGTH = 30;      // ORBmatcher::TH_HIGH = 100 (:36) in (a) and (b); ORBdist in the relocalisation form (:2246)
     std::vector<uint8_t> occ(N, 0);
     if (occupied) occ.assign(occupied, occupied + N);
     int nmatches = 0;

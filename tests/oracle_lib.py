@@ -78,7 +78,7 @@ def lib():
         L.oracle_project_last_frame.restype = None
         L.oracle_project_last_frame.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, vp]
         L.oracle_search_by_projection.restype = C.c_int
-        L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
+        L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
         L.oracle_compute_bow.restype = C.c_int
         L.oracle_compute_bow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, ip]
         L.oracle_stereo_from_rgbd.restype = None
@@ -244,7 +244,7 @@ def project_last_frame(kps_last, kps_un_last, mp_flags, world, Tcw, Tlw, cam, bo
 
 
 def search_by_projection(queries, qdesc, kps_un, desc, grid_off, grid_idx, bounds, u_right=None, occupied=None, ratio_mode=False,
-                         nnratio=0.9, check_orientation=True):
+                         nnratio=0.9, check_orientation=True, max_distance=100):
     """ORBmatcher::SearchByProjection, the search half (reference src/ORBmatcher.cc:2025-2175 with ratio_mode False, :60-135 with True).
     Returns (nmatches, matches[N] = request index per keypoint or -1, occupied[N] afterwards)."""
     q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); ku = np.ascontiguousarray(kps_un, KEYPOINT_DTYPE)
@@ -256,7 +256,7 @@ def search_by_projection(queries, qdesc, kps_un, desc, grid_off, grid_idx, bound
     gi = np.ascontiguousarray(grid_idx, np.int32) if len(grid_idx) else np.zeros(1, np.int32)
     n = lib().oracle_search_by_projection(_ptr(q), _ptr(qd), len(q), _ptr(ku), _ptr(d), N, _ptr(np.ascontiguousarray(grid_off, np.int32)), _ptr(gi),
                                           _ptr(np.ascontiguousarray(bounds, np.float32)), None if ur is None else _ptr(ur), _ptr(occ),
-                                          int(ratio_mode), nnratio, int(check_orientation), _ptr(m))
+                                          int(ratio_mode), nnratio, max_distance, int(check_orientation), _ptr(m))
     return n, m[:N].copy(), occ[:N].copy()
 
 

@@ -62,7 +62,7 @@ def make_map(last, depth, rng, valid=0.75, with_obs=0.9, desc_flip=3):
     return flags, world, mpd
 
 
-def brute_search(q, qd, un, d, inside_pos, bounds, ur, occ0, ratio, nnratio, check):
+def brute_search(q, qd, un, d, inside_pos, bounds, ur, occ0, ratio, nnratio, check, max_dist=100):
     """Independent statement on Python containers: candidates = brute-force box + level test over the keypoints inside the grid, in
     grid order; sequential best / second; acceptance; occupancy; rotation histogram."""
     N = len(un)
@@ -103,7 +103,7 @@ def brute_search(q, qd, un, d, inside_pos, bounds, ur, occ0, ratio, nnratio, che
                 best2, best, bl2, bl, bi = best, dist, bl, int(un["octave"][i2]), i2
             elif ratio and dist < best2:
                 bl2, best2 = int(un["octave"][i2]), dist
-        if not any_cand or best > 100:
+        if not any_cand or best > max_dist:
             continue
         if ratio and bl == bl2 and np.float32(best) > np.float32(nnratio) * np.float32(best2):
             continue
@@ -162,15 +162,17 @@ def random_scene(rng, n=900, nq=700, ratio=False):
     return dict(un=un, d=d, off=off, idx=idx, bounds=b, q=q, qd=qd, ur=ur, occ=occ)
 
 
-@pytest.mark.parametrize("seed,ratio,stereo,check", [(1, False, False, True), (2, False, True, True), (3, True, True, False), (4, True, False, False),
-                                                     (5, False, True, False)])
-def test_oracle_search_equals_brute_force(seed, ratio, stereo, check):
+@pytest.mark.parametrize("seed,ratio,stereo,check,maxd", [(1, False, False, True, 100), (2, False, True, True, 100), (3, True, True, False, 100),
+                                                          (4, True, False, False, 100), (5, False, True, False, 100), (7, False, False, True, 64)])
+def test_oracle_search_equals_brute_force(seed, ratio, stereo, check, maxd):
     rng = np.random.default_rng(seed)
     s = random_scene(rng, ratio=ratio)
+    if maxd != 100:      # the relocalisation form (ORBmatcher.cc:2179-2300): ORBdist, every MapPoint closes its keypoint
+        s["q"]["flags"] |= 2
     inside_pos = {int(i): p for p, i in enumerate(s["idx"])}
     nm, m, occ = O.search_by_projection(s["q"], s["qd"], s["un"], s["d"], s["off"], s["idx"], s["bounds"], s["ur"] if stereo else None,
-                                        s["occ"], ratio, 0.8, check)
-    bn, bm, bocc = brute_search(s["q"], s["qd"], s["un"], s["d"], inside_pos, s["bounds"], s["ur"] if stereo else None, s["occ"], ratio, 0.8, check)
+                                        s["occ"], ratio, 0.8, check, maxd)
+    bn, bm, bocc = brute_search(s["q"], s["qd"], s["un"], s["d"], inside_pos, s["bounds"], s["ur"] if stereo else None, s["occ"], ratio, 0.8, check, maxd)
     assert m.tolist() == bm and nm == bn and occ.tolist() == bocc
     assert nm > 50                                        # the scene is built so that many requests find their keypoint
 
@@ -241,13 +243,16 @@ def _frames_to_device(prods, cap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,ratio,stereo,check", [(1, False, False, True), (2, False, True, True), (3, True, True, False), (4, True, False, False),
-                                                     (6, False, True, False)])
-def test_gpu_search_equals_oracle_on_random_scenes(seed, ratio, stereo, check):
+@pytest.mark.parametrize("seed,ratio,stereo,check,maxd", [(1, False, False, True, 100), (2, False, True, True, 100), (3, True, True, False, 100),
+                                                          (4, True, False, False, 100), (6, False, True, False, 100), (8, False, False, True, 64)])
+def test_gpu_search_equals_oracle_on_random_scenes(seed, ratio, stereo, check, maxd):
     import torch
     P, cap, qcap = 3, 1024, 768
     rng = np.random.default_rng(seed)
     scenes = [random_scene(rng, n=int(rng.integers(500, 1000)), nq=int(rng.integers(300, 768)), ratio=ratio) for _ in range(P)]
+    if maxd != 100:      # the relocalisation form: ORBdist, every MapPoint closes its keypoint
+        for s in scenes:
+            s["q"]["flags"] |= 2
     dev = _frames_to_device([dict(un=s["un"], d=s["d"], off=s["off"], idx=s["idx"]) for s in scenes], cap)
     q = np.zeros((P, qcap), O.PROJ_QUERY_DTYPE); qd = np.zeros((P, qcap, 32), np.uint8); nq = np.zeros(P, np.int32)
     ur = np.full((P, cap), -1.0, np.float32); occ = np.zeros((P, cap), np.uint8)
@@ -258,11 +263,11 @@ def test_gpu_search_equals_oracle_on_random_scenes(seed, ratio, stereo, check):
     d_m = torch.full((P, cap), -7, dtype=torch.int32, device="cuda"); d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
     ex = X.ORBextractor(1000)
     ex.search_by_projection_device(P, (0, 1), _dev(q.view(np.uint8)), _dev(qd), (0, 1), _dev(nq), qcap, dev["un"], dev["d"], dev["n"], cap,
-                                   dev["off"], dev["idx"], scenes[0]["bounds"], _dev(ur) if stereo else None, d_occ, ratio, 0.8, check, d_m, d_nm)
+                                   dev["off"], dev["idx"], scenes[0]["bounds"], _dev(ur) if stereo else None, d_occ, ratio, 0.8, check, d_m, d_nm, max_distance=maxd)
     ex.synchronize()
     for p, s in enumerate(scenes):
         nm, m, o = O.search_by_projection(s["q"], s["qd"], s["un"], s["d"], s["off"], s["idx"], s["bounds"], s["ur"] if stereo else None,
-                                          s["occ"], ratio, 0.8, check)
+                                          s["occ"], ratio, 0.8, check, maxd)
         n = len(s["un"])
         assert int(d_nm[p]) == nm, "pair %d" % p
         assert d_m[p, :n].cpu().numpy().tolist() == m.tolist(), "pair %d" % p
