@@ -269,13 +269,14 @@ __device__ __forceinline__ unsigned resizePixel(const uint8_t* r0, const uint8_t
 
 #ifdef ORBX_CHAIN_STAMPS
 __device__ unsigned long long g_chainStamps[32];
-#define CSTAMP(i) do { if (tid == 0 && t == (int)gridDim.y - 1) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMP(i) do { if (tid == 0 && t == 0) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chainStamps), sizeof(unsigned long long) * 32); }
 #else
 #define CSTAMP(i) do {} while (0)
 #endif
 constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
 
+template <bool PACKED>
 __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
                                                              const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
                                                              uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
@@ -348,6 +349,66 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
         const uint8_t* S = buf[(j - 1) & 1];
         uint8_t* D = buf[j & 1];
         const ResizeX *cxs = coef + off, *cys = cxs + rd.w;
+        if constexpr (PACKED) {
+            // (the host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)  A thread owns four
+            // adjacent columns over a block of consecutive rows, so that — as in resizeTile — the horizontal pass of a source row
+            // (three LDS dwords, two v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it:
+            // ~10 vector instructions per pixel instead of ~35 byte by byte.  The regions narrow from ~50 column quads to ~20 along
+            // the chain, so threads are dealt quad-major (thread = row block * quads + quad): every step keeps most of the 512
+            // threads busy, each with few rows.  The steps of a level-7 tile re-derive ~30 k pixels; they are its critical path.
+            const int nq = (rd.w + 3) >> 2, nb = kChainThreads / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
+            const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
+            if (blk < nb && yb < ye) {
+                int c0[4], c1[4];
+                u16x2 wt[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const ResizeX cx = cxs[min(x4 + k, rd.w - 1)];
+                    c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
+                    wt[k] = u16x2{(unsigned short)cx.a0, (unsigned short)cx.a1};
+                }
+                const int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
+                const int base = lo & ~3;
+                const unsigned sh = (unsigned)(lo & 3);
+                unsigned sel[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
+                auto hrow = [&](int srow, unsigned (&h)[4]) {
+                    const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
+                    const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
+                    const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
+                };
+                unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
+                int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
+                for (int y = yb; y < ye; y++) {
+                    const ResizeX cy = cys[y];
+                    const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
+                    if (s0 != have0) {
+                        if (s0 == have1) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) H0[k] = H1[k];
+                        } else hrow(s0, H0);
+                        have0 = s0;
+                    }
+                    if (s1 != have1) {
+                        if (s1 == have0) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) H1[k] = H0[k];
+                        } else hrow(s1, H1);
+                        have1 = s1;
+                    }
+                    const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
+                    unsigned t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
+                    const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
+                    *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
+                }
+            }
+        } else {
         // a thread owns four adjacent columns (their coefficients stay in registers) and walks down every eighth row: sixteen
         // independent byte reads per step instead of a pixel-by-pixel chain of LDS round trips; one dword store per step
         const int x4 = 4 * (tid & 63);
@@ -365,6 +426,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
                 for (int k = 0; k < 4; k++) o |= resizePixel(r0, r1, cx[k].sx0, cx[k].sx1, cx[k].a0, cx[k].a1, cy.a0, cy.a1) << (8 * k);
                 *(unsigned*)(D + y * ds + x4) = o;      // (columns past the region's width are padding of the 4-aligned stride)
             }
+        }
         }
         off += rd.w + rd.h;
         __syncthreads();
@@ -394,8 +456,9 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
 }
 
 void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,
-                   uint8_t* pyr, int ldsBytes, int bufEvenBytes, int f0, int B) {
-    hipLaunchKernelGGL(k_pyr_rest, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+                   uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
+    if (packed) hipLaunchKernelGGL(k_pyr_rest<true>, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+    else hipLaunchKernelGGL(k_pyr_rest<false>, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,

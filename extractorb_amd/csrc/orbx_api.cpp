@@ -20,7 +20,7 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
-void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, int, int);
+void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*);
@@ -363,7 +363,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                            (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 12LL * h->numCUs);
         if (chain) {
             Prof p(h, S_RESIZE, st);
-            launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, f0, Bn);
+            launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, g.chainPacked && !h->resizeBytewise, f0, Bn);
         } else {
             for (int l = 2; l < g.nlevels; l++) {
                 Prof p(h, S_RESIZE, st);

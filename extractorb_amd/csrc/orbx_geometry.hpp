@@ -116,6 +116,7 @@ struct FrameGeom {
     long long sumPixels = 0;                 // S of SURVEY.md §8d
     std::vector<ChainTile> chain;            // tiles of levels 2.. for the small-batch pyramid kernel (k_pyr_rest)
     bool chainFits = true;                   // every intermediate region within kChainMaxW x kChainMaxH
+    bool chainPacked = true;                 // the 8 taps of any four adjacent columns of a level >= 2 lie within 8 source bytes (k_pyr_rest<true>)
     int chainLdsBytes = 0, chainEvenBytes = 0;   // two ping-pong region buffers able to hold the largest regions (even-level buffer first)
 };
 
@@ -285,6 +286,20 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         }
         g.chainEvenBytes = (maxEven + 15) & ~15;
         g.chainLdsBytes = g.chainEvenBytes + ((maxOdd + 15) & ~15) + 32;
+        // the packed horizontal pass of the in-between steps: region columns start anywhere, so every group of four adjacent
+        // columns is checked (the last step, the tile itself, goes byte by byte)
+        for (int l = 2; l < t.nlevels - 1 && g.chainPacked; l++) {
+            const std::vector<ResizeX>& X = g.rx[l];
+            const int w = g.lv[l].w;
+            for (int x = 0; x < w && g.chainPacked; x++) {
+                int lo = 1 << 30, hi = -1;
+                for (int k = 0; k < 4; k++) {
+                    const ResizeX& c = X[std::min(x + k, w - 1)];
+                    lo = std::min(lo, (int)std::min(c.sx0, c.sx1)); hi = std::max(hi, (int)std::max(c.sx0, c.sx1));
+                }
+                if (hi - lo > 7) g.chainPacked = false;
+            }
+        }
     }
     return std::string();
 }
