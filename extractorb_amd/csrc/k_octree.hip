@@ -116,7 +116,9 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 // Queued variants (large batches): 1024 and 512 threads are compiled for 8 waves per SIMD (64 VGPRs: two 1024-thread or four
 // 512-thread workgroups per CU), 256 threads for 6 (80 VGPRs, fewer values in scratch; LDS allows six such workgroups per CU
 // anyway): 179 -> 169 us per 512 frames at 640x480; the same budget on the 1024-thread variant halves its residency (1080p: 282 -> 310 us).
+#ifndef OCT_SHORT_PHASE2
 #define OCT_SHORT_PHASE2 (OCT_W <= 4)
+#endif
 #define OCT_W 8
 #define OCT_T 1024
 #define OCT_NAME(x) x##_1024
