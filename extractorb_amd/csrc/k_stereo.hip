@@ -48,9 +48,7 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(const Keypoint* __restrict
     const int per = (rows + 1023) / 1024, b0 = tid * per, e0 = min(b0 + per, rows);
     int sum = 0;
     for (int i = b0; i < e0; i++) sum += cnt[i];
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int incl = waveInclusiveScan(sum);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     int off = 0;

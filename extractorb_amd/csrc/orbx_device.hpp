@@ -80,6 +80,21 @@ struct ChainRegion { short x0, y0, w, h; };
 struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };
 
 #ifdef __HIPCC__
+// Inclusive prefix sum over the 64 lanes of a wave, every lane active: row_shr 1/2/4/8 inside the rows of 16, then lane 15 of
+// rows 0 and 2 broadcast into rows 1 and 3, lane 31 into rows 2 and 3 (DPP: six vector adds, no LDS round trip — a __shfl_up
+// ladder is six dependent ds_bpermute).  A lane with no source takes 0 (`old` of v_mov_dpp with bound_ctrl off).
+__device__ __forceinline__ int waveInclusiveScan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#endif
+
+#ifdef __HIPCC__
 // XCD-aware launch shape for "chunks x frames" grids: grid = (8, chunks, ceil(frames / 8)).
 // Workgroups are dealt round-robin to the 8 XCDs by linear id (MI355X_MICROARCH.md, Workgroup dispatch): ids b and b + 8
 // share an XCD and its private 4-MiB L2.  With chunks fastest, the chunks of one frame are sprayed over all eight L2s, so
