@@ -276,10 +276,14 @@ extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)
 #endif
 constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
 
-template <bool PACKED>
-__global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
-                                                             const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
-                                                             uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
+// FROM_IMAGE (k_pyr_all's form): the chains start at the caller's image instead of level 1 — the tile list then holds the tiles of
+// level 1 (one step) and of level 0 (a bordered copy) too, and the WHOLE pyramid is one launch: one frame at 640x480 no longer waits
+// for k_pyr_first (7 us) before its chains start; a level-7 tile pays one more step (~13 k pixels) for it.
+template <bool PACKED, bool FROM_IMAGE>
+__global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const ChainTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
+                                                              const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
+                                                              uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
+    constexpr int kStart = FROM_IMAGE ? 0 : 1;          // the level whose region is loaded from HBM
     extern __shared__ __align__(16) uint8_t lds[];
     __shared__ ResizeX coef[kChainCoefMax];
     int t, fr;
@@ -293,28 +297,72 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
     uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // region j lives in buf[j & 1]
     const LevelGeom d = lv[level];
     const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
-    // ---- every load of the tile is issued up front: level 1's region (aligned dwords from the bordered buffer) and the coefficient
-    //      records of ALL steps (x records of step j at coef[xo_j ..], y records behind them): fetched step by step, each step would
-    //      start with an L2 round trip ----
-    {
-        const LevelGeom g1 = lv[1];
-        const ChainRegion r = ct.region[1];
-        const int nDw = r.w >> 2;
-        const uint8_t* src = pyr + g1.pyrOff + (long long)f * g1.pyrFrameBytes + (long long)(kEdge + r.y0) * g1.pyrStride + kPadL + r.x0;
-        unsigned* dst = (unsigned*)buf[1];
-        const int c = min(tid & 63, nDw - 1), y0 = tid >> 6;
-        constexpr int kRowsPerThread = kChainMaxH / (kChainThreads / 64);
-        unsigned w[kRowsPerThread];
+    if constexpr (FROM_IMAGE) {
+        if (level == 0) {      // bordered level 0 = the caller's image with a 19-px REFLECT_101 frame (:1213-1215), one dword per thread
+            const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col, row = ct.tileY * kChainTileRows + (tid >> 4);
+            if (tid < kChainTileDw * kChainTileRows && dw < nd && row < d.pyrRows) {
+                const int bc0 = 4 * dw, x0 = bc0 - kPadL;       // interior x of the dword's first byte (a multiple of 4)
+                const uint8_t* srow = img.p + (long long)f * img.frame + (long long)reflect101(row - kEdge, d.h) * img.stride;
+                unsigned o;
+                if (img.aligned && x0 >= 0 && x0 + 3 < d.w) o = *(const unsigned*)(srow + x0);      // no reflection inside this dword
+                else {
+                    o = 0;
 #pragma unroll
-        for (int i = 0; i < kRowsPerThread; i++)
-            w[i] = *(const unsigned*)(src + (unsigned)(min(y0 + (kChainThreads / 64) * i, r.h - 1) * g1.pyrStride + 4 * c));
+                    for (int k = 0; k < 4; k++) {
+                        int bx = bc0 + k - (kPadL - kEdge);
+                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);      // bytes of a dword outside the bordered row are padding
+                        o |= (unsigned)srow[reflect101(bx - kEdge, d.w)] << (8 * k);
+                    }
+                }
+                *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + bc0) = o;
+            }
+            return;
+        }
+    }
+    // ---- every load of the tile is issued up front: the first region (aligned dwords of level 1's bordered buffer, or of the
+    //      caller's image) and the coefficient records of ALL steps (x records of step j at coef[xo_j ..], y records behind them):
+    //      fetched step by step, each step would start with an L2 round trip ----
+    {
+        const ChainRegion r = ct.region[kStart];
+        const int nDw = r.w >> 2, total = nDw * r.h;
+        const uint8_t* src;
+        int srcStride;
+        if constexpr (FROM_IMAGE) {
+            src = img.p + (long long)f * img.frame + (long long)r.y0 * img.stride + r.x0;
+            srcStride = img.stride;
+        } else {
+            const LevelGeom g1 = lv[1];
+            src = pyr + g1.pyrOff + (long long)f * g1.pyrFrameBytes + (long long)(kEdge + r.y0) * g1.pyrStride + kPadL + r.x0;
+            srcStride = g1.pyrStride;
+        }
+        unsigned* dst = (unsigned*)buf[kStart & 1];
+        // the region's dwords are dealt flat (dword i of the region = row i / nDw, column i % nDw; the LDS copy is contiguous in i)
+        constexpr int kLoads = ((FROM_IMAGE ? kChainMaxH0 : kChainMaxH) * kChainMaxW / 4 + kChainThreads - 1) / kChainThreads;
+        const float inv = __frcp_rn((float)nDw);
+        unsigned w[kLoads];
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+            const int idx = min(tid + i * kChainThreads, total - 1);          // clamped: every lane loads a valid address
+            const int row = (int)(((float)idx + 0.5f) * inv), c = idx - row * nDw;      // exact: idx < 6144, the quotient is >= 0.5 / nDw away from an integer
+            const uint8_t* q = src + ((unsigned)__mul24(row, srcStride) + 4u * (unsigned)c);
+            if constexpr (FROM_IMAGE) {
+                const int x = r.x0 + 4 * c;
+                if (img.aligned && x + 3 < img.readableCols) w[i] = *(const unsigned*)q;
+                else {                                                          // a row's last dword, or an unaligned image: no byte past the row is read
+                    w[i] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (x + b < img.readableCols) w[i] |= (unsigned)q[b] << (8 * b);
+                }
+            } else w[i] = *(const unsigned*)q;
+        }
         // coefficient records: the steps' records form one flat list (x records of step j, then its y records, step after step;
         // step `level` is the tile itself); a thread fetches entries tid, tid + T, ... — all loads are issued before the first
         // result is stored, whichever step an entry belongs to
         constexpr int kPerThread = (kChainCoefMax + kChainThreads - 1) / kChainThreads;
         ResizeX cv[kPerThread];
         int off = 0;
-        for (int j = 2; j <= level; j++) {                  // thread-uniform walk over the steps
+        for (int j = kStart + 1; j <= level; j++) {         // thread-uniform walk over the steps
             const int nx = j < level ? ct.region[j].w : 4 * kChainTileDw, ny = j < level ? ct.region[j].h : kChainTileRows;
             const int rx0 = j < level ? ct.region[j].x0 : 0, ry0 = j < level ? ct.region[j].y0 : 0;
             const ResizeX *xt = rxAll + lv[j].rxOff, *yt = ryAll + lv[j].ryOff;
@@ -336,14 +384,14 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
         for (int k = 0; k < kPerThread; k++)
             if (tid + k * kChainThreads < off) coef[tid + k * kChainThreads] = cv[k];
 #pragma unroll
-        for (int i = 0; i < kRowsPerThread; i++)
-            if ((tid & 63) < nDw && y0 + (kChainThreads / 64) * i < r.h) dst[(y0 + (kChainThreads / 64) * i) * nDw + c] = w[i];
+        for (int i = 0; i < kLoads; i++)
+            if (tid + i * kChainThreads < total) dst[tid + i * kChainThreads] = w[i];
     }
     __syncthreads();
     CSTAMP(1);
     // ---- the levels in between: interior pixels only ----
     int off = 0;
-    for (int j = 2; j < level; j++) {
+    for (int j = kStart + 1; j < level; j++) {
         const ChainRegion rs = ct.region[j - 1], rd = ct.region[j];
         const int ss = (rs.w + 3) & ~3, ds = (rd.w + 3) & ~3;
         const uint8_t* S = buf[(j - 1) & 1];
@@ -457,8 +505,18 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_rest(const ChainTile* __r
 
 void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,
                    uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
-    if (packed) hipLaunchKernelGGL(k_pyr_rest<true>, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
-    else hipLaunchKernelGGL(k_pyr_rest<false>, xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+    const SrcView none{};
+    if (packed) hipLaunchKernelGGL((k_pyr_chain<true, false>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, none, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+    else hipLaunchKernelGGL((k_pyr_chain<false, false>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, none, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+}
+// the whole pyramid (levels 0 .. nlevels-1) from the caller's image in one launch
+void launchPyrAll(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const ChainTile* tiles, int nTiles,
+                  const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
+    SrcView sv;
+    sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
+    sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
+    if (packed) hipLaunchKernelGGL((k_pyr_chain<true, true>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, sv, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
+    else hipLaunchKernelGGL((k_pyr_chain<false, true>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, sv, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,

@@ -21,6 +21,7 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
 void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
+void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*);
@@ -119,6 +120,8 @@ struct orbx_handle {
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
     ChainTile* d_chain = nullptr;       // tiles of the small-batch pyramid kernel
+    ChainTile* d_chainAll = nullptr;    // tiles of the one-launch pyramid (smallest batches)
+    long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
     size_t chainCap = 0;
     bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
     long long pyrChainWgs = 0;          // ORBX_PYR_CHAIN_WGS: largest k_pyr_rest grid (workgroups) still preferred to the per-level launches
@@ -206,7 +209,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -257,6 +260,8 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     }
     if (g.chain.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
     if (!g.chain.empty()) HIP_TRY(h, hipMemcpy(h->d_chain, g.chain.data(), sizeof(ChainTile) * g.chain.size(), hipMemcpyHostToDevice));
+    if (g.chainAll.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
+    if (!g.chainAll.empty()) HIP_TRY(h, hipMemcpy(h->d_chainAll, g.chainAll.data(), sizeof(ChainTile) * g.chainAll.size(), hipMemcpyHostToDevice));
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
@@ -351,6 +356,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
     auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
     auto front = [&](hipStream_t st, int f0, int Bn) {
+        // smallest batches (one or two frames): the whole pyramid in ONE launch, every tile of every level derived from the caller's image
+        const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
+                         (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
+        if (all) {
+            Prof p(h, S_RESIZE, st);
+            launchPyrAll(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_chainAll, (int)g.chainAll.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr,
+                         g.chainAllLdsBytes, g.chainAllEvenBytes, g.chainAllPacked && !h->resizeBytewise, f0, Bn);
+        } else {
         {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
             Prof p(h, S_LEVEL0, st);
             launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
@@ -371,6 +384,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                              h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                              g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
             }
+        }
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
@@ -597,6 +611,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipMalloc(&h->d_laneItem, sizeof(unsigned short) * h->laneCap));
     h->chainCap = roomy((size_t)(((max_width + 38 + 32 + 63) / 64 + 1) * ((max_height + 38 + 15) / 16 + 1)) * nlevels);
     CREATE_TRY(hipMalloc(&h->d_chain, sizeof(ChainTile) * h->chainCap));
+    CREATE_TRY(hipMalloc(&h->d_chainAll, sizeof(ChainTile) * h->chainCap));
+    h->pyrAllWgs = getenv("ORBX_PYR_ALL_WGS") ? atoll(getenv("ORBX_PYR_ALL_WGS")) : 0;
     h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
     h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 12 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);

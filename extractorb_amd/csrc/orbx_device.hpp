@@ -75,7 +75,7 @@ struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) an
 // rectangle of level j's interior the tile needs: x0 (a multiple of 4 for j = 1), y0, width, height.
 constexpr int kChainTileDw = 16;     // dword columns per tile
 constexpr int kChainTileRows = 16;
-constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
+constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainMaxH0 = 96, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
 struct ChainRegion { short x0, y0, w, h; };
 struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };
 

@@ -117,6 +117,9 @@ struct FrameGeom {
     std::vector<ChainTile> chain;            // tiles of levels 2.. for the small-batch pyramid kernel (k_pyr_rest)
     bool chainFits = true;                   // every intermediate region within kChainMaxW x kChainMaxH
     bool chainPacked = true;                 // the 8 taps of any four adjacent columns of a level >= 2 lie within 8 source bytes (k_pyr_rest<true>)
+    std::vector<ChainTile> chainAll;         // tiles of EVERY level for the one-launch pyramid (k_pyr_all: regions down to the caller's image)
+    bool chainAllFits = true, chainAllPacked = true;
+    int chainAllLdsBytes = 0, chainAllEvenBytes = 0;
     int chainLdsBytes = 0, chainEvenBytes = 0;   // two ping-pong region buffers able to hold the largest regions (even-level buffer first)
 };
 
@@ -237,69 +240,81 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
             }
         }
     }
-    // ---- small-batch pyramid: per tile of levels >= 2, the chain of source regions down to level 1 ----
+    // ---- small-batch pyramid: per 64-byte x 16-row tile of a level, the chain of source regions down to the level the kernel
+    //      loads: level 1 (k_pyr_rest after k_pyr_first: tiles of levels >= 2) or the caller's image (k_pyr_all: tiles of every
+    //      level; a level-0 tile is a bordered copy and has no regions) ----
     {
         auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
-        int maxEven = 0, maxOdd = 0;     // bytes of the largest region kept in buffer (j & 1)
-        for (int l = t.nlevels - 1; l >= 2; l--) {      // coarsest level first: its tiles have the longest chains and should start first
-            const LevelGeom& L = g.lv[l];
-            const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
-            const int tx = (nd + kChainTileDw - 1) / kChainTileDw, ty = (L.pyrRows + kChainTileRows - 1) / kChainTileRows;
-            for (int iy = 0; iy < ty; iy++)
-                for (int ix = 0; ix < tx; ix++) {
-                    ChainTile c{};
-                    c.level = (short)l; c.tileX = (short)ix; c.tileY = (short)iy;
-                    // interior hull of the tile's bordered bytes / rows (the kernel clamps and reflects exactly like this)
-                    int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
-                    for (int b = ix * kChainTileDw * 4; b < (ix + 1) * kChainTileDw * 4; b++) {
-                        int bx = b - (kPadL - kEdge);
-                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
-                        const int v = refl(bx - kEdge, L.w);
-                        x0 = std::min(x0, v); x1 = std::max(x1, v);
+        auto build = [&](int start, std::vector<ChainTile>& out, bool& fits, int& ldsBytes, int& evenBytes, int maxW, int maxH) {
+            int maxEven = 0, maxOdd = 0;     // bytes of the largest region kept in buffer (j & 1)
+            for (int l = t.nlevels - 1; l >= start; l--) {      // coarsest level first: its tiles have the longest chains and should start first
+                const LevelGeom& L = g.lv[l];
+                const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
+                const int tx = (nd + kChainTileDw - 1) / kChainTileDw, ty = (L.pyrRows + kChainTileRows - 1) / kChainTileRows;
+                if (l == start && start != 0) break;            // (the loaded level itself is written by k_pyr_first)
+                for (int iy = 0; iy < ty; iy++)
+                    for (int ix = 0; ix < tx; ix++) {
+                        ChainTile c{};
+                        c.level = (short)l; c.tileX = (short)ix; c.tileY = (short)iy;
+                        // interior hull of the tile's bordered bytes / rows (the kernel clamps and reflects exactly like this)
+                        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+                        for (int b = ix * kChainTileDw * 4; b < (ix + 1) * kChainTileDw * 4; b++) {
+                            int bx = b - (kPadL - kEdge);
+                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                            const int v = refl(bx - kEdge, L.w);
+                            x0 = std::min(x0, v); x1 = std::max(x1, v);
+                        }
+                        for (int r = iy * kChainTileRows; r < (iy + 1) * kChainTileRows; r++) {
+                            const int br = r < L.pyrRows ? r : L.pyrRows - 1;
+                            const int v = refl(br - kEdge, L.h);
+                            y0 = std::min(y0, v); y1 = std::max(y1, v);
+                        }
+                        for (int j = l - 1; j >= start; j--) {       // region of level j that [x0,x1] x [y0,y1] of level j + 1 is resized from
+                            const std::vector<ResizeX>& X = g.rx[j + 1];
+                            const std::vector<ResizeX>& Y = g.ry[j + 1];
+                            int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
+                            for (int x = x0; x <= x1; x++) { sx0 = std::min(sx0, (int)std::min(X[x].sx0, X[x].sx1)); sx1 = std::max(sx1, (int)std::max(X[x].sx0, X[x].sx1)); }
+                            for (int y = y0; y <= y1; y++) { sy0 = std::min(sy0, (int)std::min(Y[y].sx0, Y[y].sx1)); sy1 = std::max(sy1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
+                            if (j == start) sx0 &= ~3;           // the first region is loaded from HBM in aligned dwords
+                            int w = sx1 - sx0 + 1;
+                            if (j == start) w = (w + 3) & ~3;    // (level 1: up to 3 px past the need, still inside the level's right border; the image: the kernel never reads past a row)
+                            c.region[j] = ChainRegion{(short)sx0, (short)sy0, (short)w, (short)(sy1 - sy0 + 1)};
+                            const int bytes = ((w + 3) & ~3) * (sy1 - sy0 + 1);
+                            if (j == start ? (bytes > maxW * maxH) : (w > kChainMaxW || sy1 - sy0 + 1 > kChainMaxH)) fits = false;
+                            if (j & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
+                            x0 = sx0; x1 = sx0 + w - 1 < g.lv[j].w ? sx0 + w - 1 : g.lv[j].w - 1; y0 = sy0; y1 = sy1;
+                            if (j == start) x1 = sx1;            // (the padding columns of the loaded region are never sources of a needed pixel)
+                        }
+                        int coefs = 4 * kChainTileDw + kChainTileRows;
+                        for (int j = start + 1; j < l; j++) coefs += c.region[j].w + c.region[j].h;
+                        if (coefs > kChainCoefMax) fits = false;
+                        out.push_back(c);
                     }
-                    for (int r = iy * kChainTileRows; r < (iy + 1) * kChainTileRows; r++) {
-                        const int br = r < L.pyrRows ? r : L.pyrRows - 1;
-                        const int v = refl(br - kEdge, L.h);
-                        y0 = std::min(y0, v); y1 = std::max(y1, v);
-                    }
-                    for (int j = l - 1; j >= 1; j--) {       // region of level j that [x0,x1] x [y0,y1] of level j + 1 is resized from
-                        const std::vector<ResizeX>& X = g.rx[j + 1];
-                        const std::vector<ResizeX>& Y = g.ry[j + 1];
-                        int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
-                        for (int x = x0; x <= x1; x++) { sx0 = std::min(sx0, (int)std::min(X[x].sx0, X[x].sx1)); sx1 = std::max(sx1, (int)std::max(X[x].sx0, X[x].sx1)); }
-                        for (int y = y0; y <= y1; y++) { sy0 = std::min(sy0, (int)std::min(Y[y].sx0, Y[y].sx1)); sy1 = std::max(sy1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
-                        if (j == 1) sx0 &= ~3;               // level 1 is loaded from HBM in aligned dwords
-                        int w = sx1 - sx0 + 1;
-                        if (j == 1) w = (w + 3) & ~3;        // (reads up to 3 px past the need: still inside the level's right border)
-                        c.region[j] = ChainRegion{(short)sx0, (short)sy0, (short)w, (short)(sy1 - sy0 + 1)};
-                        if (w > kChainMaxW || sy1 - sy0 + 1 > kChainMaxH) g.chainFits = false;
-                        const int bytes = ((w + 3) & ~3) * (sy1 - sy0 + 1);
-                        if (j & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
-                        x0 = sx0; x1 = sx0 + w - 1 < g.lv[j].w ? sx0 + w - 1 : g.lv[j].w - 1; y0 = sy0; y1 = sy1;
-                        if (j == 1) x1 = sx1;                // (the padding columns of level 1 are never sources of a needed pixel)
-                    }
-                    int coefs = 4 * kChainTileDw + kChainTileRows;
-                    for (int j = 2; j < l; j++) coefs += c.region[j].w + c.region[j].h;
-                    if (coefs > kChainCoefMax) g.chainFits = false;
-                    g.chain.push_back(c);
-                }
-        }
-        g.chainEvenBytes = (maxEven + 15) & ~15;
-        g.chainLdsBytes = g.chainEvenBytes + ((maxOdd + 15) & ~15) + 32;
+            }
+            evenBytes = (maxEven + 15) & ~15;
+            ldsBytes = evenBytes + ((maxOdd + 15) & ~15) + 32;
+        };
+        build(1, g.chain, g.chainFits, g.chainLdsBytes, g.chainEvenBytes, kChainMaxW, kChainMaxH);
+        build(0, g.chainAll, g.chainAllFits, g.chainAllLdsBytes, g.chainAllEvenBytes, kChainMaxW, kChainMaxH0);
         // the packed horizontal pass of the in-between steps: region columns start anywhere, so every group of four adjacent
         // columns is checked (the last step, the tile itself, goes byte by byte)
-        for (int l = 2; l < t.nlevels - 1 && g.chainPacked; l++) {
-            const std::vector<ResizeX>& X = g.rx[l];
-            const int w = g.lv[l].w;
-            for (int x = 0; x < w && g.chainPacked; x++) {
-                int lo = 1 << 30, hi = -1;
-                for (int k = 0; k < 4; k++) {
-                    const ResizeX& c = X[std::min(x + k, w - 1)];
-                    lo = std::min(lo, (int)std::min(c.sx0, c.sx1)); hi = std::max(hi, (int)std::max(c.sx0, c.sx1));
+        auto packedFrom = [&](int first) {
+            for (int l = first; l < t.nlevels - 1; l++) {
+                const std::vector<ResizeX>& X = g.rx[l];
+                const int w = g.lv[l].w;
+                for (int x = 0; x < w; x++) {
+                    int lo = 1 << 30, hi = -1;
+                    for (int k = 0; k < 4; k++) {
+                        const ResizeX& c = X[std::min(x + k, w - 1)];
+                        lo = std::min(lo, (int)std::min(c.sx0, c.sx1)); hi = std::max(hi, (int)std::max(c.sx0, c.sx1));
+                    }
+                    if (hi - lo > 7) return false;
                 }
-                if (hi - lo > 7) g.chainPacked = false;
             }
-        }
+            return true;
+        };
+        g.chainPacked = packedFrom(2);
+        g.chainAllPacked = g.chainPacked && (t.nlevels < 3 || packedFrom(1));
     }
     return std::string();
 }

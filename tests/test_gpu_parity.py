@@ -302,10 +302,11 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
-                                          ("ORBX_RESIZE_BYTEWISE", "1")])
+                                          ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_ALL_WGS", "-1"), ("ORBX_PYR_CHAIN", "0")])
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
-    # the quad-tree kernel exists in three workgroup sizes and the resize kernel in a packed and a byte-gather form; the
-    # host picks by batch size / image area / tap geometry, and every choice must give the reference result
+    # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid of
+    # a small batch is one launch (from the image), two (level 0/1, then chains from level 1) or one per level; the host picks by
+    # batch size / image area / tap geometry, and every choice must give the reference result
     monkeypatch.setenv(switch, value)
     for shape, nf, variant in (((480, 640), 1000, "noise"), ((333, 517), 700, "textured"), ((480, 640), 1200, "natural")):
         img = synth.frames(variant, 21, 1, *shape)[0]
