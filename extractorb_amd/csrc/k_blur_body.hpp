@@ -32,7 +32,15 @@ __device__ __forceinline__ void blurLanes(const BlurItem* __restrict__ items, co
     const int rowsValid = min(kBlurRows, g.h - y0);     // output rows this block really owns
     const int lastIn = g.h + kEdge - 1 - (y0 - 3);      // input rows below the bordered buffer are clamped (their outputs are not stored)
 
-    unsigned h[7][4] = {};
+    // Vertical pass on row sums packed two rows to a register (u16 halves: a row sum is <= 255 * 257 = 65535): rows (2k, 2k + 1) of the
+    // block form pair k, a 7-row window is four pairs (one of them half used), and v_dot2_u32_u16 against the matching weight pair
+    // adds two taps per instruction — four instead of three adds and four multiply-adds per pixel.  The loop is unrolled, so the
+    // parity of the output row (which halves of which pairs it uses) is static.  The sums are the same integers as tap by tap.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](unsigned pair, unsigned short w0, unsigned short w1, unsigned acc) {
+        return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), u16x2{w0, w1}, acc, false);
+    };
+    unsigned P[4][4] = {}, lo[4] = {};      // the four youngest complete pairs (oldest first); the even row waiting for its partner
 #pragma unroll
     for (int i = 0; i < kBlurRows + 6; i++) {
         const int r = i < lastIn ? i : lastIn;
@@ -43,23 +51,29 @@ __device__ __forceinline__ void blurLanes(const BlurItem* __restrict__ items, co
         hn[1] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2));
         hn[2] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3));
         hn[3] = hsum4(d1, d2);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-            for (int t = 0; t < 6; t++) h[t][j] = h[t + 1][j];
-            h[6][j] = hn[j];
-        }
-        if (i >= 6) {
-            unsigned outw = 0;
+        if (i & 1) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                // 24-bit multiplies (row sums <= 2 * 65535): a 32-bit v_mul_lo_u32 issues at a quarter of the rate
-                const unsigned s = __umul24(18u, h[0][j] + h[6][j]) + __umul24(34u, h[1][j] + h[5][j]) + __umul24(49u, h[2][j] + h[4][j]) +
-                                   __umul24(55u, h[3][j]);
-                unsigned v = (s + 32768u) >> 16;
-                v = v > 255u ? 255u : v;
-                outw |= v << (8 * j);
+                P[0][j] = P[1][j]; P[1][j] = P[2][j]; P[2][j] = P[3][j];
+                P[3][j] = (hn[j] << 16) | lo[j];
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) lo[j] = hn[j];
+        }
+        if (i >= 6) {
+            unsigned t[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned sacc;
+                if (i & 1)      // rows i-6 .. i = high half of P[0], P[1], P[2], P[3]
+                    sacc = dot2(P[3][j], 34, 18, dot2(P[2][j], 55, 49, dot2(P[1][j], 34, 49, dot2(P[0][j], 0, 18, 32768u))));
+                else            // rows i-6 .. i = P[1], P[2], P[3], the waiting even row
+                    sacc = dot2(lo[j], 18, 0, dot2(P[3][j], 49, 34, dot2(P[2][j], 49, 55, dot2(P[1][j], 18, 34, 32768u))));
+                t[j] = min(sacc, 0x00FFFFFFu);      // (s + 32768) >> 16 clamped to 255 is byte 2 of this
+            }
+            const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(t[3], t[2], 0x0C0C0602u);
+            const unsigned outw = (p23 << 16) | p01;
             const int orow = i - 6;
             if (orow < rowsValid) *(unsigned*)(dp + (long long)orow * g.blurStride) = outw;
         }
