@@ -50,6 +50,10 @@ WORKLOADS = {
     # configs[1] + Frame::ComputeBoW (§8f-4) with a synthetic vocabulary of ORBvoc.txt's shape (k = 10, L = 6: 1 111 111 nodes, 10^6 words)
     "mono640_bow": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", bow=True,
                         desc="640x480 mono stream, 8 levels, 1000 features: extraction + ComputeBoW (synthetic 10^6-word vocabulary, levelsup 4)"),
+    # the above + ORBmatcher::SearchByBoW(frame i as the reference keyframe, frame i+1) (Tracking::TrackReferenceKeyFrame)
+    "mono640_refkf": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="pan", bow=True, refkf=True,
+                          desc="mono 640x480 stream panning 1 px per frame, 8 levels, 1000 features: extraction + ComputeBoW (synthetic 10^6-word "
+                               "vocabulary) + SearchByBoW(frame i as keyframe with every keypoint holding a MapPoint, frame i+1)"),
     # the caller's side: BGR frames as Tracking::GrabImageMonocular receives them, cvtColor(BGR2GRAY) on the device, then configs[1]
     "mono640_bgr": dict(rows=480, cols=640, nfeatures=1000, lapping=(0, 1000), batch=512, variant="noise", color=3,
                         desc="640x480 BGR stream: cvtColor(BGR2GRAY) + extraction, 8 levels, 1000 features"),
@@ -163,8 +167,16 @@ def main():
         d_fn = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_fi = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
         d_nfv = torch.zeros(B, dtype=torch.int32, device="cuda")
 
+    refkf = bool(wl.get("refkf"))
+    if refkf:
+        d_kfflags = torch.ones((B - 1, cap), dtype=torch.uint8, device="cuda")
+        d_mb = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda"); d_nmb = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+
     def compute_bow(e_, b):
         e_.compute_bow_device(voc, B, b + off_d, b + off_n, cap, d_wid, d_ww, d_nw, d_fn, d_fi, d_nfv, levels_up=4)
+        if refkf:
+            e_.search_by_bow_device(B - 1, (0, 1), (1, 1), d_fn, d_fi, d_nfv, d_kfflags, b + off_k, b + off_d, b + off_n, cap, d_mb, d_nmb,
+                                    nnratio=0.7, th_low=50, check_orientation=True)
 
     track = bool(wl.get("track"))
     if track:
@@ -413,6 +425,7 @@ def main():
                        **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
                        **({"mean_projection_matches_per_pair": round(float(d_nmt.float().mean().item()), 1)} if track else {}),
                        **({"mean_words_per_frame": round(float(d_nw.float().mean().item()), 1)} if bow else {}),
+                       **({"mean_bow_matches_per_pair": round(float(d_nmb.float().mean().item()), 1)} if refkf else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": extras or None,

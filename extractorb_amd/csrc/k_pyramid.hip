@@ -142,7 +142,7 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
                 h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[j])), wt[j], 0u, false) & ~15u;
         };
         unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
-        int have0 = -1 << 20, have1 = -1 << 20;              // source rows held in H0 / H1
+        int have0 = -(1 << 20), have1 = -(1 << 20);             // source rows held in H0 / H1
 #pragma unroll
         for (int r = 0; r < kPyrRows; r++) {
             const int s0 = __builtin_amdgcn_readfirstlane((int)cy[r].sx0), s1 = __builtin_amdgcn_readfirstlane((int)cy[r].sx1);

@@ -148,6 +148,8 @@ def load_library():
     L.orbx_vocabulary_destroy.restype = None
     L.orbx_vocabulary_info.argtypes = [vp, ip, ip, ip, ip]
     L.orbx_compute_bow_device.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.orbx_search_by_bow_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
+                                            C.c_int, C.c_int, vp, vp]
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -449,6 +451,15 @@ class ORBextractor:
             return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
         self._check(self._L.orbx_compute_bow_device(self._h, vocab._v, n_frames, dp(d_desc), dp(d_n), capacity, levels_up, dp(d_word_ids),
                                                     dp(d_word_weights), dp(d_n_words), dp(d_feat_nodes), dp(d_feat_idx), dp(d_n_feat)))
+
+    def search_by_bow_device(self, n_pairs, kf, cur, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, d_kps, d_desc, d_n, capacity,
+                             d_matches, d_n_matches, nnratio=0.7, th_low=50, check_orientation=True):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (reference src/ORBmatcher.cc:269-471); kf and cur = (first, step)."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self._L.orbx_search_by_bow_device(self._h, n_pairs, kf[0], kf[1], cur[0], cur[1], dp(d_feat_nodes), dp(d_feat_idx),
+                                                      dp(d_n_feat), dp(d_kf_mp_flags), dp(d_kps), dp(d_desc), dp(d_n), capacity,
+                                                      C.c_float(nnratio), th_low, int(check_orientation), dp(d_matches), dp(d_n_matches)))
 
     def stereo_from_rgbd_device(self, n_frames, d_kps, d_kps_un, d_n, capacity, d_depth, depth_is_u16, rows, cols, depth_map_factor, mbf,
                                 d_u_right, d_depth_out, depth_stride_bytes=None, depth_frame_stride_bytes=None):

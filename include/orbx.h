@@ -295,6 +295,24 @@ int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_fram
                             int levels_up, uint32_t* d_word_ids, double* d_word_weights, int* d_n_words, uint32_t* d_feat_nodes,
                             uint32_t* d_feat_idx, int* d_n_feat);
 
+/* ---- the consumer of the FeatureVector: ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) ------------------
+ * (src/ORBmatcher.cc:269-471; Tracking::TrackReferenceKeyFrame, Tracking::Relocalization), Nleft == -1: for n_pairs pairs
+ * (keyframe = frame kf_first + p*kf_step, current frame = frame cur_first + p*cur_step of one device-resident batch) the features of
+ * the two frames that fell into the same vocabulary node are matched: nearest / second nearest by ORBmatcher::DescriptorDistance
+ * among the frame's not yet matched features of the node, TH_LOW and the ratio test, rotation-histogram clean-up (ComputeThreeMaxima).
+ *   d_feat_nodes, d_feat_idx, d_n_feat : mFeatVec of all frames as written by orbx_compute_bow_device (same capacity)
+ *   d_kf_mp_flags[p*capacity + i]      : bit 0 = keypoint i of the keyframe holds a MapPoint that is not bad (:301-307)
+ *   d_kps[f*capacity + i]              : mvKeys of all frames (only .angle is read: mvKeysUn keeps it, src/Frame.cc:776-780)
+ *   d_desc, d_n_out                    : mDescriptors, N of all frames
+ *   nn_ratio = mfNNratio, th_low = ORBmatcher::TH_LOW (50), check_orientation = mbCheckOrientation
+ *   d_matches[p*capacity + i]          : out, the keyframe keypoint whose MapPoint keypoint i of the frame receives, -1 = none
+ *   d_n_matches[p]                     : out, the return value
+ * Asynchronous on the handle's stream.  Errors: ORBX_ERR_UNSUPPORTED if 17 * capacity bytes of LDS do not fit a workgroup. */
+int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step,
+                              const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags,
+                              const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
+                              int th_low, int check_orientation, int* d_matches, int* d_n_matches);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

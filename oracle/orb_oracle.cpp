@@ -1263,6 +1263,71 @@ int oracle_compute_bow(int k, int L, int scoring, int weighting, int nNodes, con
     return nw;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:269-471), Nleft == -1
+// (and pKF->mpCamera2 == NULL: kp = pKF->mvKeysUn[realIdxKF], whose angle is mvKeys' angle, src/Frame.cc:776-780).
+// The FeatureVectors arrive flattened in (node, feature index) order, as oracle_compute_bow writes them, and are rebuilt into the
+// std::map<NodeId, vector<unsigned>> the reference walks.  kfFlags[i] bit 0 = "pMP && !pMP->isBad()" (:301-307).
+// matches[iF] (out, NF ints) = the keyframe keypoint whose MapPoint F's keypoint iF receives, -1 = NULL.  Returns nmatches.
+int oracle_search_by_bow(const unsigned* kfNodes, const unsigned* kfIdx, int nKF, const unsigned* fNodes, const unsigned* fIdx, int nF,
+                         const uint8_t* kfFlags, const void* kpsKF_, const uint8_t* descKF, const void* kpsF_, const uint8_t* descF, int NF,
+                         float nnratio, int thLow, int checkOrientation, int* matches) {
+    const KeyPoint* kpsKF = (const KeyPoint*)kpsKF_;
+    const KeyPoint* kpsF = (const KeyPoint*)kpsF_;
+    std::map<unsigned, std::vector<unsigned>> vFeatVecKF, vFeatVecF;
+    for (int i = 0; i < nKF; i++) vFeatVecKF[kfNodes[i]].push_back(kfIdx[i]);
+    for (int i = 0; i < nF; i++) vFeatVecF[fNodes[i]].push_back(fIdx[i]);
+    for (int i = 0; i < NF; i++) matches[i] = -1;                                        // :273
+    int nmatches = 0;
+    const int HISTO_LENGTH = 30;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;                                            // :282
+    auto KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+    auto Fit = vFeatVecF.begin(), Fend = vFeatVecF.end();
+    while (KFit != KFend && Fit != Fend) {                                               // :290
+        if (KFit->first == Fit->first) {
+            const std::vector<unsigned>& vIndicesKF = KFit->second;
+            const std::vector<unsigned>& vIndicesF = Fit->second;
+            for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+                const unsigned realIdxKF = vIndicesKF[iKF];
+                if (!(kfFlags[realIdxKF] & 1)) continue;                                 // :303-307
+                const uint8_t* dKF = descKF + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
+                    const unsigned realIdxF = vIndicesF[iF];
+                    if (matches[realIdxF] >= 0) continue;                                // :318-319
+                    const int dist = descriptorDistance(dKF, descF + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }     // :325-330
+                    else if (dist < bestDist2) bestDist2 = dist;                                                    // :331-334
+                }
+                if (bestDist1 <= thLow) {                                                // :375
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {                 // :377
+                        matches[bestIdxF] = (int)realIdxKF;
+                        if (checkOrientation) {                                          // :384-401
+                            float rot = kpsKF[realIdxKF].angle - kpsF[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++; Fit++;
+        } else if (KFit->first < Fit->first) KFit = vFeatVecKF.lower_bound(Fit->first);  // :432-435
+        else Fit = vFeatVecF.lower_bound(KFit->first);                                   // :436-439
+    }
+    if (checkOrientation) {                                                              // :445-468
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { matches[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8-bit images as Tracking::GrabImage* calls it
 // (src/Tracking.cc:915-941, 985-1001).  OpenCV 3.4 generic path: 14-bit fixed point with R2Y = 4899, G2Y = 9617,
 // B2Y = 1868 and CV_DESCALE's rounding; alpha ignored.

@@ -79,6 +79,8 @@ def lib():
         L.oracle_project_last_frame.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, vp]
         L.oracle_search_by_projection.restype = C.c_int
         L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
+        L.oracle_search_by_bow.restype = C.c_int
+        L.oracle_search_by_bow.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
         L.oracle_compute_bow.restype = C.c_int
         L.oracle_compute_bow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, ip]
         L.oracle_stereo_from_rgbd.restype = None
@@ -273,6 +275,22 @@ def compute_bow(vocab, desc, levelsup=4):
                                   _ptr(np.ascontiguousarray(vocab["desc"], np.uint8)), _ptr(np.ascontiguousarray(vocab["weight"], np.float64)),
                                   _ptr(d), N, levelsup, _ptr(wid), _ptr(ww), _ptr(fn), _ptr(fi), C.byref(nf))
     return wid[:nw].copy(), ww[:nw].copy(), fn[:nf.value].copy(), fi[:nf.value].copy()
+
+
+def search_by_bow(kf_fv, f_fv, kf_flags, kps_kf, desc_kf, kps_f, desc_f, nnratio=0.7, th_low=50, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (reference src/ORBmatcher.cc:269-471).  kf_fv / f_fv = (nodes, idx) flattened
+    FeatureVectors; kf_flags[i] bit 0 = the keyframe's keypoint i holds a good MapPoint.  Returns (nmatches, matches[NF])."""
+    kn, ki = (np.ascontiguousarray(a, np.uint32) for a in kf_fv)
+    fn, fi = (np.ascontiguousarray(a, np.uint32) for a in f_fv)
+    kk = np.ascontiguousarray(kps_kf, KEYPOINT_DTYPE); kf = np.ascontiguousarray(kps_f, KEYPOINT_DTYPE)
+    dk = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32); df = np.ascontiguousarray(desc_f, np.uint8).reshape(-1, 32)
+    fl = np.ascontiguousarray(kf_flags, np.uint8)
+    NF = len(kf)
+    m = np.full(max(NF, 1), -1, np.int32)
+    pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+    n = lib().oracle_search_by_bow(_ptr(pad(kn)), _ptr(pad(ki)), len(kn), _ptr(pad(fn)), _ptr(pad(fi)), len(fn), _ptr(pad(fl)), _ptr(pad(kk)), _ptr(pad(dk)),
+                                   _ptr(pad(kf)), _ptr(pad(df)), NF, nnratio, th_low, int(check_orientation), _ptr(m))
+    return n, m[:NF].copy()
 
 
 def stereo_from_rgbd(kps, kps_un, depth, factor, mbf):

@@ -12,6 +12,7 @@ run --steps 30 --workload stereo640_match
 run --steps 30 --workload mono640_init
 run --steps 30 --workload mono640_track
 run --steps 30 --workload mono640_bow
+run --steps 30 --workload mono640_refkf
 run --steps 30 --workload mono640_bgr
 run --steps 30 --workload hd720
 run --steps 30 --workload hd1080
