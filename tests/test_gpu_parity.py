@@ -249,6 +249,38 @@ def test_device_path_with_padded_rows_and_frames():
         assert d_lc[f].cpu().numpy().tolist() == [len(o.level_keypoints(l)) for l in range(8)]
 
 
+@pytest.mark.parametrize("form", ["default", "ORBX_PYR_ALL_WGS=-1"])
+@pytest.mark.parametrize("B,offset,stride", [(1, 1, 643), (2, 3, 641), (3, 2, 650), (1, 0, 640)])
+def test_device_path_with_unaligned_pointer_and_stride(B, offset, stride, form, monkeypatch):
+    """cv::Mat ROIs handed over on the device: a base pointer and a row step that are not multiples of 4 (every pyramid form stages
+    through aligned dwords when it can and must fall back to byte reads here, never reading past a row of the caller's buffer)."""
+    import torch
+    if form != "default":
+        monkeypatch.setenv(*form.split("="))
+    rows, cols = 480, 640
+    fstride = stride * rows + 5
+    frames = synth.frames("noise", 31, B, rows, cols)
+    buf = np.full(offset + B * fstride, 255, np.uint8)       # 255 outside the images: a stray read would change FAST scores
+    for f in range(B):
+        buf[offset + f * fstride: offset + f * fstride + rows * stride].reshape(rows, stride)[:, :cols] = frames[f]
+    # the buffer ends with the last image row's last pixel (+ padding of the frame stride): nothing readable behind it
+    ex = X.ORBextractor(1000, max_batch=B)
+    cap = ex.capacity
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_buf = torch.from_numpy(buf).cuda()
+    d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_m = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_buf.data_ptr() + offset, B, rows, cols, d_k, d_d, d_n, d_m, cap, stride=stride, frame_stride=fstride)
+    ex.synchronize()
+    n = d_n.cpu().numpy()
+    for f in range(B):
+        o, want = oracle_run(frames[f], 1000)
+        k = d_k[f, :n[f]].cpu().numpy().view(np.uint8).reshape(-1, 28).copy().view(X.KEYPOINT_DTYPE).reshape(-1)
+        assert_same_result((int(d_m[f]), k, d_d[f, :n[f]].cpu().numpy()), want, "unaligned frame %d" % f)
+        for l in (0, 1, 4, 7):
+            assert np.array_equal(ex.image_pyramid_level(l, frame=f, bordered=True), o.level(l, bordered=True)), "level %d" % l
+
+
 def test_profile_api_and_algorithmic_bytes():
     ex = X.ORBextractor(1000, max_batch=4)
     fr = synth.frames("noise", 0, 4, 480, 640)
