@@ -68,6 +68,15 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
 
 
+def _search_rounds():
+    """rounds the fixed-point searches of the last launch needed for pair 0 (diagnostic export of the library)"""
+    import ctypes as C
+    import extractorb_amd as X
+    out = (C.c_int * 4)()
+    X.load_library().orbx_debug_search_rounds(out)
+    return list(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,7 +432,8 @@ def main():
                        "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        **({"stereo_pairs_per_sec": round(fps / 2, 1), "mean_stereo_matches_per_pair": round(float(d_nm.float().mean().item()), 1)} if match else {}),
                        **({"mean_init_matches_per_pair": round(float(d_nm12.float().mean().item()), 1)} if init_match else {}),
-                       **({"mean_projection_matches_per_pair": round(float(d_nmt.float().mean().item()), 1)} if track else {}),
+                       **({"mean_projection_matches_per_pair": round(float(d_nmt.float().mean().item()), 1),
+                           "projection_search_rounds_pair0": _search_rounds()} if track else {}),
                        **({"mean_words_per_frame": round(float(d_nw.float().mean().item()), 1)} if bow else {}),
                        **({"mean_bow_matches_per_pair": round(float(d_nmb.float().mean().item()), 1)} if refkf else {}),
                        "handles_per_gpu": nH,

@@ -12,16 +12,16 @@
 // level range) under the current frame's pose.  For (b) the tracker's frustum test already produced those numbers
 // (MapPoint::mTrackProjX / mTrackProjY / mTrackProjXR / mnTrackScaleLevel / mTrackViewCos), so the caller passes queries directly.
 // k_search_proj is the matching proper.  A keypoint that receives a MapPoint with observations is closed to later requests
-// (:64-66, :2035-2037), so the requests of one frame form a sequential chain: ONE WORKGROUP PER FRAME walks them in order and its
-// 256 lanes share each search, exactly as k_search_init does (k_match.hip):
-//   * the current frame's keypoints are staged once into LDS in grid order (cell x*48+y, push_back order inside a cell) with
+// (:64-66, :2035-2037), so the requests of one frame form a sequential chain in the reference — but a request only looks at the few
+// keypoints of its window, so ONE WORKGROUP PER FRAME settles all requests as a parallel fixed point (see the kernel), one request per
+// thread per round:
+//   * the current frame's keypoints are staged once into LDS in mGrid's CSR order (cell x*48+y, push_back order inside a cell) with
 //     descriptor words transposed; GetFeaturesInArea visits cells in ascending grid position, so the strict "<" of the
-//     reference's running minimum is "smallest (distance, position)" and the cell columns of a window are one slot range;
-//   * a lane keeps its two smallest keys (distance << 16 | position); the reference's (bestDist, bestLevel, bestDist2, bestLevel2)
+//     reference's running minimum is "smallest (distance, slot)" and a window is one slot range per cell column;
+//   * a request keeps its two smallest keys (distance << 16 | slot); the reference's (bestDist, bestLevel, bestDist2, bestLevel2)
 //     after its sequential scan are the smallest and the second smallest key of the window (the element that ends up providing
-//     bestDist2 is the first in traversal order among those with the second smallest distance — see DESIGN.md §4f);
-//   * acceptance is uniform over the workgroup; every wave records "occupied" for its own next search, wave 0 owns the match
-//     tables; one barrier per request (merge scratch double-buffered).
+//     bestDist2 is the first in traversal order among those with the second smallest distance — see DESIGN.md §4f).
+// One frame pair: 868 us as a walk (one barrier per request) -> see DESIGN.md §4f for the fixed point's figure.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,7 +48,9 @@ namespace {
 constexpr int kCols = 64, kRows = 48, kCells = kCols * kRows;
 constexpr int kHistoLength = 30;                          // ORBmatcher.cc:38 (the distance bound, TH_HIGH = 100 or the caller's ORBdist, is a parameter)
 constexpr int kNoneKey = (256 << 16) | 0xFFFF;            // bestDist = 256, no position
-constexpr int kThreads = 256, kWaves = kThreads / 64;
+constexpr int kTop = 4;                                   // best keys a request remembers between rounds
+constexpr unsigned kNoDecision = 0xFFFFFFFFu;             // the request is inactive, finds nothing or is rejected
+constexpr int kThreads = 1024;     // one request per thread per round at ~1000 requests; 16 waves hide the LDS latency of the window scans (256 threads: 111 us for the first scan)
 
 __device__ __forceinline__ int bcast(int v, int srcLane) { return __builtin_amdgcn_readlane(v, srcLane); }
 __device__ __forceinline__ float bcastf(float v, int srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane)); }
@@ -117,12 +119,16 @@ __global__ __launch_bounds__(256) void k_project_last(const Keypoint* __restrict
     *out = q;
 }
 
-size_t projSearchLdsBytes(int capacity) {
+size_t projSearchLdsBytes(int capacity, int queryCapacity, bool topList) {
     const size_t c = (size_t)((capacity + 3) & ~3);
-    return c * (32 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 2 + 1 + 1 + 2) + (kCols + 2) * sizeof(int) + 2 * kWaves * 2 * sizeof(int) + 2 * kWaves * sizeof(int) + 64;
+    return c * (32 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 1 + 1 + 2) + (kCells + 1 + kHistoLength + 4) * sizeof(int) +
+           (size_t)queryCapacity * (4 + 1 + (topList ? 4 * kTop : 0)) + 64;
 }
+__device__ int g_searchRounds[4];      // diagnostics: rounds the last launch's pair 0 needed (projection search, initialisation search)
+extern "C" int orbx_debug_search_rounds(int* out4) { return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_searchRounds), sizeof(int) * 4); }
 
-// grid: n_pairs; 256 threads.
+// grid: n_pairs; 256 threads.  TOPLIST: the requests' best-key lists fit in LDS next to the staged frame.
+template <bool TOPLIST>
 __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __restrict__ queries, const uint8_t* __restrict__ qdesc,
                                                           const int* __restrict__ nQueries, const Keypoint* __restrict__ kpsUn,
                                                           const uint8_t* __restrict__ desc, const int* __restrict__ nOut,
@@ -138,15 +144,18 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     float* ur2 = a2 + capA;                                // mvuRight (<= 0: no stereo observation)
     int* m2q = (int*)(ur2 + capA);                         // query whose MapPoint the keypoint holds, -1 = none
     unsigned* binMask = (unsigned*)(m2q + capA);           // rotHist bins the keypoint was pushed to
-    int* colStart = (int*)(binMask + capA);                // [66] first slot of cell column c (c = 64, 65: n2)
-    int* merge = colStart + kCols + 2;                     // [2][kWaves][2] per-wave (best key, second key), double-buffered
-    int* wcnt = merge + 2 * kWaves * 2;                    // [2][kWaves] staging counts
-    unsigned short* cell2 = (unsigned short*)(wcnt + 2 * kWaves);  // ix << 8 | iy
-    unsigned short* idx2 = cell2 + capA;                   // keypoint index in the frame
+    int* closedBy = (int*)(binMask + capA);                // [capA] first request that closes the keypoint (-1: closed on entry, INT_MAX: nobody)
+    int* top = closedBy + capA;                            // [queryCapacity][kTop] (TOPLIST; 16-byte aligned) the requests' smallest keys, ascending
+    int* cellOff = top + (TOPLIST ? (long long)p.queryCapacity * kTop : 0);      // [kCells + 1] slot range of every grid cell (mGrid's CSR offsets)
+    unsigned* dec = (unsigned*)(cellOff + kCells + 1);     // [queryCapacity] decision of every request: slot | closes << 16, or kNoDecision
+    int* hist = (int*)(dec + p.queryCapacity);             // [30] rotHist sizes
+    int* flags = hist + kHistoLength;                      // [3] "a decision changed" (two alternating slots), number of accepted requests
+    unsigned short* idx2 = (unsigned short*)(flags + 4);   // keypoint index in the frame
     uint8_t* oct2 = (uint8_t*)(idx2 + capA);               // octave
     uint8_t* occ = oct2 + capA;                            // holds a MapPoint with Observations() > 0
+    uint8_t* qflag = occ + capA;                           // [queryCapacity] orbx_proj_query::flags
 
-    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = blockIdx.x, tid = threadIdx.x;
     const int f2 = p.curFirst + pair * p.curStep;
     const int N2 = min(nOut[f2], cap);
     const Keypoint* K2 = kpsUn + (long long)f2 * cap;
@@ -162,135 +171,162 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     const int nIn2 = min(off2[kCells], N2);
 
     // ---- stage the frame's keypoints in grid order (every octave: the level window differs per request) ----
-    int n2 = 0;
-    for (int base = 0, it = 0; base < nIn2; base += kThreads, it ^= 1) {
-        const int pos = base + tid;
-        const bool keep = pos < nIn2;
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wcnt[it * kWaves + wave] = __popcll(m);
-        __syncthreads();
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; w++) { const int c = wcnt[it * kWaves + w]; all += c; before += w < wave ? c : 0; }
-        const int slot = n2 + before + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) {
-            const int i2 = gi2[pos];
-            const Keypoint k = K2[i2];
-            const int posX = (int)roundf(__fmul_rn(__fsub_rn(k.x, p.minX), p.wInv));   // the cell AssignFeaturesToGrid put it in
-            const int posY = (int)roundf(__fmul_rn(__fsub_rn(k.y, p.minY), p.hInv));   // (PosInGrid, Frame.cc:728-729)
-            x2[slot] = k.x; y2[slot] = k.y; a2[slot] = k.angle;
-            ur2[slot] = UR ? UR[i2] : -1.0f;
-            cell2[slot] = (unsigned short)((posX << 8) | posY);
-            idx2[slot] = (unsigned short)i2;
-            oct2[slot] = (uint8_t)min(max(k.octave, 0), 255);
-            occ[slot] = occIO ? occIO[i2] : (uint8_t)0;
-            m2q[slot] = -1; binMask[slot] = 0u;
-            const uint4 lo = *(const uint4*)(D2 + (long long)i2 * 8), hi = *(const uint4*)(D2 + (long long)i2 * 8 + 4);
-            d2w[0 * capA + slot] = lo.x; d2w[1 * capA + slot] = lo.y; d2w[2 * capA + slot] = lo.z; d2w[3 * capA + slot] = lo.w;
-            d2w[4 * capA + slot] = hi.x; d2w[5 * capA + slot] = hi.y; d2w[6 * capA + slot] = hi.z; d2w[7 * capA + slot] = hi.w;
-        }
-        n2 += all;
+    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+    const int n2 = nIn2;                                   // slot = position in mGrid's CSR order (cell x*48+y, push_back order inside a cell)
+    for (int slot = tid; slot < n2; slot += kThreads) {
+        const int i2 = gi2[slot];
+        const Keypoint k = K2[i2];
+        x2[slot] = k.x; y2[slot] = k.y; a2[slot] = k.angle;
+        ur2[slot] = UR ? UR[i2] : -1.0f;
+        idx2[slot] = (unsigned short)i2;
+        oct2[slot] = (uint8_t)min(max(k.octave, 0), 255);
+        occ[slot] = occIO ? occIO[i2] : (uint8_t)0;
+        m2q[slot] = -1; binMask[slot] = 0u;
+        const uint4 lo = *(const uint4*)(D2 + (long long)i2 * 8), hi = *(const uint4*)(D2 + (long long)i2 * 8 + 4);
+        d2w[0 * capA + slot] = lo.x; d2w[1 * capA + slot] = lo.y; d2w[2 * capA + slot] = lo.z; d2w[3 * capA + slot] = lo.w;
+        d2w[4 * capA + slot] = hi.x; d2w[5 * capA + slot] = hi.y; d2w[6 * capA + slot] = hi.z; d2w[7 * capA + slot] = hi.w;
     }
     for (int i = tid; i < cap; i += kThreads) out[i] = -1;     // keypoints outside the grid can never match
+    for (int c = tid; c <= kCells; c += kThreads) cellOff[c] = min(off2[c], n2);      // mGrid's CSR offsets: slot range of every cell
+    for (int i = tid; i < NQ; i += kThreads) dec[i] = kNoDecision;
+    if (tid < kHistoLength) hist[tid] = 0;
+    if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; }
     __syncthreads();
-    if (tid < kCols + 2) {      // first slot whose cell column is >= tid (slots are sorted by column)
-        int lo = 0, hi = n2;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((cell2[mid] >> 8) < tid) lo = mid + 1; else hi = mid; }
-        colStart[tid] = lo;
-    }
+    for (int s = tid; s < n2; s += kThreads) closedBy[s] = occ[s] ? -1 : 0x7fffffff;
     __syncthreads();
 
-    int nm = 0;
-    int histCnt = 0;        // lane b counts rotHist[b].size()
-    int parity = 0;
+    // ---- the searches.  In the reference request i sees the keypoints that requests j < i closed (:64-66, :2035-2037), a sequential
+    //      chain; but a request only ever looks at the handful of keypoints in its window, so almost all of the chain is independent.
+    //      Fixed point instead of a walk: every request decides in parallel against closedBy[s] = the FIRST request that closes keypoint
+    //      s under the current decisions (request i sees s closed iff closedBy[s] < i), closedBy is rebuilt, and the round repeats until
+    //      no decision changes.  By induction the decisions of requests 0..k are final after round k + 1 (whether some j < i closes s
+    //      depends only on decisions of requests < i), so the fixed point IS the sequential result; real frames settle in 3-6 rounds
+    //      instead of a thousand dependent steps. ----
+    const unsigned long long tStaged = __builtin_amdgcn_s_memrealtime();
     const float factor = 1.0f / kHistoLength;
-    for (int base1 = 0; base1 < NQ; base1 += 64) {
-        // one request per lane (every wave holds the same 64)
-        const int mine = base1 + lane;
-        ProjQuery q{0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0.f};
-        uint4 dlo = make_uint4(0, 0, 0, 0), dhi = dlo;
-        if (mine < NQ) {
-            q = Q[mine];
-            dlo = *(const uint4*)(QD + (long long)mine * 8); dhi = *(const uint4*)(QD + (long long)mine * 8 + 4);
-        }
+    // the kTop smallest keys (distance << 16 | slot) of a request's window, ascending, among the keypoints that pass the static tests
+    // (cell window, level, box, stereo column, not closed on entry) and - if `live` - are not closed for this request right now
+    auto scan = [&](int iq, bool live, int (&keys)[kTop]) -> int {
+#pragma unroll
+        for (int k = 0; k < kTop; k++) keys[k] = kNoneKey;
+        const ProjQuery q = Q[iq];
+        if (!(q.flags & 1)) return 0;
         const float r = q.radius;
         // GetFeaturesInArea's cell window (Frame.cc:666-688); an empty window is "no candidates"
         const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.u, p.minX), r), p.wInv)));
         const int maxCX = min(kCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.u, p.minX), r), p.wInv)));
         const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.v, p.minY), r), p.hInv)));
         const int maxCY = min(kRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.v, p.minY), r), p.hInv)));
-        const bool window = !(minCX >= kCols || maxCX < 0 || minCY >= kRows || maxCY < 0 || minCX > maxCX || minCY > maxCY);
-        const int myBeg = window ? colStart[minCX] : 0, myEnd = window ? colStart[maxCX + 1] : 0;
-        const int myCY = (minCY << 8) | (maxCY & 255);
+        if (minCX >= kCols || maxCX < 0 || minCY >= kRows || maxCY < 0 || minCX > maxCX || minCY > maxCY) return q.flags;
         // level filter of GetFeaturesInArea (:690, :705-712) as an inclusive range; without bCheckLevels everything passes
         const bool checkLevels = q.minLevel > 0 || q.maxLevel >= 0;
-        const int loL = checkLevels ? max(q.minLevel, 0) : 0, hiL = checkLevels && q.maxLevel >= 0 ? min(q.maxLevel, 255) : 255;
-        const int myLv = (loL << 8) | hiL;
-        unsigned long long todo = __ballot((q.flags & 1) && myBeg < myEnd);
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int iq = base1 + j;
-            const float x = bcastf(q.u, j), y = bcastf(q.v, j), rr = bcastf(r, j), urq = bcastf(q.ur, j);
-            const int sBeg = bcast(myBeg, j), sEnd = bcast(myEnd, j), cyr = bcast(myCY, j), lvr = bcast(myLv, j), qflags = bcast(q.flags, j);
-            const int loCY = cyr >> 8, hiCY = cyr & 255, loLv = lvr >> 8, hiLv = lvr & 255;
-            const uint32_t w0 = bcast(dlo.x, j), w1 = bcast(dlo.y, j), w2 = bcast(dlo.z, j), w3 = bcast(dlo.w, j);
-            const uint32_t w4 = bcast(dhi.x, j), w5 = bcast(dhi.y, j), w6 = bcast(dhi.z, j), w7 = bcast(dhi.w, j);
-            int key = kNoneKey, second = kNoneKey;             // key = distance << 16 | slot
-            for (int s = sBeg + tid; s < sEnd; s += kThreads) {
-                const int cy = cell2[s] & 255, lv = oct2[s];
-                const float distx = __fsub_rn(x2[s], x), disty = __fsub_rn(y2[s], y), us = ur2[s];
-                const int dist = __popc(w0 ^ d2w[s]) + __popc(w1 ^ d2w[capA + s]) + __popc(w2 ^ d2w[2 * capA + s]) +
-                                 __popc(w3 ^ d2w[3 * capA + s]) + __popc(w4 ^ d2w[4 * capA + s]) + __popc(w5 ^ d2w[5 * capA + s]) +
-                                 __popc(w6 ^ d2w[6 * capA + s]) + __popc(w7 ^ d2w[7 * capA + s]);
-                const bool stereoOut = us > 0.0f && fabsf(__fsub_rn(urq, us)) > rr;                                 // :68-73, :2039-2046
-                const bool in = (int)(cy >= loCY) & (int)(cy <= hiCY) & (int)(lv >= loLv) & (int)(lv <= hiLv) &
-                                (int)(fabsf(distx) < rr) & (int)(fabsf(disty) < rr) & (int)!occ[s] & (int)!stereoOut;  // Frame.cc:717; :64-66
+        const int loLv = checkLevels ? max(q.minLevel, 0) : 0, hiLv = checkLevels && q.maxLevel >= 0 ? min(q.maxLevel, 255) : 255;
+        const uint4 dlo = *(const uint4*)(QD + (long long)iq * 8), dhi = *(const uint4*)(QD + (long long)iq * 8 + 4);
+        for (int cx = minCX; cx <= maxCX; cx++) {          // ascending cells, push_back order inside a cell = ascending slots (Frame.cc:690-720)
+            const int sEnd = cellOff[cx * kRows + maxCY + 1];
+            for (int s = cellOff[cx * kRows + minCY]; s < sEnd; s++) {
+                const int lv = oct2[s];
+                const float distx = __fsub_rn(x2[s], q.u), disty = __fsub_rn(y2[s], q.v), us = ur2[s];
+                const bool stereoOut = us > 0.0f && fabsf(__fsub_rn(q.ur, us)) > r;                                    // :68-73, :2039-2046
+                const int cb = closedBy[s];
+                const bool in = (int)(lv >= loLv) & (int)(lv <= hiLv) & (int)(fabsf(distx) < r) & (int)(fabsf(disty) < r) &
+                                (int)(live ? !(cb < iq) : cb != -1) & (int)!stereoOut;                                 // Frame.cc:717; :64-66
                 if (in) {
-                    const int k = (dist << 16) | s;            // slots ascend per lane: a later equal distance never displaces
-                    if (k < key) { second = key; key = k; }
-                    else if (k < second) second = k;
-                }
-            }
-            const int wkey = waveMin(key);
-            const int wsecond = waveMin(key == wkey ? second : key);
-            if (lane == 0) { merge[(parity * kWaves + wave) * 2] = wkey; merge[(parity * kWaves + wave) * 2 + 1] = wsecond; }
-            __syncthreads();
-            int bkey = merge[parity * kWaves * 2], bsecond = merge[parity * kWaves * 2 + 1];
+                    const int dist = __popc(dlo.x ^ d2w[s]) + __popc(dlo.y ^ d2w[capA + s]) + __popc(dlo.z ^ d2w[2 * capA + s]) +
+                                     __popc(dlo.w ^ d2w[3 * capA + s]) + __popc(dhi.x ^ d2w[4 * capA + s]) + __popc(dhi.y ^ d2w[5 * capA + s]) +
+                                     __popc(dhi.z ^ d2w[6 * capA + s]) + __popc(dhi.w ^ d2w[7 * capA + s]);
+                    int k = (dist << 16) | s;              // slots ascend: a later equal distance never displaces
 #pragma unroll
-            for (int w = 1; w < kWaves; w++) {
-                const int ok = merge[(parity * kWaves + w) * 2], os = merge[(parity * kWaves + w) * 2 + 1];
-                bsecond = min(max(bkey, ok), min(bsecond, os));
-                bkey = min(bkey, ok);
-            }
-            parity ^= 1;
-            const int bestDist = bkey >> 16, bs = bkey & 0xFFFF;
-            if (bestDist <= p.maxDist) {                                                                       // :98 / :2058 / :2246
-                bool accept = true;
-                if (p.ratioMode) {      // only when best and second lie on the same level does the ratio apply (:100-104)
-                    const int bestDist2 = bsecond >> 16;
-                    const int bestLevel = oct2[bs], bestLevel2 = bestDist2 < 256 ? (int)oct2[bsecond & 0xFFFF] : -1;
-                    accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(p.nnRatio, (float)bestDist2));
-                }
-                if (accept) {
-                    const float ang2 = a2[bs];
-                    // every wave records the occupancy itself (its own next search reads it: no barrier needed); the match
-                    // tables belong to wave 0 alone
-                    if (lane == 0) occ[bs] = (uint8_t)((qflags >> 1) & 1);
-                    if (tid == 0) m2q[bs] = iq;                                                                // F.mvpMapPoints[bestIdx] = pMP
-                    nm++;
-                    if (!p.ratioMode && p.checkOrientation) {                                                  // :2064-2080
-                        float rot = __fsub_rn(bcastf(q.angle, j), ang2);
-                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                        int bin = (int)roundf(__fmul_rn(rot, factor));
-                        if (bin == kHistoLength) bin = 0;
-                        if (tid == 0) binMask[bs] |= 1u << bin;
-                        histCnt += lane == bin;
-                    }
+                    for (int t = 0; t < kTop; t++) { const int lo = min(keys[t], k); k = max(keys[t], k); keys[t] = lo; }      // sorted insert
                 }
             }
         }
+        return q.flags;
+    };
+    // the reference's acceptance tests on (best, second best) of the keypoints a request sees
+    auto judge = [&](int key, int second, int qflags) -> unsigned {
+        const int bestDist = key >> 16, bs = key & 0xFFFF;
+        if (key == kNoneKey || bestDist > p.maxDist) return kNoDecision;                                           // :98 / :2058 / :2246
+        if (p.ratioMode) {      // only when best and second lie on the same level does the ratio apply (:100-104)
+            const int bestDist2 = second >> 16;
+            const int bestLevel = oct2[bs], bestLevel2 = bestDist2 < 256 ? (int)oct2[second & 0xFFFF] : -1;
+            if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(p.nnRatio, (float)bestDist2)) return kNoDecision;
+        }
+        return (unsigned)bs | (((unsigned)qflags >> 1) & 1u) << 16;      // accepted: keypoint slot, bit 16 = the MapPoint closes it
+    };
+    // round 0: every request scans its window once and keeps its kTop best keys; later rounds only look at those (a full re-scan
+    // is needed only if closed keypoints have used up a truncated list)
+    for (int iq = tid; iq < NQ; iq += kThreads) {
+        int keys[kTop];
+        const int qf = scan(iq, false, keys);
+        qflag[iq] = (uint8_t)qf;
+        if (TOPLIST) *(int4*)(top + (long long)iq * kTop) = make_int4(keys[0], keys[1], keys[2], keys[3]);
+        dec[iq] = (qf & 1) ? judge(keys[0], keys[1], qf) : kNoDecision;
     }
+    __syncthreads();
+    const unsigned long long tScanned = __builtin_amdgcn_s_memrealtime();
+    int rounds = 1;
+    for (int round = 1; round <= NQ + 1; round++, rounds++) {
+        // closedBy[s] = first request that closes keypoint s under the current decisions
+        for (int iq = tid; iq < NQ; iq += kThreads) {
+            const unsigned d = dec[iq];
+            if (d != kNoDecision && (d >> 16)) atomicMin(&closedBy[d & 0xFFFFu], iq);
+        }
+        __syncthreads();
+        bool mineChanged = false;
+        for (int iq = tid; iq < NQ; iq += kThreads) {
+            const int qf = qflag[iq];
+            if (!(qf & 1)) continue;
+            int key = kNoneKey, second = kNoneKey;
+            bool rescan = !TOPLIST;
+            if (TOPLIST) {
+                const int4 t4 = *(const int4*)(top + (long long)iq * kTop);
+                const int t[kTop] = {t4.x, t4.y, t4.z, t4.w};
+                int nvis = 0;
+#pragma unroll
+                for (int k = 0; k < kTop; k++)
+                    if (t[k] != kNoneKey && !(closedBy[t[k] & 0xFFFF] < iq)) { if (nvis == 0) key = t[k]; else if (nvis == 1) second = t[k]; nvis++; }
+                rescan = t[kTop - 1] != kNoneKey && nvis < (p.ratioMode ? 2 : 1);      // truncated list used up
+            }
+            if (rescan) {
+                int keys[kTop];
+                scan(iq, true, keys);
+                key = keys[0]; second = keys[1];
+            }
+            const unsigned d = judge(key, second, qf);
+            if (d != dec[iq]) { dec[iq] = d; mineChanged = true; }
+        }
+        if (mineChanged) flags[round & 1] = 1;
+        __syncthreads();
+        const bool any = flags[round & 1] != 0;
+        if (tid == 0) flags[(round & 1) ^ 1] = 0;          // the other slot is read again only after the next barriers
+        if (!any) break;
+        for (int s = tid; s < n2; s += kThreads) closedBy[s] = occ[s] ? -1 : 0x7fffffff;
+        __syncthreads();
+    }
+    if (tid == 0 && pair == 0) {      // diagnostics (100 MHz ticks): staging, first scan, rounds
+        g_searchRounds[0] = rounds; g_searchRounds[1] = (int)(tStaged - tStart); g_searchRounds[2] = (int)(tScanned - tStaged);
+        g_searchRounds[3] = (int)(__builtin_amdgcn_s_memrealtime() - tScanned);
+    }
+    // ---- the tables the walk would have left: F.mvpMapPoints[bestIdx] = pMP is overwritten by every later accepted request
+    //      (a MapPoint without observations does not close its keypoint), nmatches and rotHist count every acceptance ----
+    int nm = 0;
+    for (int iq = tid; iq < NQ; iq += kThreads) {
+        const unsigned d = dec[iq];
+        if (d == kNoDecision) continue;
+        const int bs = (int)(d & 0xFFFFu);
+        atomicMax(&m2q[bs], iq);
+        nm++;
+        if (!p.ratioMode && p.checkOrientation) {                                                                  // :2064-2080
+            float rot = __fsub_rn(Q[iq].angle, a2[bs]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == kHistoLength) bin = 0;
+            atomicOr(&binMask[bs], 1u << bin);
+            atomicAdd(&hist[bin], 1);
+        }
+    }
+    if (nm) atomicAdd(&flags[2], nm);
     __syncthreads();
 
     unsigned dropBins = 0u;
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     if (!p.ratioMode && p.checkOrientation) {                                                                  // ComputeThreeMaxima
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < kHistoLength; i++) {
-            const int s = bcast(histCnt, i);
+            const int s = hist[i];
             if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
             else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
             else if (s > max3) { max3 = s; ind3 = i; }
@@ -306,14 +342,14 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
         if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) ind3 = -1;
         for (int i = 0; i < kHistoLength; i++)
-            if (i != ind1 && i != ind2 && i != ind3) { dropBins |= 1u << i; droppedCount += bcast(histCnt, i); }   // :2166-2170: one nmatches-- per entry
+            if (i != ind1 && i != ind2 && i != ind3) { dropBins |= 1u << i; droppedCount += hist[i]; }             // :2166-2170: one nmatches-- per entry
     }
     for (int s = tid; s < n2; s += kThreads) {
         const bool dropped = (binMask[s] & dropBins) != 0u;
         out[idx2[s]] = dropped ? -1 : m2q[s];
-        if (occIO) occIO[idx2[s]] = dropped ? (uint8_t)0 : occ[s];
+        if (occIO) occIO[idx2[s]] = dropped ? (uint8_t)0 : (uint8_t)(closedBy[s] != 0x7fffffff);
     }
-    if (tid == 0) nMatches[pair] = nm - droppedCount;
+    if (tid == 0) nMatches[pair] = flags[2] - droppedCount;
 }
 
 void launchProjectLast(hipStream_t st, const Keypoint* kps, const Keypoint* kpsUn, const int* nOut, const uint8_t* mpFlags,
@@ -324,8 +360,13 @@ void launchProjectLast(hipStream_t st, const Keypoint* kps, const Keypoint* kpsU
 void launchSearchProj(hipStream_t st, const ProjQuery* queries, const uint8_t* qdesc, const int* nQueries, const Keypoint* kpsUn,
                       const uint8_t* desc, const int* nOut, const int* gridOff, const int* gridIdx, const float* uRight,
                       uint8_t* occupied, const ProjSearchParams& p, int* matches, int* nMatches, int nPairs) {
-    hipLaunchKernelGGL(k_search_proj, dim3(nPairs), dim3(kThreads), projSearchLdsBytes(p.capacity), st, queries, qdesc, nQueries, kpsUn,
-                       desc, nOut, gridOff, gridIdx, uRight, occupied, p, matches, nMatches);
+    // the best-key lists ride in LDS when they fit (640x480 x 1000 features: 103 KB); otherwise every round re-scans the windows
+    if (projSearchLdsBytes(p.capacity, p.queryCapacity, true) <= 160 * 1024 - 512)
+        hipLaunchKernelGGL(k_search_proj<true>, dim3(nPairs), dim3(kThreads), projSearchLdsBytes(p.capacity, p.queryCapacity, true), st, queries, qdesc,
+                           nQueries, kpsUn, desc, nOut, gridOff, gridIdx, uRight, occupied, p, matches, nMatches);
+    else
+        hipLaunchKernelGGL(k_search_proj<false>, dim3(nPairs), dim3(kThreads), projSearchLdsBytes(p.capacity, p.queryCapacity, false), st, queries, qdesc,
+                           nQueries, kpsUn, desc, nOut, gridOff, gridIdx, uRight, occupied, p, matches, nMatches);
 }
 
 }  // namespace orbx

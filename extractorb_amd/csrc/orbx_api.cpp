@@ -64,7 +64,7 @@ struct ProjSearchParams {
     float minX, minY, wInv, hInv, nnRatio;
     int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep, maxDist;
 };
-size_t projSearchLdsBytes(int capacity);
+size_t projSearchLdsBytes(int capacity, int queryCapacity, bool topList);
 void launchProjectLast(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const float*, const float*, const ProjectParams&,
                        ProjQuery*, int);
 void launchSearchProj(hipStream_t, const ProjQuery*, const uint8_t*, const int*, const Keypoint*, const uint8_t*, const int*, const int*,
@@ -1144,7 +1144,7 @@ int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first,
         !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/query_capacity/n_pairs < 1, negative frame index/step or empty bounds");
     if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
-    if (projSearchLdsBytes(capacity) > 160 * 1024 - 512)
+    if (projSearchLdsBytes(capacity, query_capacity, false) > 160 * 1024 - 512)
         return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (64 bytes per keypoint, 160 KB per CU)");
     HIP_TRY(h, hipSetDevice(h->device));
     ProjSearchParams p;
