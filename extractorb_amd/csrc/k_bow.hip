@@ -6,7 +6,7 @@
 // k_bow_words: every descriptor descends the vocabulary tree; 16 lanes share one descriptor, one child each (k <= 16 in one
 // round, more in several), the nearest child — first one on ties, as the strict "<" of :1243 — by a 16-lane DPP minimum over
 // (distance << 8 | child rank).  Output per feature: word id, word weight, node at level L - levelsup.
-// k_bow_reduce: one workgroup per frame builds the two std::maps the reference builds: features sorted by (word, index) and
+// k_bow_reduce: one workgroup (1024 threads) per frame builds the two std::maps the reference builds: features sorted by (word, index) and
 // summed per word IN FEATURE ORDER (BowVector::addWeight adds one weight at a time, and floating-point addition is not
 // associative), the L1 / L2 norm accumulated over the words in ascending order by ONE lane (the map iteration order of
 // BowVector::normalize), then the division; and features sorted by (node, index) for the FeatureVector.
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_bow_words(VocabDevice V, const uint8_t*
 }
 
 namespace {
+constexpr int kReduceThreads = 1024;      // one key per thread at ~1000 features: a bitonic step is one compare-exchange + one barrier
 // in-place ascending bitonic sort of n = power of two u64 keys in LDS, all threads of the workgroup
 template <int T>
 __device__ void bitonicSort(unsigned long long* key, int n) {
@@ -101,65 +102,79 @@ __device__ void bitonicSort(unsigned long long* key, int n) {
 }
 }  // namespace
 
-// grid n_frames; 256 threads; dynamic LDS: P u64 keys (P = next power of two >= capacity).
-__global__ __launch_bounds__(256) void k_bow_reduce(const uint32_t* __restrict__ featWord, const double* __restrict__ featWeight,
+// grid n_frames; 1024 threads; dynamic LDS: P u64 keys + P doubles (P = next power of two >= capacity).
+// (One frame used to take 193 us here with 256 threads, a rank loop of O(i) per word and the norm summed from global memory; the
+// reference's floating-point order leaves exactly one sequential piece, the norm, and that now runs on LDS values.)
+__global__ __launch_bounds__(kReduceThreads) void k_bow_reduce(const uint32_t* __restrict__ featWord, const double* __restrict__ featWeight,
                                                     const uint32_t* __restrict__ featNode, const int* __restrict__ nOut, int capacity, int P,
                                                     int scoring, int weighting, uint32_t* __restrict__ wordIds, double* __restrict__ wordWeights,
                                                     int* __restrict__ nWords, uint32_t* __restrict__ fvNodes, uint32_t* __restrict__ fvIdx,
                                                     int* __restrict__ nFeat) {
+    constexpr int T = kReduceThreads;
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long* key = (unsigned long long*)smem;
-    __shared__ int sCount, sWords;
+    // [P] summed weight of word rank r: in LDS while 16 P bytes fit a workgroup, else in the output array itself
+    double* wsum = P <= 8192 ? (double*)(key + P) : wordWeights + (long long)blockIdx.x * capacity;
+    __shared__ int sCount, sWaveSum[T / 64];
     __shared__ double sNorm;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = min(nOut[f], capacity);
     const long long base = (long long)f * capacity;
     // ---- BowVector: features with a positive weight, sorted by (word id, feature index) ----
     if (tid == 0) sCount = 0;
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += T) {
         unsigned long long k = ~0ull;
         if (i < N && featWeight[base + i] > 0) k = ((unsigned long long)featWord[base + i] << 32) | (unsigned)i;      // if (w > 0) (:1161)
         key[i] = k;
     }
     __syncthreads();
-    bitonicSort<256>(key, P);
-    for (int i = tid; i < P; i += 256)
+    bitonicSort<T>(key, P);
+    for (int i = tid; i < P; i += T)
         if (key[i] != ~0ull && (i + 1 == P || key[i + 1] == ~0ull)) sCount = i + 1;
     __syncthreads();
     const int M = sCount;
-    if (tid == 0) { nFeat[f] = M; sWords = 0; }
+    if (tid == 0) nFeat[f] = M;
     // word segments: the thread at a segment's first entry walks it, adding the feature weights one by one in feature order
-    // (BowVector::addWeight, BowVector.cpp:34-46; TF / TF_IDF), or takes the first (addIfNotExist, :50-58; IDF / BINARY)
+    // (BowVector::addWeight, BowVector.cpp:34-46; TF / TF_IDF), or takes the first (addIfNotExist, :50-58; IDF / BINARY).  The
+    // segment's rank (= position of the word in the map) is a prefix count of segment starts: every thread owns a block of `per`
+    // consecutive entries, a wave-level DPP scan + the wave totals give the number of starts before the block.
     const bool accumulate = weighting == 0 || weighting == 1;      // TF_IDF = 0, TF = 1, IDF = 2, BINARY = 3
-    // rank of the segment = number of segment starts before it: counted with a second pass over flags kept in the key's low bits? the
-    // keys must stay intact for the walk, so the ranks are counted directly (M <= a few thousand)
+    const int per = (P + T - 1) / T, b = tid * per, e = min(b + per, M);
+    int starts = 0;
+    for (int i = b; i < e; i++) starts += i == 0 || (unsigned)(key[i] >> 32) != (unsigned)(key[i - 1] >> 32);
+    const int incl = waveInclusiveScan(starts);
+    if (lane == 63) sWaveSum[wave] = incl;
     __syncthreads();
-    for (int i = tid; i < M; i += 256) {
+    int rank = incl - starts, W = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; w++) { const int t = sWaveSum[w]; rank += w < wave ? t : 0; W += t; }
+    for (int i = b; i < e; i++) {
         const unsigned word = (unsigned)(key[i] >> 32);
         if (i > 0 && (unsigned)(key[i - 1] >> 32) == word) continue;
-        int rank = 0;
-        for (int j = 1; j <= i; j++) rank += (unsigned)(key[j] >> 32) != (unsigned)(key[j - 1] >> 32);
         double s = featWeight[base + (unsigned)key[i]];
         if (accumulate)
             for (int j = i + 1; j < M && (unsigned)(key[j] >> 32) == word; j++) s = __dadd_rn(s, featWeight[base + (unsigned)key[j]]);
         wordIds[base + rank] = word;
-        wordWeights[base + rank] = s;
-        atomicMax(&sWords, rank + 1);
+        wsum[rank] = s;
+        rank++;
     }
-    __syncthreads();
-    const int W = sWords;
     if (tid == 0) nWords[f] = W;
-    __threadfence_block();
+    __syncthreads();
     // normalisation (:1170-1176 when the scoring needs none: divide by the number of words; else BowVector::normalize, BowVector.cpp:62-83)
     const bool must = scoring != 5;                       // every scoring but DOT_PRODUCT normalises (ScoringObject.h:74-89)
     const bool l2 = scoring == 1;                         // L2_NORM uses L2, the rest L1
     if (tid == 0) {
         double norm = 0.0;
         if (must) {
-            for (int j = 0; j < W; j++) {                 // ascending word order = the map's iteration order
-                const double v = wordWeights[base + j];
-                norm = l2 ? __dadd_rn(norm, __dmul_rn(v, v)) : __dadd_rn(norm, fabs(v));
+            int j = 0;
+            for (; j + 8 <= W; j += 8) {                  // ascending word order = the map's iteration order; eight LDS reads in flight
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = wsum[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) norm = l2 ? __dadd_rn(norm, __dmul_rn(v[u], v[u])) : __dadd_rn(norm, fabs(v[u]));
             }
+            for (; j < W; j++) { const double v = wsum[j]; norm = l2 ? __dadd_rn(norm, __dmul_rn(v, v)) : __dadd_rn(norm, fabs(v)); }
             if (l2) norm = __dsqrt_rn(norm);
         } else if (accumulate) {
             norm = (double)W;
@@ -168,18 +183,17 @@ __global__ __launch_bounds__(256) void k_bow_reduce(const uint32_t* __restrict__
     }
     __syncthreads();
     const double norm = sNorm;
-    if (norm > 0.0)
-        for (int j = tid; j < W; j += 256) wordWeights[base + j] = __ddiv_rn(wordWeights[base + j], norm);
+    for (int j = tid; j < W; j += T) wordWeights[base + j] = norm > 0.0 ? __ddiv_rn(wsum[j], norm) : wsum[j];
     __syncthreads();
     // ---- FeatureVector: the same features sorted by (node at level L - levelsup, feature index) (FeatureVector.cpp:31-46) ----
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += T) {
         unsigned long long k = ~0ull;
         if (i < N && featWeight[base + i] > 0) k = ((unsigned long long)featNode[base + i] << 32) | (unsigned)i;
         key[i] = k;
     }
     __syncthreads();
-    bitonicSort<256>(key, P);
-    for (int i = tid; i < M; i += 256) { fvNodes[base + i] = (unsigned)(key[i] >> 32); fvIdx[base + i] = (unsigned)key[i]; }
+    bitonicSort<T>(key, P);
+    for (int i = tid; i < M; i += T) { fvNodes[base + i] = (unsigned)(key[i] >> 32); fvIdx[base + i] = (unsigned)key[i]; }
 }
 
 void launchBow(hipStream_t st, const VocabDevice& V, const uint8_t* desc, const int* nOut, int capacity, int levelsUp, uint32_t* featWord,
@@ -188,7 +202,7 @@ void launchBow(hipStream_t st, const VocabDevice& V, const uint8_t* desc, const 
     hipLaunchKernelGGL(k_bow_words, dim3((capacity + 15) / 16, B), dim3(256), 0, st, V, desc, nOut, capacity, levelsUp, featWord, featWeight, featNode);
     int P = 1;
     while (P < capacity) P <<= 1;
-    hipLaunchKernelGGL(k_bow_reduce, dim3(B), dim3(256), (size_t)P * 8, st, featWord, featWeight, featNode, nOut, capacity, P, V.scoring, V.weighting,
+    hipLaunchKernelGGL(k_bow_reduce, dim3(B), dim3(kReduceThreads), (size_t)P * (P <= 8192 ? 16 : 8), st, featWord, featWeight, featNode, nOut, capacity, P, V.scoring, V.weighting,
                        wordIds, wordWeights, nWords, fvNodes, fvIdx, nFeat);
 }
 

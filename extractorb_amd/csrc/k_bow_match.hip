@@ -28,7 +28,7 @@ struct BowMatchParams {
 namespace {
 constexpr int kHistoLength = 30;                          // ORBmatcher.cc:38
 constexpr unsigned kNoneKey = (256u << 16) | 0xFFFFu;     // bestDist = 256, no position
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;     // 64 rows of 16 lanes: ~100 node segments of a frame are two sequential segments per row
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dppMinU(unsigned v) {
@@ -45,9 +45,11 @@ __device__ __forceinline__ unsigned rowMin16(unsigned v) {
 }
 }  // namespace
 
-size_t bowMatchLdsBytes(int capacity) { return (size_t)capacity * (4 + 4 + 4 + 4 + 1) + 64; }
+size_t bowMatchLdsBytes(int capacity, bool stageDesc) { return (size_t)((capacity + 15) & ~15) * (4 + 4 + 4 + 4 + 1 + 2 + 2 + 1 + (stageDesc ? 64 : 0)) + 64; }
 
-// grid n_pairs; 256 threads; dynamic LDS bowMatchLdsBytes(capacity)
+// grid n_pairs; 1024 threads; dynamic LDS bowMatchLdsBytes(capacity, STAGE).  STAGE: both frames' descriptors fit in LDS next to the
+// tables (a row's walk over its keyframe features is a chain of dependent descriptor reads: from L2 it was 169 us per pair)
+template <bool STAGE>
 __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restrict__ featNodes, const uint32_t* __restrict__ featIdx,
                                                          const int* __restrict__ nFeat, const uint8_t* __restrict__ kfFlags,
                                                          const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
@@ -55,14 +57,19 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
                                                          int* __restrict__ nMatches) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int sSeg, sHist[kHistoLength], sCount;
-    const int cap = p.capacity, pair = blockIdx.x, tid = threadIdx.x, sub = tid & 15, row = tid >> 4;
+    const int cap = p.capacity, capA = (cap + 15) & ~15, pair = blockIdx.x, tid = threadIdx.x, sub = tid & 15, row = tid >> 4;
     const int fK = p.kfFirst + pair * p.kfStep, fC = p.curFirst + pair * p.curStep;
-    uint32_t* nodeK = (uint32_t*)smem;                    // [cap] node column of the keyframe's FeatureVector
-    uint32_t* nodeC = nodeK + cap;                        // [cap] ... of the frame's
-    int* segList = (int*)(nodeC + cap);                   // [cap] first entry of every keyframe node segment
-    volatile int* takenBy = (volatile int*)(segList + cap);   // [cap] frame keypoint -> keyframe keypoint whose MapPoint it got (vpMapPointMatches)
-    uint8_t* binOf = (uint8_t*)(takenBy + cap);           // [cap] rotHist bin the frame keypoint was pushed to
-    const int MK = min(nFeat[fK], cap), MC = min(nFeat[fC], cap), NC = min(nOut[fC], cap);
+    uint4* sDescK = (uint4*)smem;                         // (STAGE) [capA][2] the keyframe's descriptors
+    uint4* sDescC = sDescK + (STAGE ? 2 * capA : 0);      // (STAGE) [capA][2] the frame's
+    uint32_t* nodeK = (uint32_t*)(sDescC + (STAGE ? 2 * capA : 0));      // [capA] node column of the keyframe's FeatureVector
+    uint32_t* nodeC = nodeK + capA;                       // [capA] ... of the frame's
+    int* segList = (int*)(nodeC + capA);                  // [capA] first entry of every keyframe node segment
+    volatile int* takenBy = (volatile int*)(segList + capA);  // [capA] frame keypoint -> keyframe keypoint whose MapPoint it got (vpMapPointMatches)
+    unsigned short* sIdxK = (unsigned short*)(takenBy + capA);      // [capA] feature-index column of the keyframe's FeatureVector
+    unsigned short* sIdxC = sIdxK + capA;                 // [capA] ... of the frame's
+    uint8_t* binOf = (uint8_t*)(sIdxC + capA);            // [capA] rotHist bin the frame keypoint was pushed to
+    uint8_t* sFlag = binOf + capA;                        // [capA] the keyframe's MapPoint flags
+    const int MK = min(nFeat[fK], cap), MC = min(nFeat[fC], cap), NC = min(nOut[fC], cap), NK = min(nOut[fK], cap);
     const uint32_t *gNodeK = featNodes + (long long)fK * cap, *gNodeC = featNodes + (long long)fC * cap;
     const uint32_t *idxK = featIdx + (long long)fK * cap, *idxC = featIdx + (long long)fC * cap;
     const uint8_t* flags = kfFlags + (long long)pair * cap;
@@ -70,9 +77,21 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
     const Keypoint *kpK = kps + (long long)fK * cap, *kpC = kps + (long long)fC * cap;
     if (tid == 0) { sSeg = 0; sCount = 0; }
     if (tid < kHistoLength) sHist[tid] = 0;
-    for (int i = tid; i < MK; i += kThreads) nodeK[i] = gNodeK[i];
-    for (int i = tid; i < MC; i += kThreads) nodeC[i] = gNodeC[i];
-    for (int i = tid; i < cap; i += kThreads) { takenBy[i] = -1; binOf[i] = 255; }
+    for (int i = tid; i < MK; i += kThreads) { nodeK[i] = gNodeK[i]; sIdxK[i] = (unsigned short)idxK[i]; }
+    for (int i = tid; i < MC; i += kThreads) { nodeC[i] = gNodeC[i]; sIdxC[i] = (unsigned short)idxC[i]; }
+    for (int i = tid; i < cap; i += kThreads) { takenBy[i] = -1; binOf[i] = 255; sFlag[i] = flags[i]; }
+    if constexpr (STAGE) {
+        for (int i = tid; i < 2 * NK; i += kThreads) sDescK[i] = ((const uint4*)descK)[i];
+        for (int i = tid; i < 2 * NC; i += kThreads) sDescC[i] = ((const uint4*)descC)[i];
+    }
+    auto loadK = [&](int idx, uint4& a, uint4& b) {
+        if constexpr (STAGE) { a = sDescK[2 * idx]; b = sDescK[2 * idx + 1]; }
+        else { a = *(const uint4*)(descK + (long long)idx * 8); b = *(const uint4*)(descK + (long long)idx * 8 + 4); }
+    };
+    auto loadC = [&](int idx, uint4& a, uint4& b) {
+        if constexpr (STAGE) { a = sDescC[2 * idx]; b = sDescC[2 * idx + 1]; }
+        else { a = *(const uint4*)(descC + (long long)idx * 8); b = *(const uint4*)(descC + (long long)idx * 8 + 4); }
+    };
     __syncthreads();
     for (int i = tid; i < MK; i += kThreads)
         if (i == 0 || nodeK[i] != nodeK[i - 1]) segList[atomicAdd(&sSeg, 1)] = i;      // (any order: nodes are independent)
@@ -90,14 +109,16 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
         int c1 = c0 + 1;
         while (c1 < MC && nodeC[c1] == node) c1++;
         for (int k = k0; k < MK && nodeK[k] == node; k++) {                                 // vIndicesKF in list order (:297)
-            const int realIdxKF = (int)idxK[k];
-            if (!(flags[realIdxKF] & 1)) continue;                                          // no MapPoint, or a bad one (:303-307)
-            const uint4 a = *(const uint4*)(descK + (long long)realIdxKF * 8), b = *(const uint4*)(descK + (long long)realIdxKF * 8 + 4);
+            const int realIdxKF = (int)sIdxK[k];
+            if (!(sFlag[realIdxKF] & 1)) continue;                                          // no MapPoint, or a bad one (:303-307)
+            uint4 a, b;
+            loadK(realIdxKF, a, b);
             unsigned key = kNoneKey, second = kNoneKey;
             for (int c = c0 + sub; c < c1; c += 16) {
-                const int realIdxF = (int)idxC[c];
+                const int realIdxF = (int)sIdxC[c];
                 if (takenBy[realIdxF] >= 0) continue;                                       // :318-319
-                const uint4 x = *(const uint4*)(descC + (long long)realIdxF * 8), y = *(const uint4*)(descC + (long long)realIdxF * 8 + 4);
+                uint4 x, y;
+                loadC(realIdxF, x, y);
                 const int dist = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) +
                                  __popc(b.y ^ y.y) + __popc(b.z ^ y.z) + __popc(b.w ^ y.w);
                 const unsigned kk = ((unsigned)dist << 16) | (unsigned)(c - c0);            // positions ascend per lane: a later equal distance never displaces (:325, :331)
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
             const unsigned best2 = rowMin16(key == best ? second : key);
             const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(best2 >> 16);
             if (bestDist1 <= p.thLow && (float)bestDist1 < __fmul_rn(p.nnRatio, (float)bestDist2)) {       // :375-377
-                const int bestIdxF = (int)idxC[c0 + (int)(best & 0xFFFFu)];
+                const int bestIdxF = (int)sIdxC[c0 + (int)(best & 0xFFFFu)];
                 if (sub == 0) {
                     takenBy[bestIdxF] = realIdxKF;                                          // vpMapPointMatches[bestIdxF] = pMP
                     if (p.checkOrientation) {                                               // :384-401
@@ -154,8 +175,12 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
 
 void launchSearchBow(hipStream_t st, const uint32_t* featNodes, const uint32_t* featIdx, const int* nFeat, const uint8_t* kfFlags,
                      const Keypoint* kps, const uint8_t* desc, const int* nOut, const BowMatchParams& p, int* matches, int* nMatches, int nPairs) {
-    hipLaunchKernelGGL(k_search_bow, dim3(nPairs), dim3(kThreads), bowMatchLdsBytes(p.capacity), st, featNodes, featIdx, nFeat, kfFlags, kps, desc,
-                       nOut, p, matches, nMatches);
+    if (bowMatchLdsBytes(p.capacity, true) <= 150 * 1024)
+        hipLaunchKernelGGL(k_search_bow<true>, dim3(nPairs), dim3(kThreads), bowMatchLdsBytes(p.capacity, true), st, featNodes, featIdx, nFeat, kfFlags,
+                           kps, desc, nOut, p, matches, nMatches);
+    else
+        hipLaunchKernelGGL(k_search_bow<false>, dim3(nPairs), dim3(kThreads), bowMatchLdsBytes(p.capacity, false), st, featNodes, featIdx, nFeat, kfFlags,
+                           kps, desc, nOut, p, matches, nMatches);
 }
 
 }  // namespace orbx

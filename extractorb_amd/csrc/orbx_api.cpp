@@ -22,7 +22,7 @@ void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, con
                   uint8_t*, int, int, bool, int, int);
 void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep; };
-size_t bowMatchLdsBytes(int capacity);
+size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
@@ -1302,7 +1302,7 @@ int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_
         capacity < 1 || n_pairs < 1 || kf_first < 0 || cur_first < 0 || kf_first + (long long)(n_pairs - 1) * kf_step < 0 ||
         cur_first + (long long)(n_pairs - 1) * cur_step < 0)
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1 or a negative frame index");
-    if (bowMatchLdsBytes(capacity) > 150 * 1024) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large: the node columns and the match table of a pair live in LDS");
+    if (capacity > 65535 || bowMatchLdsBytes(capacity, false) > 150 * 1024) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large: the node columns and the match table of a pair live in LDS");
     HIP_TRY(h, hipSetDevice(h->device));
     BowMatchParams p{nn_ratio, th_low, check_orientation ? 1 : 0, capacity, kf_first, kf_step, cur_first, cur_step};
     {
