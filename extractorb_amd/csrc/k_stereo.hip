@@ -243,29 +243,49 @@ __global__ __launch_bounds__(256) void k_stereo_match(const LevelGeom* __restric
 __global__ __launch_bounds__(1024) void k_stereo_filter(const int* __restrict__ nOut, StereoParams sp, float* __restrict__ uRight,
                                                          float* __restrict__ depth, const int* __restrict__ sadDist,
                                                          int* __restrict__ nMatched) {
-    extern __shared__ int d[];   // [capacity] SAD distances, -1 = unmatched
-    __shared__ int sCnt, sMedian, sKept;
+    extern __shared__ __align__(16) int d[];   // [capacity rounded up to 4] SAD distances, -1 = unmatched
+    __shared__ int sCnt, sMedian, sKept, hist[256], sSel[2];
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int N = min(nOut[2 * pair], sp.capacity);
     const long long base = (long long)pair * sp.capacity;
     if (tid == 0) { sCnt = 0; sMedian = 0; sKept = 0; }
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < N; i += 1024) { d[i] = sadDist[base + i]; mine += d[i] >= 0; }
+    for (int i = tid; i < ((N + 3) & ~3); i += 1024) { d[i] = i < N ? sadDist[base + i] : -1; mine += d[i] >= 0; }      // padded to whole int4s (unmatched)
     if (mine) atomicAdd(&sCnt, mine);
     __syncthreads();
     const int cnt = sCnt;
     if (cnt == 0) { if (tid == 0) nMatched[pair] = 0; return; }       // the reference reads vDistIdx[0] here (undefined)
     const int kth = cnt / 2;
-    for (int i = tid; i < N; i += 1024) {
-        const int di = d[i];
-        if (di < 0) continue;
-        int rank = 0;
-        for (int j = 0; j < N; j++) {
-            const int dj = d[j];
-            rank += dj >= 0 && (dj < di || (dj == di && j < i));
+    // the median is the kth smallest distance VALUE (the index only orders equal distances): radix select, most significant byte first —
+    // per byte a 256-bin LDS histogram of the distances that share the prefix found so far, and one wave's scan for the bin that holds
+    // rank kth.  (Counting every keypoint's rank against every other is O(N^2) on ONE CU: 75 of this kernel's 85 us for one pair.)
+    {
+        unsigned prefix = 0u;
+        int remaining = kth;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned himask = shift == 24 ? 0u : ~0u << (shift + 8);
+            for (int i = tid; i < N; i += 1024) {
+                const int di = d[i];
+                if (di >= 0 && ((unsigned)di & himask) == prefix) atomicAdd(&hist[((unsigned)di >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {      // wave 0: bins 4 lane .. 4 lane + 3, inclusive scan of the lane sums, first bin whose running count exceeds `remaining`
+                const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                const int incl = waveInclusiveScan(c0 + c1 + c2 + c3), before = incl - (c0 + c1 + c2 + c3);
+                if (before <= remaining && remaining < incl) {      // exactly one lane
+                    int b = 0, cum = before;
+                    if (remaining >= cum + c0) { cum += c0; b = 1; if (remaining >= cum + c1) { cum += c1; b = 2; if (remaining >= cum + c2) { cum += c2; b = 3; } } }
+                    sSel[0] = 4 * tid + b; sSel[1] = cum;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)sSel[0] << shift;
+            remaining -= sSel[1];
         }
-        if (rank == kth) sMedian = di;
+        if (tid == 0) sMedian = (int)prefix;
     }
     __syncthreads();
     const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)sMedian);
@@ -288,7 +308,7 @@ void launchStereo(hipStream_t st, const LevelGeom* lv, const uint8_t* pyr, const
                        rowOff, rowList);
     hipLaunchKernelGGL(k_stereo_match, dim3((sp.capacity + 3) / 4, nPairs), dim3(256), 0, st, lv, pyr, kps, desc, nOut, sp,
                        rows, rowOff, rowList, uRight, depth, sadDist);
-    hipLaunchKernelGGL(k_stereo_filter, dim3(nPairs), dim3(1024), (size_t)sp.capacity * sizeof(int), st, nOut, sp, uRight,
+    hipLaunchKernelGGL(k_stereo_filter, dim3(nPairs), dim3(1024), (size_t)((sp.capacity + 3) & ~3) * sizeof(int), st, nOut, sp, uRight,
                        depth, sadDist, nMatched);
 }
 
