@@ -19,6 +19,10 @@ run --steps 30 --workload hd1080
 run --steps 30 --workload hd1080 --variant natural
 run --steps 300 --batch 1
 run --steps 300 --batch 2 --workload stereo640
+run --steps 200 --batch 2 --workload stereo640_match
+run --steps 200 --batch 2 --workload mono640_track
+run --steps 200 --batch 2 --workload mono640_refkf
+run --steps 200 --batch 2 --workload mono640_init
 run --steps 200 --batch 8
 run --steps 100 --batch 64
 run --steps 50 --batch 256
