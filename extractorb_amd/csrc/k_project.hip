@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_project_last(const Keypoint* __restrict
 
 size_t projSearchLdsBytes(int capacity, int queryCapacity, bool topList) {
     const size_t c = (size_t)((capacity + 3) & ~3);
-    return c * (32 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 2 + 1 + 1 + 2) + (kCells + 1 + kHistoLength + 4) * sizeof(int) +
+    return c * (32 + 4 + 4 + 4 + 4 + 4 + 2 + 1 + 1 + 2) + (kHistoLength + 4) * sizeof(int) + (kCells + 2) * sizeof(unsigned short) +
            (size_t)queryCapacity * (4 + 1 + (topList ? 4 * kTop : 0)) + 64;
 }
 __device__ int g_searchRounds[4];      // diagnostics: rounds the last launch's pair 0 needed (projection search, initialisation search)
@@ -142,15 +142,15 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     float* y2 = x2 + capA;
     float* a2 = y2 + capA;                                 // angle
     float* ur2 = a2 + capA;                                // mvuRight (<= 0: no stereo observation)
-    int* m2q = (int*)(ur2 + capA);                         // query whose MapPoint the keypoint holds, -1 = none
-    unsigned* binMask = (unsigned*)(m2q + capA);           // rotHist bins the keypoint was pushed to
-    int* closedBy = (int*)(binMask + capA);                // [capA] first request that closes the keypoint (-1: closed on entry, INT_MAX: nobody)
+    int* m2q = (int*)d2w;                                  // (after the rounds, over the then dead descriptor words) query whose MapPoint the keypoint holds, -1 = none
+    unsigned* binMask = (unsigned*)(m2q + capA);           // (same) rotHist bins the keypoint was pushed to
+    int* closedBy = (int*)(ur2 + capA);                    // [capA] first request that closes the keypoint (-1: closed on entry, INT_MAX: nobody)
     int* top = closedBy + capA;                            // [queryCapacity][kTop] (TOPLIST; 16-byte aligned) the requests' smallest keys, ascending
-    int* cellOff = top + (TOPLIST ? (long long)p.queryCapacity * kTop : 0);      // [kCells + 1] slot range of every grid cell (mGrid's CSR offsets)
-    unsigned* dec = (unsigned*)(cellOff + kCells + 1);     // [queryCapacity] decision of every request: slot | closes << 16, or kNoDecision
+    unsigned* dec = (unsigned*)(top + (TOPLIST ? (long long)p.queryCapacity * kTop : 0));      // [queryCapacity] decision of every request: slot | closes << 16, or kNoDecision
     int* hist = (int*)(dec + p.queryCapacity);             // [30] rotHist sizes
     int* flags = hist + kHistoLength;                      // [3] "a decision changed" (two alternating slots), number of accepted requests
-    unsigned short* idx2 = (unsigned short*)(flags + 4);   // keypoint index in the frame
+    unsigned short* cellOff = (unsigned short*)(flags + 4);      // [kCells + 2] slot range of every grid cell (mGrid's CSR offsets)
+    unsigned short* idx2 = cellOff + kCells + 2;           // keypoint index in the frame
     uint8_t* oct2 = (uint8_t*)(idx2 + capA);               // octave
     uint8_t* occ = oct2 + capA;                            // holds a MapPoint with Observations() > 0
     uint8_t* qflag = occ + capA;                           // [queryCapacity] orbx_proj_query::flags
@@ -181,13 +181,12 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
         idx2[slot] = (unsigned short)i2;
         oct2[slot] = (uint8_t)min(max(k.octave, 0), 255);
         occ[slot] = occIO ? occIO[i2] : (uint8_t)0;
-        m2q[slot] = -1; binMask[slot] = 0u;
         const uint4 lo = *(const uint4*)(D2 + (long long)i2 * 8), hi = *(const uint4*)(D2 + (long long)i2 * 8 + 4);
         d2w[0 * capA + slot] = lo.x; d2w[1 * capA + slot] = lo.y; d2w[2 * capA + slot] = lo.z; d2w[3 * capA + slot] = lo.w;
         d2w[4 * capA + slot] = hi.x; d2w[5 * capA + slot] = hi.y; d2w[6 * capA + slot] = hi.z; d2w[7 * capA + slot] = hi.w;
     }
     for (int i = tid; i < cap; i += kThreads) out[i] = -1;     // keypoints outside the grid can never match
-    for (int c = tid; c <= kCells; c += kThreads) cellOff[c] = min(off2[c], n2);      // mGrid's CSR offsets: slot range of every cell
+    for (int c = tid; c <= kCells; c += kThreads) cellOff[c] = (unsigned short)min(off2[c], n2);      // mGrid's CSR offsets: slot range of every cell
     for (int i = tid; i < NQ; i += kThreads) dec[i] = kNoDecision;
     if (tid < kHistoLength) hist[tid] = 0;
     if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; }
@@ -310,6 +309,8 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     }
     // ---- the tables the walk would have left: F.mvpMapPoints[bestIdx] = pMP is overwritten by every later accepted request
     //      (a MapPoint without observations does not close its keypoint), nmatches and rotHist count every acceptance ----
+    for (int s = tid; s < n2; s += kThreads) { m2q[s] = -1; binMask[s] = 0u; }      // (nobody reads the descriptor words any more)
+    __syncthreads();
     int nm = 0;
     for (int iq = tid; iq < NQ; iq += kThreads) {
         const unsigned d = dec[iq];

@@ -346,3 +346,81 @@ def test_gpu_search_argument_errors():
         ex.search_by_projection_device(0, (0, 1), z, z, (0, 1), None, 16, z, z, z, 16, z, z, b, None, None, False, 0.9, True, z, z)      # n_pairs
     with pytest.raises(X.OrbxError):
         ex.search_by_projection_device(1, (0, 1), None, z, (0, 1), None, 16, z, z, z, 16, z, z, b, None, None, False, 0.9, True, z, z)   # null
+
+
+def crowd_scene(rng, n=400, nq=700, clusters=6, ratio=False):
+    """Many requests compete for few keypoints: every cluster holds ~n/clusters keypoints within a few pixels, all on neighbouring levels,
+    with near-identical descriptors, and ~nq/clusters requests that all aim at the cluster centre with a radius covering it.  In the
+    reference each accepted request closes its keypoint and the next one has to settle for the next best: dependency chains as long as the
+    cluster, best-key lists that run dry (the kernel's re-scan path), ties everywhere."""
+    cam = O.camera(**CAM)
+    b = O.image_bounds(cam, COLS, ROWS)
+    centres = np.stack([rng.uniform(60, COLS - 60, clusters), rng.uniform(60, ROWS - 60, clusters)], 1)
+    k = np.zeros(n, O.KEYPOINT_DTYPE)
+    which = rng.integers(0, clusters, n)
+    k["x"] = (centres[which, 0] + rng.uniform(-9, 9, n)).astype(np.float32); k["y"] = (centres[which, 1] + rng.uniform(-9, 9, n)).astype(np.float32)
+    k["octave"] = rng.integers(1, 4, n); k["angle"] = rng.uniform(0, 360, n).astype(np.float32); k["size"], k["class_id"] = 31, -1
+    proto = rng.integers(0, 256, (clusters, 32), dtype=np.uint8)
+    d = proto[which].copy()
+    for i in range(n):
+        for bit in rng.integers(0, 256, int(rng.integers(0, 4))):
+            d[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+    un, off, idx = O.frame_finish(cam, k, b)
+    q = np.zeros(nq, O.PROJ_QUERY_DTYPE); qd = np.zeros((nq, 32), np.uint8)
+    for i in range(nq):
+        c = int(rng.integers(0, clusters))
+        q["u"][i], q["v"][i] = centres[c, 0] + rng.uniform(-2, 2), centres[c, 1] + rng.uniform(-2, 2)
+        q["radius"][i] = np.float32(rng.choice([9.0, 14.0, 30.0]))
+        q["ur"][i] = q["u"][i] - 8.0
+        q["min_level"][i], q["max_level"][i] = [(0, -1), (1, 3), (2, -1), (-1, -1)][int(rng.integers(0, 4))]
+        q["flags"][i] = 1 | (2 if rng.random() < 0.9 else 0)
+        q["angle"][i] = np.float32(rng.uniform(0, 360))
+        qd[i] = proto[c]
+        for bit in rng.integers(0, 256, int(rng.integers(0, 3))):
+            qd[i, bit >> 3] ^= np.uint8(1 << (bit & 7))
+    ur = np.full(n, -1.0, np.float32)
+    occ = (rng.random(n) < 0.05).astype(np.uint8)
+    return dict(un=un, d=d, off=off, idx=idx, bounds=b, q=q, qd=qd, ur=ur, occ=occ)
+
+
+@pytest.mark.parametrize("seed,ratio", [(21, False), (22, True)])
+def test_oracle_crowded_requests_equal_brute_force(seed, ratio):
+    rng = np.random.default_rng(seed)
+    s = crowd_scene(rng, ratio=ratio)
+    inside = {int(i): p for p, i in enumerate(s["idx"])}
+    nm, m, o = O.search_by_projection(s["q"], s["qd"], s["un"], s["d"], s["off"], s["idx"], s["bounds"], None, s["occ"], ratio, 0.8, not ratio, 100)
+    bn, bm, bo = brute_search(s["q"], s["qd"], s["un"], s["d"], inside, s["bounds"], None, s["occ"], ratio, 0.8, not ratio)
+    assert nm == bn and m.tolist() == bm and o.tolist() == bo
+    assert (m >= 0).sum() > 60           # the crowds do get matched, one keypoint after the other (random angles: the histogram drops many)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,ratio,cap,qcap", [(21, False, 1024, 768), (22, True, 1024, 768), (23, False, 2200, 2200), (24, True, 2200, 1500)])
+def test_gpu_search_settles_crowded_requests_like_the_walk(seed, ratio, cap, qcap):
+    """The fixed point against the oracle's sequential walk where the chains are long; cap = 2200 takes the kernel variant without
+    best-key lists (they do not fit in LDS next to the staged frame)."""
+    import torch
+    P = 3
+    rng = np.random.default_rng(seed)
+    scenes = [crowd_scene(rng, n=int(rng.integers(300, 500)), nq=int(rng.integers(500, 760)), clusters=int(rng.integers(3, 9)), ratio=ratio) for _ in range(P)]
+    dev = _frames_to_device([dict(un=s["un"], d=s["d"], off=s["off"], idx=s["idx"]) for s in scenes], cap)
+    q = np.zeros((P, qcap), O.PROJ_QUERY_DTYPE); qd = np.zeros((P, qcap, 32), np.uint8); nq = np.zeros(P, np.int32)
+    occ = np.zeros((P, cap), np.uint8)
+    for p, s in enumerate(scenes):
+        q[p, :len(s["q"])] = s["q"]; qd[p, :len(s["q"])] = s["qd"]; nq[p] = len(s["q"]); occ[p, :len(s["occ"])] = s["occ"]
+    d_occ = _dev(occ)
+    d_m = torch.full((P, cap), -7, dtype=torch.int32, device="cuda"); d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    ex = X.ORBextractor(1000)
+    ex.search_by_projection_device(P, (0, 1), _dev(q.view(np.uint8)), _dev(qd), (0, 1), _dev(nq), qcap, dev["un"], dev["d"], dev["n"], cap,
+                                   dev["off"], dev["idx"], scenes[0]["bounds"], None, d_occ, ratio, 0.8, not ratio, d_m, d_nm)
+    ex.synchronize()
+    import ctypes as C
+    rounds = (C.c_int * 4)()
+    X.load_library().orbx_debug_search_rounds(rounds)
+    assert rounds[0] > 8                 # pair 0 really needed many rounds
+    for p, s in enumerate(scenes):
+        nm, m, o = O.search_by_projection(s["q"], s["qd"], s["un"], s["d"], s["off"], s["idx"], s["bounds"], None, s["occ"], ratio, 0.8, not ratio, 100)
+        n = len(s["un"])
+        assert int(d_nm[p]) == nm, "pair %d" % p
+        assert d_m[p, :n].cpu().numpy().tolist() == m.tolist(), "pair %d" % p
+        assert d_occ[p, :n].cpu().numpy().tolist() == o.tolist(), "pair %d" % p
