@@ -280,7 +280,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                             if (j == start) w = (w + 3) & ~3;    // (level 1: up to 3 px past the need, still inside the level's right border; the image: the kernel never reads past a row)
                             c.region[j] = ChainRegion{(short)sx0, (short)sy0, (short)w, (short)(sy1 - sy0 + 1)};
                             const int bytes = ((w + 3) & ~3) * (sy1 - sy0 + 1);
-                            if (j == start ? (bytes > maxW * maxH) : (w > kChainMaxW || sy1 - sy0 + 1 > kChainMaxH)) fits = false;
+                            if (j == start ? (bytes > maxW * maxH) : (w > kChainMaxW)) fits = false;      // (the loaded region: the staging's loads in flight; in between: one column quad per lane; the height only costs LDS, checked by the caller)
                             if (j & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
                             x0 = sx0; x1 = sx0 + w - 1 < g.lv[j].w ? sx0 + w - 1 : g.lv[j].w - 1; y0 = sy0; y1 = sy1;
                             if (j == start) x1 = sx1;            // (the padding columns of the loaded region are never sources of a needed pixel)
