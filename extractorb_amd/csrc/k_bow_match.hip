@@ -23,6 +23,7 @@ namespace orbx {
 struct BowMatchParams {
     float nnRatio;
     int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep;
+    int twoKeyFrames;      // SearchByBoW(pKF1, pKF2, vpMatches12): candidates must hold a MapPoint, strict threshold, result indexed by pKF1's keypoints
 };
 
 namespace {
@@ -52,7 +53,7 @@ size_t bowMatchLdsBytes(int capacity, bool stageDesc) { return (size_t)((capacit
 template <bool STAGE>
 __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restrict__ featNodes, const uint32_t* __restrict__ featIdx,
                                                          const int* __restrict__ nFeat, const uint8_t* __restrict__ kfFlags,
-                                                         const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                         const uint8_t* __restrict__ curFlags, const Keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                          const int* __restrict__ nOut, BowMatchParams p, int* __restrict__ matches,
                                                          int* __restrict__ nMatches) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -79,7 +80,11 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
     if (tid < kHistoLength) sHist[tid] = 0;
     for (int i = tid; i < MK; i += kThreads) { nodeK[i] = gNodeK[i]; sIdxK[i] = (unsigned short)idxK[i]; }
     for (int i = tid; i < MC; i += kThreads) { nodeC[i] = gNodeC[i]; sIdxC[i] = (unsigned short)idxC[i]; }
-    for (int i = tid; i < cap; i += kThreads) { takenBy[i] = -1; binOf[i] = 255; sFlag[i] = flags[i]; }
+    // (the second keyframe's keypoints without a good MapPoint are never candidates (:879-886): closed from the start, marked -2)
+    for (int i = tid; i < cap; i += kThreads) {
+        takenBy[i] = p.twoKeyFrames && !(curFlags[(long long)pair * cap + i] & 1) ? -2 : -1;
+        binOf[i] = 255; sFlag[i] = flags[i];
+    }
     if constexpr (STAGE) {
         for (int i = tid; i < 2 * NK; i += kThreads) sDescK[i] = ((const uint4*)descK)[i];
         for (int i = tid; i < 2 * NC; i += kThreads) sDescC[i] = ((const uint4*)descC)[i];
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
             unsigned key = kNoneKey, second = kNoneKey;
             for (int c = c0 + sub; c < c1; c += 16) {
                 const int realIdxF = (int)sIdxC[c];
-                if (takenBy[realIdxF] >= 0) continue;                                       // :318-319
+                if (takenBy[realIdxF] != -1) continue;                                      // :318-319 (:884-888)
                 uint4 x, y;
                 loadC(realIdxF, x, y);
                 const int dist = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) +
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
             const unsigned best = rowMin16(key);
             const unsigned best2 = rowMin16(key == best ? second : key);
             const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(best2 >> 16);
-            if (bestDist1 <= p.thLow && (float)bestDist1 < __fmul_rn(p.nnRatio, (float)bestDist2)) {       // :375-377
+            if ((p.twoKeyFrames ? bestDist1 < p.thLow : bestDist1 <= p.thLow) && (float)bestDist1 < __fmul_rn(p.nnRatio, (float)bestDist2)) {   // :375-377 (:908-910)
                 const int bestIdxF = (int)sIdxC[c0 + (int)(best & 0xFFFFu)];
                 if (sub == 0) {
                     takenBy[bestIdxF] = realIdxKF;                                          // vpMapPointMatches[bestIdxF] = pMP
@@ -162,10 +167,15 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
     }
     int mine = 0;
     int* out = matches + (long long)pair * cap;
+    if (p.twoKeyFrames) {      // vpMatches12[idx1] = vpMapPoints2[bestIdx2]: the table is indexed by the FIRST keyframe's keypoints
+        for (int i = tid; i < cap; i += kThreads) out[i] = -1;
+        __syncthreads();
+    }
     for (int i = tid; i < cap; i += kThreads) {
         int m = i < NC ? takenBy[i] : -1;
         if (m >= 0 && binOf[i] < kHistoLength && ((dropBins >> binOf[i]) & 1u)) m = -1;
-        out[i] = m;
+        if (!p.twoKeyFrames) out[i] = m;
+        else if (m >= 0) out[m] = i;
         mine += m >= 0;
     }
     if (mine) atomicAdd(&sCount, mine);
@@ -174,13 +184,13 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
 }
 
 void launchSearchBow(hipStream_t st, const uint32_t* featNodes, const uint32_t* featIdx, const int* nFeat, const uint8_t* kfFlags,
-                     const Keypoint* kps, const uint8_t* desc, const int* nOut, const BowMatchParams& p, int* matches, int* nMatches, int nPairs) {
+                     const uint8_t* curFlags, const Keypoint* kps, const uint8_t* desc, const int* nOut, const BowMatchParams& p, int* matches, int* nMatches, int nPairs) {
     if (bowMatchLdsBytes(p.capacity, true) <= 150 * 1024)
         hipLaunchKernelGGL(k_search_bow<true>, dim3(nPairs), dim3(kThreads), bowMatchLdsBytes(p.capacity, true), st, featNodes, featIdx, nFeat, kfFlags,
-                           kps, desc, nOut, p, matches, nMatches);
+                           curFlags, kps, desc, nOut, p, matches, nMatches);
     else
         hipLaunchKernelGGL(k_search_bow<false>, dim3(nPairs), dim3(kThreads), bowMatchLdsBytes(p.capacity, false), st, featNodes, featIdx, nFeat, kfFlags,
-                           kps, desc, nOut, p, matches, nMatches);
+                           curFlags, kps, desc, nOut, p, matches, nMatches);
 }
 
 }  // namespace orbx

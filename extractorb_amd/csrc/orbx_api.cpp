@@ -21,9 +21,9 @@ void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const Lev
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
 void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
-struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep; };
+struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
-void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
+void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
@@ -1293,10 +1293,10 @@ int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_fram
     return ORBX_OK;
 }
 
-int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step,
-                              const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags,
-                              const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
-                              int th_low, int check_orientation, int* d_matches, int* d_n_matches) {
+static int searchByBow(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step, const uint32_t* d_feat_nodes,
+                       const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags, const uint8_t* d_cur_mp_flags,
+                       const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio, int th_low,
+                       int check_orientation, int* d_matches, int* d_n_matches) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
     if (!d_feat_nodes || !d_feat_idx || !d_n_feat || !d_kf_mp_flags || !d_kps || !d_desc || !d_n_out || !d_matches || !d_n_matches ||
         capacity < 1 || n_pairs < 1 || kf_first < 0 || cur_first < 0 || kf_first + (long long)(n_pairs - 1) * kf_step < 0 ||
@@ -1304,13 +1304,30 @@ int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1 or a negative frame index");
     if (capacity > 65535 || bowMatchLdsBytes(capacity, false) > 150 * 1024) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large: the node columns and the match table of a pair live in LDS");
     HIP_TRY(h, hipSetDevice(h->device));
-    BowMatchParams p{nn_ratio, th_low, check_orientation ? 1 : 0, capacity, kf_first, kf_step, cur_first, cur_step};
+    BowMatchParams p{nn_ratio, th_low, check_orientation ? 1 : 0, capacity, kf_first, kf_step, cur_first, cur_step, d_cur_mp_flags ? 1 : 0};
     {
         Prof pr(h, S_FRAME);
-        launchSearchBow(h->stream, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, (const Keypoint*)d_kps, d_desc, d_n_out, p, d_matches, d_n_matches, n_pairs);
+        launchSearchBow(h->stream, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, d_cur_mp_flags, (const Keypoint*)d_kps, d_desc, d_n_out, p, d_matches,
+                        d_n_matches, n_pairs);
     }
     HIP_TRY(h, hipGetLastError());
     return ORBX_OK;
+}
+int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step,
+                              const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags,
+                              const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
+                              int th_low, int check_orientation, int* d_matches, int* d_n_matches) {
+    return searchByBow(h, n_pairs, kf_first, kf_step, cur_first, cur_step, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, nullptr, d_kps, d_desc,
+                       d_n_out, capacity, nn_ratio, th_low, check_orientation, d_matches, d_n_matches);
+}
+int orbx_search_by_bow_keyframes_device(orbx_handle* h, int n_pairs, int kf1_first, int kf1_step, int kf2_first, int kf2_step,
+                                        const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat,
+                                        const uint8_t* d_kf1_mp_flags, const uint8_t* d_kf2_mp_flags, const orbx_keypoint* d_kps,
+                                        const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio, int th_low,
+                                        int check_orientation, int* d_matches12, int* d_n_matches) {
+    if (h && !d_kf2_mp_flags) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer (the second keyframe's MapPoint flags)");
+    return searchByBow(h, n_pairs, kf1_first, kf1_step, kf2_first, kf2_step, d_feat_nodes, d_feat_idx, d_n_feat, d_kf1_mp_flags, d_kf2_mp_flags, d_kps,
+                       d_desc, d_n_out, capacity, nn_ratio, th_low, check_orientation, d_matches12, d_n_matches);
 }
 
 int orbx_profile_enable(orbx_handle* h, int enable) {

@@ -150,6 +150,8 @@ def load_library():
     L.orbx_compute_bow_device.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_search_by_bow_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
                                             C.c_int, C.c_int, vp, vp]
+    L.orbx_search_by_bow_keyframes_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
+                                                      C.c_float, C.c_int, C.c_int, vp, vp]
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -460,6 +462,16 @@ class ORBextractor:
         self._check(self._L.orbx_search_by_bow_device(self._h, n_pairs, kf[0], kf[1], cur[0], cur[1], dp(d_feat_nodes), dp(d_feat_idx),
                                                       dp(d_n_feat), dp(d_kf_mp_flags), dp(d_kps), dp(d_desc), dp(d_n), capacity,
                                                       C.c_float(nnratio), th_low, int(check_orientation), dp(d_matches), dp(d_n_matches)))
+
+    def search_by_bow_keyframes_device(self, n_pairs, kf1, kf2, d_feat_nodes, d_feat_idx, d_n_feat, d_kf1_mp_flags, d_kf2_mp_flags, d_kps, d_desc,
+                                       d_n, capacity, d_matches12, d_n_matches, nnratio=0.8, th_low=50, check_orientation=True):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (reference src/ORBmatcher.cc:823-963); kf1 and kf2 = (first, step)."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self._L.orbx_search_by_bow_keyframes_device(self._h, n_pairs, kf1[0], kf1[1], kf2[0], kf2[1], dp(d_feat_nodes), dp(d_feat_idx),
+                                                                dp(d_n_feat), dp(d_kf1_mp_flags), dp(d_kf2_mp_flags), dp(d_kps), dp(d_desc), dp(d_n),
+                                                                capacity, C.c_float(nnratio), th_low, int(check_orientation), dp(d_matches12),
+                                                                dp(d_n_matches)))
 
     def stereo_from_rgbd_device(self, n_frames, d_kps, d_kps_un, d_n, capacity, d_depth, depth_is_u16, rows, cols, depth_map_factor, mbf,
                                 d_u_right, d_depth_out, depth_stride_bytes=None, depth_frame_stride_bytes=None):

@@ -313,6 +313,17 @@ int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_
                               const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
                               int th_low, int check_orientation, int* d_matches, int* d_n_matches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (src/ORBmatcher.cc:823-963; LoopClosing.cc:624): as above between two
+ * keyframes — a keypoint of pKF2 is a candidate only if it holds a good MapPoint and has not been matched (:879-888), the threshold is strict
+ * (bestDist1 < TH_LOW, :908), and the result is indexed by pKF1's keypoints:
+ *   d_kf1_mp_flags / d_kf2_mp_flags[p*capacity + i] : bit 0 = keypoint i of keyframe 1 / 2 holds a MapPoint that is not bad
+ *   d_matches12[p*capacity + i]                     : out, the keypoint of pKF2 whose MapPoint vpMatches12[i] names, -1 = NULL */
+int orbx_search_by_bow_keyframes_device(orbx_handle* h, int n_pairs, int kf1_first, int kf1_step, int kf2_first, int kf2_step,
+                                        const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat,
+                                        const uint8_t* d_kf1_mp_flags, const uint8_t* d_kf2_mp_flags, const orbx_keypoint* d_kps,
+                                        const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio, int th_low,
+                                        int check_orientation, int* d_matches12, int* d_n_matches);
+
 /* Stream control.  By default the handle owns a stream; orbx_set_stream adopts a caller stream
  * (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) so the caller's events
  * and graphs see the work. */

@@ -1328,6 +1328,69 @@ int oracle_search_by_bow(const unsigned* kfNodes, const unsigned* kfIdx, int nKF
     return nmatches;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:823-963), NLeft == -1.
+// flags1 / flags2 bit 0 = "pMP && !pMP->isBad()" of the two keyframes' keypoints.  matches12[idx1] (out, N1 ints) = the keypoint of pKF2
+// whose MapPoint vpMatches12[idx1] names, -1 = NULL.  Returns nmatches.
+int oracle_search_by_bow_keyframes(const unsigned* nodes1, const unsigned* idx1_, int n1, const unsigned* nodes2, const unsigned* idx2_, int n2,
+                                   const uint8_t* flags1, const uint8_t* flags2, const void* kps1_, const uint8_t* desc1, int N1, const void* kps2_,
+                                   const uint8_t* desc2, int N2, float nnratio, int thLow, int checkOrientation, int* matches12) {
+    const KeyPoint* vKeysUn1 = (const KeyPoint*)kps1_;
+    const KeyPoint* vKeysUn2 = (const KeyPoint*)kps2_;
+    std::map<unsigned, std::vector<unsigned>> vFeatVec1, vFeatVec2;
+    for (int i = 0; i < n1; i++) vFeatVec1[nodes1[i]].push_back(idx1_[i]);
+    for (int i = 0; i < n2; i++) vFeatVec2[nodes2[i]].push_back(idx2_[i]);
+    for (int i = 0; i < N1; i++) matches12[i] = -1;                                      // :835
+    std::vector<bool> vbMatched2(N2, false);                                             // :836
+    const int HISTO_LENGTH = 30;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;                                            // :842
+    int nmatches = 0;
+    auto f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+    auto f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+    while (f1it != f1end && f2it != f2end) {                                             // :851
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+                const size_t idx1 = f1it->second[i1];
+                if (!(flags1[idx1] & 1)) continue;                                       // :862-866
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+                    const size_t idx2 = f2it->second[i2];
+                    if (vbMatched2[idx2] || !(flags2[idx2] & 1)) continue;               // :884-888
+                    const int dist = descriptorDistance(d1, desc2 + idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }     // :894-899
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < thLow) {                                                 // :906 (strict, unlike :375)
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        matches12[idx1] = bestIdx2;                                      // vpMatches12[idx1] = vpMapPoints2[bestIdx2]
+                        vbMatched2[bestIdx2] = true;
+                        if (checkOrientation) {
+                            float rot = vKeysUn1[idx1].angle - vKeysUn2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (f1it->first < f2it->first) f1it = vFeatVec1.lower_bound(f2it->first);
+        else f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+    if (checkOrientation) {                                                              // :940-960
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 // cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) for 8-bit images as Tracking::GrabImage* calls it
 // (src/Tracking.cc:915-941, 985-1001).  OpenCV 3.4 generic path: 14-bit fixed point with R2Y = 4899, G2Y = 9617,
 // B2Y = 1868 and CV_DESCALE's rounding; alpha ignored.

@@ -81,6 +81,8 @@ def lib():
         L.oracle_search_by_projection.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
         L.oracle_search_by_bow.restype = C.c_int
         L.oracle_search_by_bow.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
+        L.oracle_search_by_bow_keyframes.restype = C.c_int
+        L.oracle_search_by_bow_keyframes.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp]
         L.oracle_compute_bow.restype = C.c_int
         L.oracle_compute_bow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, ip]
         L.oracle_stereo_from_rgbd.restype = None
@@ -291,6 +293,21 @@ def search_by_bow(kf_fv, f_fv, kf_flags, kps_kf, desc_kf, kps_f, desc_f, nnratio
     n = lib().oracle_search_by_bow(_ptr(pad(kn)), _ptr(pad(ki)), len(kn), _ptr(pad(fn)), _ptr(pad(fi)), len(fn), _ptr(pad(fl)), _ptr(pad(kk)), _ptr(pad(dk)),
                                    _ptr(pad(kf)), _ptr(pad(df)), NF, nnratio, th_low, int(check_orientation), _ptr(m))
     return n, m[:NF].copy()
+
+
+def search_by_bow_keyframes(fv1, fv2, flags1, flags2, kps1, desc1, kps2, desc2, nnratio=0.8, th_low=50, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (reference src/ORBmatcher.cc:823-963).  Returns (nmatches, matches12[N1])."""
+    n1, i1 = (np.ascontiguousarray(a, np.uint32) for a in fv1)
+    n2, i2 = (np.ascontiguousarray(a, np.uint32) for a in fv2)
+    k1 = np.ascontiguousarray(kps1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(kps2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    f1 = np.ascontiguousarray(flags1, np.uint8); f2 = np.ascontiguousarray(flags2, np.uint8)
+    m = np.full(max(len(k1), 1), -1, np.int32)
+    pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+    n = lib().oracle_search_by_bow_keyframes(_ptr(pad(n1)), _ptr(pad(i1)), len(n1), _ptr(pad(n2)), _ptr(pad(i2)), len(n2), _ptr(pad(f1)), _ptr(pad(f2)),
+                                             _ptr(pad(k1)), _ptr(pad(d1)), len(k1), _ptr(pad(k2)), _ptr(pad(d2)), len(k2), nnratio, th_low,
+                                             int(check_orientation), _ptr(m))
+    return n, m[:len(k1)].copy()
 
 
 def stereo_from_rgbd(kps, kps_un, depth, factor, mbf):

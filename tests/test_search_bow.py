@@ -189,3 +189,98 @@ def test_gpu_search_by_bow_on_extracted_frames():
         assert int(d_nm[p]) == want_n and d_m[p, :n[b]].cpu().numpy().tolist() == want.tolist(), "pair %d" % p
         total += want_n
     assert total > 150      # shifted views of one scene do match
+
+
+# ---- the keyframe-to-keyframe overload: ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher.cc:823-963) ----
+
+def brute_keyframes(p, flags2, nnratio, th_low, check):
+    (kn, ki), (fn, fi) = p["fv_k"], p["fv_f"]
+    bits_k = np.unpackbits(p["dk"], axis=1).astype(np.int16); bits_f = np.unpackbits(p["df"], axis=1).astype(np.int16)
+    m12 = np.full(len(p["dk"]), -1, np.int64)
+    matched2 = np.zeros(len(p["df"]), bool)
+    bins = {}
+    for node in sorted(set(kn.tolist()) & set(fn.tolist())):
+        fs = fi[fn == node]
+        for k in ki[kn == node]:
+            if not p["flags"][k] & 1:
+                continue
+            free = [int(f) for f in fs if not matched2[f] and flags2[f] & 1]
+            if not free:
+                continue
+            dist = np.abs(bits_f[free] - bits_k[k]).sum(1)
+            order = np.argsort(dist, kind="stable")
+            b1 = int(dist[order[0]]); b2 = int(dist[order[1]]) if len(free) > 1 else 256
+            if b1 < th_low and np.float32(b1) < np.float32(nnratio) * np.float32(b2):
+                f = free[int(order[0])]
+                m12[k] = f; matched2[f] = True
+                rot = np.float32(p["kps_k"]["angle"][k]) - np.float32(p["kps_f"]["angle"][f])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360.0))
+                bins[int(k)] = int(np.floor(float(np.float32(rot * np.float32(1.0 / 30))) + 0.5)) % 30
+    if check:
+        cnt = [sum(1 for b in bins.values() if b == i) for i in range(30)]
+        m1 = m2 = m3 = 0; i1 = i2 = i3 = -1
+        for i, s in enumerate(cnt):
+            if s > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+            elif s > m2:
+                m3, m2, i3, i2 = m2, s, i2, i
+            elif s > m3:
+                m3, i3 = s, i
+        if m2 < np.float32(0.1) * np.float32(m1):
+            i2 = i3 = -1
+        elif m3 < np.float32(0.1) * np.float32(m1):
+            i3 = -1
+        for k, b in bins.items():
+            if b not in (i1, i2, i3):
+                m12[k] = -1
+    return int((m12 >= 0).sum()), m12
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_oracle_keyframe_search_by_bow_equals_independent_statement(case):
+    rng = np.random.default_rng(case["seed"] + 40)
+    p = synthetic_pair(rng, case.get("n_kf", 900), case.get("n_f", 1000), case.get("n_nodes", 60), case.get("tie_heavy", False))
+    flags2 = (rng.random(len(p["df"])) < 0.7).astype(np.uint8)
+    nn, th, chk = case.get("nnratio", 0.8), case.get("th_low", 50), case.get("check", True)
+    n, m = O.search_by_bow_keyframes(p["fv_k"], p["fv_f"], p["flags"], flags2, p["kps_k"], p["dk"], p["kps_f"], p["df"], nn, th, chk)
+    bn, bm = brute_keyframes(p, flags2, nn, th, chk)
+    assert n == bn and m.tolist() == bm.tolist()
+    got = m[m >= 0]
+    assert len(set(got.tolist())) == len(got) and all(flags2[g] & 1 for g in got)
+    if case.get("n_nodes", 60) <= 60:
+        assert n > 80
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_gpu_keyframe_search_by_bow_equals_oracle(case):
+    import torch
+    rng = np.random.default_rng(case["seed"] + 140)
+    pairs = [synthetic_pair(rng, case.get("n_kf", 900) - 13 * i, case.get("n_f", 1000) - 29 * i, case.get("n_nodes", 60), case.get("tie_heavy", False))
+             for i in range(3)]
+    nn, th, chk = case.get("nnratio", 0.8), case.get("th_low", 50), case.get("check", True)
+    cap = 1024
+    B = 2 * len(pairs)
+    desc = np.zeros((B, cap, 32), np.uint8); kps = np.zeros((B, cap), X.KEYPOINT_DTYPE)
+    fn = np.zeros((B, cap), np.uint32); fi = np.zeros((B, cap), np.uint32)
+    nfeat = np.zeros(B, np.int32); nout = np.zeros(B, np.int32)
+    flags1 = np.zeros((len(pairs), cap), np.uint8); flags2 = np.zeros((len(pairs), cap), np.uint8)
+    for i, p in enumerate(pairs):
+        for f, (d, k, fv) in ((2 * i, (p["dk"], p["kps_k"], p["fv_k"])), (2 * i + 1, (p["df"], p["kps_f"], p["fv_f"]))):
+            desc[f, :len(d)] = d; kps[f, :len(k)] = k; nout[f] = len(d)
+            fn[f, :len(fv[0])] = fv[0]; fi[f, :len(fv[1])] = fv[1]; nfeat[f] = len(fv[0])
+        flags1[i, :len(p["flags"])] = p["flags"]
+        flags2[i, :len(p["df"])] = (rng.random(len(p["df"])) < 0.7).astype(np.uint8) | 2      # bit 1 is noise
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8) if a.dtype.fields else np.ascontiguousarray(a)).cuda()
+    d_m = torch.full((len(pairs), cap), -7, dtype=torch.int32, device="cuda"); d_nm = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    ex = X.ORBextractor(1000)
+    ex.search_by_bow_keyframes_device(len(pairs), (0, 2), (1, 2), dev(fn.view(np.int32)), dev(fi.view(np.int32)), dev(nfeat), dev(flags1), dev(flags2),
+                                      dev(kps), dev(desc), dev(nout), cap, d_m, d_nm, nnratio=nn, th_low=th, check_orientation=chk)
+    ex.synchronize()
+    m = d_m.cpu().numpy()
+    for i, p in enumerate(pairs):
+        n, want = O.search_by_bow_keyframes(p["fv_k"], p["fv_f"], p["flags"], flags2[i, :len(p["df"])], p["kps_k"], p["dk"], p["kps_f"], p["df"], nn, th, chk)
+        assert int(d_nm[i]) == n, "pair %d" % i
+        assert m[i, :len(want)].tolist() == want.tolist(), "pair %d" % i
+        assert (m[i, len(want):] == -1).all()
