@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_project_last(const Keypoint* __restrict
 
 size_t projSearchLdsBytes(int capacity, int queryCapacity, bool topList) {
     const size_t c = (size_t)((capacity + 3) & ~3);
-    return c * (32 + 4 + 4 + 4 + 4 + 4 + 2 + 1 + 1 + 2) + (kHistoLength + 4) * sizeof(int) + (kCells + 2) * sizeof(unsigned short) +
+    return c * (32 + 16 + 4 + 4 + 2 + 1 + 1 + 2) + (kHistoLength + 4) * sizeof(int) + (kCells + 2) * sizeof(unsigned short) +
            (size_t)queryCapacity * (4 + 1 + (topList ? 4 * kTop : 0)) + 64;
 }
 __device__ int g_searchRounds[4];      // diagnostics: rounds the last launch's pair 0 needed (projection search, initialisation search)
@@ -137,14 +137,12 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
                                                           ProjSearchParams p, int* __restrict__ matches, int* __restrict__ nMatches) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int cap = p.capacity, capA = (cap + 3) & ~3;
-    uint32_t* d2w = (uint32_t*)smem;                       // [8][capA] descriptor word k of slot s
-    float* x2 = (float*)(d2w + 8 * capA);                  // [capA]
-    float* y2 = x2 + capA;
-    float* a2 = y2 + capA;                                 // angle
-    float* ur2 = a2 + capA;                                // mvuRight (<= 0: no stereo observation)
-    int* m2q = (int*)d2w;                                  // (after the rounds, over the then dead descriptor words) query whose MapPoint the keypoint holds, -1 = none
+    uint4* d2 = (uint4*)smem;                              // [capA][2] descriptor of slot s (two 128-bit LDS reads per candidate)
+    float4* rec = (float4*)(d2 + 2 * capA);                // [capA] {x, y, mvuRight (<= 0: no stereo observation), octave as bits}: one read per visited slot
+    float* a2 = (float*)(rec + capA);                      // [capA] angle
+    int* m2q = (int*)d2;                                   // (after the rounds, over the then dead descriptors) query whose MapPoint the keypoint holds, -1 = none
     unsigned* binMask = (unsigned*)(m2q + capA);           // (same) rotHist bins the keypoint was pushed to
-    int* closedBy = (int*)(ur2 + capA);                    // [capA] first request that closes the keypoint (-1: closed on entry, INT_MAX: nobody)
+    int* closedBy = (int*)(a2 + capA);                    // [capA] first request that closes the keypoint (-1: closed on entry, INT_MAX: nobody)
     int* top = closedBy + capA;                            // [queryCapacity][kTop] (TOPLIST; 16-byte aligned) the requests' smallest keys, ascending
     unsigned* dec = (unsigned*)(top + (TOPLIST ? (long long)p.queryCapacity * kTop : 0));      // [queryCapacity] decision of every request: slot | closes << 16, or kNoDecision
     int* hist = (int*)(dec + p.queryCapacity);             // [30] rotHist sizes
@@ -176,14 +174,14 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     for (int slot = tid; slot < n2; slot += kThreads) {
         const int i2 = gi2[slot];
         const Keypoint k = K2[i2];
-        x2[slot] = k.x; y2[slot] = k.y; a2[slot] = k.angle;
-        ur2[slot] = UR ? UR[i2] : -1.0f;
+        const int oct = min(max(k.octave, 0), 255);
+        rec[slot] = make_float4(k.x, k.y, UR ? UR[i2] : -1.0f, __int_as_float(oct));
+        a2[slot] = k.angle;
         idx2[slot] = (unsigned short)i2;
-        oct2[slot] = (uint8_t)min(max(k.octave, 0), 255);
+        oct2[slot] = (uint8_t)oct;
         occ[slot] = occIO ? occIO[i2] : (uint8_t)0;
         const uint4 lo = *(const uint4*)(D2 + (long long)i2 * 8), hi = *(const uint4*)(D2 + (long long)i2 * 8 + 4);
-        d2w[0 * capA + slot] = lo.x; d2w[1 * capA + slot] = lo.y; d2w[2 * capA + slot] = lo.z; d2w[3 * capA + slot] = lo.w;
-        d2w[4 * capA + slot] = hi.x; d2w[5 * capA + slot] = hi.y; d2w[6 * capA + slot] = hi.z; d2w[7 * capA + slot] = hi.w;
+        d2[2 * slot] = lo; d2[2 * slot + 1] = hi;
     }
     for (int i = tid; i < cap; i += kThreads) out[i] = -1;     // keypoints outside the grid can never match
     for (int c = tid; c <= kCells; c += kThreads) cellOff[c] = (unsigned short)min(off2[c], n2);      // mGrid's CSR offsets: slot range of every cell
@@ -224,16 +222,17 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
         for (int cx = minCX; cx <= maxCX; cx++) {          // ascending cells, push_back order inside a cell = ascending slots (Frame.cc:690-720)
             const int sEnd = cellOff[cx * kRows + maxCY + 1];
             for (int s = cellOff[cx * kRows + minCY]; s < sEnd; s++) {
-                const int lv = oct2[s];
-                const float distx = __fsub_rn(x2[s], q.u), disty = __fsub_rn(y2[s], q.v), us = ur2[s];
+                const float4 rc = rec[s];
+                const int lv = __float_as_int(rc.w);
+                const float distx = __fsub_rn(rc.x, q.u), disty = __fsub_rn(rc.y, q.v), us = rc.z;
                 const bool stereoOut = us > 0.0f && fabsf(__fsub_rn(q.ur, us)) > r;                                    // :68-73, :2039-2046
                 const int cb = closedBy[s];
                 const bool in = (int)(lv >= loLv) & (int)(lv <= hiLv) & (int)(fabsf(distx) < r) & (int)(fabsf(disty) < r) &
                                 (int)(live ? !(cb < iq) : cb != -1) & (int)!stereoOut;                                 // Frame.cc:717; :64-66
                 if (in) {
-                    const int dist = __popc(dlo.x ^ d2w[s]) + __popc(dlo.y ^ d2w[capA + s]) + __popc(dlo.z ^ d2w[2 * capA + s]) +
-                                     __popc(dlo.w ^ d2w[3 * capA + s]) + __popc(dhi.x ^ d2w[4 * capA + s]) + __popc(dhi.y ^ d2w[5 * capA + s]) +
-                                     __popc(dhi.z ^ d2w[6 * capA + s]) + __popc(dhi.w ^ d2w[7 * capA + s]);
+                    const uint4 e = d2[2 * s], f = d2[2 * s + 1];
+                    const int dist = __popc(dlo.x ^ e.x) + __popc(dlo.y ^ e.y) + __popc(dlo.z ^ e.z) + __popc(dlo.w ^ e.w) + __popc(dhi.x ^ f.x) +
+                                     __popc(dhi.y ^ f.y) + __popc(dhi.z ^ f.z) + __popc(dhi.w ^ f.w);
                     int k = (dist << 16) | s;              // slots ascend: a later equal distance never displaces
 #pragma unroll
                     for (int t = 0; t < kTop; t++) { const int lo = min(keys[t], k); k = max(keys[t], k); keys[t] = lo; }      // sorted insert
