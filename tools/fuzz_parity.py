@@ -61,4 +61,4 @@ if __name__ == "__main__":
     t0 = time.time()
     done, skipped, nkp, nbytes = run(n, seed, progress=True)
     print("fuzz parity: %d cases bit-exact (%d keypoints, %d descriptor bytes), %d geometries rejected by orbx_create, %.0f s"
-          % (done, skipped, nkp, nbytes, time.time() - t0))
+          % (done, nkp, nbytes, skipped, time.time() - t0))
