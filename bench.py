@@ -421,6 +421,28 @@ def main():
             extras["hd1080_note"] = "1920x1080 x 2000 features (BASELINE.json configs[2]), %d noise frames per call, device-resident, %.0f keypoints per frame" % (B2, n2)
             extras["hd1080_path_frac"] = round(B2 * 10 / dt * e2.algorithmic_bytes(w2["rows"], w2["cols"], int(round(n2))) / 1e9 / HBM_PEAK_GBS, 5)
             del e2
+            # (c) the reference's own call shape: ONE 640x480 frame per call (Frame::ExtractORB), device-resident, back to back
+            w1 = WORKLOADS["mono640"]
+            f1 = torch.from_numpy(synth.frames("noise", 0, 1, w1["rows"], w1["cols"])).cuda()
+            e1 = X.ORBextractor(w1["nfeatures"], 1.2, 8, 20, 7, max_width=w1["cols"], max_height=w1["rows"], max_batch=1, device=local_rank)
+            e1.set_stream(stream.cuda_stream)
+            cap1 = min(e1.capacity, w1["nfeatures"] + 24)
+            l1 = sharding.slab_layout(1, cap1)
+            s1 = torch.zeros(l1["bytes"], dtype=torch.uint8, device="cuda")
+            b1 = s1.data_ptr()
+            run1 = lambda: e1.extract_batch_device(f1, 1, w1["rows"], w1["cols"], b1 + l1["keypoints"], b1 + l1["descriptors"], b1 + l1["n"],
+                                                   b1 + l1["mono"], cap1, lapping=w1["lapping"])
+            for _ in range(20):
+                run1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(300):
+                run1()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extras["single_frame_us"] = round(dt / 300 * 1e6, 1)
+            extras["single_frame_note"] = "one 640x480 frame per call (the reference's call shape), device-resident, 300 calls back to back: %.0f calls/s" % (300 / dt)
+            del e1
         result = {
             "metric": "frames/sec (ORB extract, %dx%dx8-level x%d feat)" % (cols, rows, nf),
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,

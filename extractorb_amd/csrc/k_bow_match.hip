@@ -78,8 +78,9 @@ __global__ __launch_bounds__(kThreads) void k_search_bow(const uint32_t* __restr
     const Keypoint *kpK = kps + (long long)fK * cap, *kpC = kps + (long long)fC * cap;
     if (tid == 0) { sSeg = 0; sCount = 0; }
     if (tid < kHistoLength) sHist[tid] = 0;
-    for (int i = tid; i < MK; i += kThreads) { nodeK[i] = gNodeK[i]; sIdxK[i] = (unsigned short)idxK[i]; }
-    for (int i = tid; i < MC; i += kThreads) { nodeC[i] = gNodeC[i]; sIdxC[i] = (unsigned short)idxC[i]; }
+    // (indices clamped: a corrupt FeatureVector must not index past the tables)
+    for (int i = tid; i < MK; i += kThreads) { nodeK[i] = gNodeK[i]; sIdxK[i] = (unsigned short)min(idxK[i], (uint32_t)(cap - 1)); }
+    for (int i = tid; i < MC; i += kThreads) { nodeC[i] = gNodeC[i]; sIdxC[i] = (unsigned short)min(idxC[i], (uint32_t)(cap - 1)); }
     // (the second keyframe's keypoints without a good MapPoint are never candidates (:879-886): closed from the start, marked -2)
     for (int i = tid; i < cap; i += kThreads) {
         takenBy[i] = p.twoKeyFrames && !(curFlags[(long long)pair * cap + i] & 1) ? -2 : -1;

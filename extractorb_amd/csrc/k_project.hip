@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kThreads) void k_search_proj(const ProjQuery* __res
     const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
     const int n2 = nIn2;                                   // slot = position in mGrid's CSR order (cell x*48+y, push_back order inside a cell)
     for (int slot = tid; slot < n2; slot += kThreads) {
-        const int i2 = gi2[slot];
+        const int i2 = min(max(gi2[slot], 0), cap - 1);      // (clamped: a corrupt grid must not index past the frame)
         const Keypoint k = K2[i2];
         const int oct = min(max(k.octave, 0), 255);
         rec[slot] = make_float4(k.x, k.y, UR ? UR[i2] : -1.0f, __int_as_float(oct));

@@ -332,6 +332,8 @@ void* orbx_get_stream(const orbx_handle* h);
 int orbx_synchronize(orbx_handle* h);
 
 /* ---- introspection used by tests and bench.py (not part of the reference surface) ------------- */
+/* rounds the fixed-point projection search of the last launch needed for pair 0, and 100-MHz ticks of its staging / first scan / rounds */
+int orbx_debug_search_rounds(int* out4);
 
 /* Stage outputs of frame `frame` of the last batch, copied to host.  Candidates are the reference's
  * vToDistributeKeys of one level (ORBextractor.cc:786-864) in rectangle coordinates; their order is
