@@ -30,6 +30,7 @@ struct InitMatchParams {
     float minX, minY, wInv, hInv;   // mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv of frame 2
     float r, nnRatio;               // windowSize as float (Frame.cc:660-661), mfNNratio
     int checkOrientation, capacity;
+    int slotCapacity;               // level-0 keypoints of frame 2 the LDS tables hold (a multiple of 4)
     int f1First, f1Step, f2First, f2Step;
 };
 
@@ -56,9 +57,21 @@ __device__ __forceinline__ int waveMin(int v) {
 }
 }  // namespace
 
-size_t initMatchLdsBytes(int capacity) {
-    const size_t c = (size_t)((capacity + 3) & ~3);
-    return c * (32 + 4 + 4 + 4 + 2 + 2 + 2 + 2 + 2 + 2) + (kCols + 2) * sizeof(int) + 2 * kWaves * 2 * sizeof(int) + 2 * kWaves * sizeof(int);
+// LDS: per staged (level-0) keypoint of frame 2 its descriptor, position, angle, cell, index, matched distance and back pointer (52 B);
+// per keypoint of frame 1 vnMatches12 and its rotHist bin (4 B).  Only level-0 keypoints are candidates (:722-726), about a fifth of a
+// frame, so the slot tables are sized apart from `capacity`: the initialisation extractor's frames (ORBextractor(5 * nFeatures),
+// Tracking.cc:774: 5000-10 000 keypoints) fit although 56 B x capacity would not.
+size_t initMatchLdsBytes(int capacity, int slotCapacity) {
+    const size_t c = (size_t)((capacity + 3) & ~3), sc = (size_t)((slotCapacity + 3) & ~3);
+    return sc * (32 + 4 + 4 + 4 + 2 + 2 + 2 + 2) + c * (2 + 2) + (kCols + 2) * sizeof(int) + 2 * kWaves * 2 * sizeof(int) + 2 * kWaves * sizeof(int) + 16;
+}
+// the largest slot table that fits next to the frame-1 tables (0: not even those fit)
+int initMatchSlotCapacity(int capacity) {
+    const long long fixed = (long long)((capacity + 3) & ~3) * 4 + (kCols + 2) * sizeof(int) + 4 * kWaves * sizeof(int) + 2 * kWaves * sizeof(int) + 16;
+    const long long room = 160LL * 1024 - 512 - fixed;
+    if (room < 52 * 64) return 0;
+    const long long sc = room / 52;
+    return (int)(sc < capacity ? sc & ~3LL : (capacity + 3) & ~3);
 }
 
 // grid: n_pairs; 256 threads.
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
                                                           float* __restrict__ prevMatched, int* __restrict__ matches12,
                                                           int* __restrict__ nMatches) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const int cap = p.capacity, capA = (cap + 3) & ~3;
+    const int cap = p.capacity, capA = p.slotCapacity, capF = (cap + 3) & ~3;      // capA: slots (level-0 keypoints of frame 2); capF: keypoints of frame 1
     uint32_t* d2w = (uint32_t*)smem;                       // [8][capA] descriptor word k of slot s
     float* x2 = (float*)(d2w + 8 * capA);                  // [capA]
     float* y2 = x2 + capA;
@@ -80,8 +93,8 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
     unsigned short* idx2 = cell2 + capA;                   // keypoint index in frame 2
     unsigned short* mdist = idx2 + capA;                   // vMatchedDistance (kNone = INT_MAX)
     short* m21 = (short*)(mdist + capA);                   // vnMatches21
-    short* m12 = m21 + capA;                               // vnMatches12 (frame 1 index space)
-    short* rbin = m12 + capA;                              // rotHist bin the keypoint was pushed to, -1 = none
+    short* m12 = m21 + capA;                               // [capF] vnMatches12 (frame 1 index space)
+    short* rbin = m12 + capF;                              // [capF] rotHist bin the keypoint was pushed to, -1 = none
 
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f1 = p.f1First + pair * p.f1Step, f2 = p.f2First + pair * p.f2Step;
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
 #pragma unroll
         for (int w = 0; w < kWaves; w++) { const int c = wcnt[it * kWaves + w]; all += c; before += w < wave ? c : 0; }
         const int slot = n2 + before + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) {
+        if (keep && slot < capA) {
             const int posX = (int)roundf(__fmul_rn(__fsub_rn(k.x, p.minX), p.wInv));   // the cell AssignFeaturesToGrid put it in
             const int posY = (int)roundf(__fmul_rn(__fsub_rn(k.y, p.minY), p.hInv));   // (PosInGrid, Frame.cc:728-729)
             x2[slot] = k.x; y2[slot] = k.y; a2[slot] = k.angle;
@@ -122,6 +135,11 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
             d2w[4 * capA + slot] = hi.x; d2w[5 * capA + slot] = hi.y; d2w[6 * capA + slot] = hi.z; d2w[7 * capA + slot] = hi.w;
         }
         n2 += all;
+    }
+    if (n2 > capA) {      // more level-0 keypoints than the slot tables hold (not with a pyramid of several levels): report, match nothing
+        for (int i = tid; i < N1; i += kThreads) matches12[(long long)pair * cap + i] = -1;
+        if (tid == 0) nMatches[pair] = -1;
+        return;
     }
     for (int i = tid; i < N1; i += kThreads) { m12[i] = -1; rbin[i] = -1; }
     __syncthreads();
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void k_search_init(const Keypoint* __rest
 
 void launchSearchInit(hipStream_t st, const Keypoint* kpsUn, const uint8_t* desc, const int* nOut, const int* gridOff,
                       const int* gridIdx, const InitMatchParams& p, float* prevMatched, int* matches12, int* nMatches, int nPairs) {
-    hipLaunchKernelGGL(k_search_init, dim3(nPairs), dim3(kThreads), initMatchLdsBytes(p.capacity), st, kpsUn, desc, nOut, gridOff,
+    hipLaunchKernelGGL(k_search_init, dim3(nPairs), dim3(kThreads), initMatchLdsBytes(p.capacity, p.slotCapacity), st, kpsUn, desc, nOut, gridOff,
                        gridIdx, p, prevMatched, matches12, nMatches);
 }
 

@@ -48,9 +48,10 @@ void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*
                   int, int*, unsigned short*, float*, float*, int*, int*, int);
 struct InitMatchParams {
     float minX, minY, wInv, hInv, r, nnRatio;
-    int checkOrientation, capacity, f1First, f1Step, f2First, f2Step;
+    int checkOrientation, capacity, slotCapacity, f1First, f1Step, f2First, f2Step;
 };
-size_t initMatchLdsBytes(int capacity);
+size_t initMatchLdsBytes(int capacity, int slotCapacity);
+int initMatchSlotCapacity(int capacity);
 void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
                       float*, int*, int*, int);
 struct ProjQuery { float u, v, ur, radius; int minLevel, maxLevel, flags; float angle; };
@@ -590,43 +591,53 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     }
     h->outCap = mg.selPerFrame + 8 * nlevels;
 
+// device allocation of orbx_create; ORBX_POISON=<byte> fills it (tests run with it: no kernel may depend on what hipMalloc returns,
+// which is zeroed pages in a fresh process and another test's leftovers later)
+#define CREATE_ALLOC(ptr, bytes)                                                         \
+    do {                                                                                 \
+        const size_t n_ = (size_t)(bytes);                                               \
+        CREATE_TRY(hipMalloc(&(ptr), n_));                                               \
+        if (poison >= 0) CREATE_TRY(hipMemset((ptr), poison, n_));                       \
+    } while (0)
+
+    const int poison = getenv("ORBX_POISON") ? atoi(getenv("ORBX_POISON")) & 255 : -1;
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->ownStream = true;
-    CREATE_TRY(hipMalloc(&h->d_input, (size_t)max_width * max_height * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_pyr, h->pyrBytes));
-    CREATE_TRY(hipMalloc(&h->d_blur, h->blurBytes));
-    CREATE_TRY(hipMalloc(&h->d_candPos, h->candEntries * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc(&h->d_candSeg, h->candEntries * sizeof(unsigned)));
-    CREATE_TRY(hipMalloc(&h->d_cellCount, sizeof(unsigned) * h->cellCap * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_cellOff, sizeof(int) * h->cellCap * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_nodeOf, h->candEntries * sizeof(unsigned short)));
-    CREATE_TRY(hipMalloc(&h->d_candCount, sizeof(unsigned) * max_batch * nlevels));
-    CREATE_TRY(hipMalloc(&h->d_sel, h->selEntries * sizeof(uint2)));
-    if (h->octArenaSlice) CREATE_TRY(hipMalloc(&h->d_octArena, h->octArenaSlice * max_batch * nlevels));
-    CREATE_TRY(hipMalloc(&h->d_levelCount, sizeof(int) * max_batch * nlevels));
-    CREATE_TRY(hipMalloc(&h->d_levelLap, sizeof(int) * max_batch * nlevels));
-    CREATE_TRY(hipMalloc(&h->d_lap, sizeof(int) * 2 * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_lv, sizeof(LevelGeom) * kMaxLevels));
-    CREATE_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * h->cellCap));
-    CREATE_TRY(hipMalloc(&h->d_rx, sizeof(ResizeX) * h->rxCap));
-    CREATE_TRY(hipMalloc(&h->d_ry, sizeof(ResizeX) * h->rxCap));
-    CREATE_TRY(hipMalloc(&h->d_tiles, sizeof(BlurItem) * h->tileCap));
-    CREATE_TRY(hipMalloc(&h->d_laneItem, sizeof(unsigned short) * h->laneCap));
+    CREATE_ALLOC(h->d_input, (size_t)max_width * max_height * max_batch);
+    CREATE_ALLOC(h->d_pyr, h->pyrBytes);
+    CREATE_ALLOC(h->d_blur, h->blurBytes);
+    CREATE_ALLOC(h->d_candPos, h->candEntries * sizeof(unsigned));
+    CREATE_ALLOC(h->d_candSeg, h->candEntries * sizeof(unsigned));
+    CREATE_ALLOC(h->d_cellCount, sizeof(unsigned) * h->cellCap * max_batch);
+    CREATE_ALLOC(h->d_cellOff, sizeof(int) * h->cellCap * max_batch);
+    CREATE_ALLOC(h->d_nodeOf, h->candEntries * sizeof(unsigned short));
+    CREATE_ALLOC(h->d_candCount, sizeof(unsigned) * max_batch * nlevels);
+    CREATE_ALLOC(h->d_sel, h->selEntries * sizeof(uint2));
+    if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
+    CREATE_ALLOC(h->d_levelCount, sizeof(int) * max_batch * nlevels);
+    CREATE_ALLOC(h->d_levelLap, sizeof(int) * max_batch * nlevels);
+    CREATE_ALLOC(h->d_lap, sizeof(int) * 2 * max_batch);
+    CREATE_ALLOC(h->d_lv, sizeof(LevelGeom) * kMaxLevels);
+    CREATE_ALLOC(h->d_cells, sizeof(CellDesc) * h->cellCap);
+    CREATE_ALLOC(h->d_rx, sizeof(ResizeX) * h->rxCap);
+    CREATE_ALLOC(h->d_ry, sizeof(ResizeX) * h->rxCap);
+    CREATE_ALLOC(h->d_tiles, sizeof(BlurItem) * h->tileCap);
+    CREATE_ALLOC(h->d_laneItem, sizeof(unsigned short) * h->laneCap);
     h->chainCap = roomy((size_t)(((max_width + 38 + 32 + 63) / 64 + 1) * ((max_height + 38 + 15) / 16 + 1)) * nlevels);
-    CREATE_TRY(hipMalloc(&h->d_chain, sizeof(ChainTile) * h->chainCap));
-    CREATE_TRY(hipMalloc(&h->d_chainAll, sizeof(ChainTile) * h->chainCap));
+    CREATE_ALLOC(h->d_chain, sizeof(ChainTile) * h->chainCap);
+    CREATE_ALLOC(h->d_chainAll, sizeof(ChainTile) * h->chainCap);
     h->pyrAllWgs = getenv("ORBX_PYR_ALL_WGS") ? atoll(getenv("ORBX_PYR_ALL_WGS")) : 0;
     h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
     h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 12 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
-    CREATE_TRY(hipMalloc(&h->d_foot, sizeof(TileFoot) * h->footCap));
+    CREATE_ALLOC(h->d_foot, sizeof(TileFoot) * h->footCap);
     const size_t oc = (size_t)h->outCap * max_batch;
-    CREATE_TRY(hipMalloc(&h->d_outK, oc * sizeof(Keypoint)));
-    CREATE_TRY(hipMalloc(&h->d_outLevelK, oc * sizeof(Keypoint)));
-    CREATE_TRY(hipMalloc(&h->d_outD, oc * 32));
-    CREATE_TRY(hipMalloc(&h->d_nOut, sizeof(int) * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_monoOut, sizeof(int) * max_batch));
-    CREATE_TRY(hipMalloc(&h->d_outLevelCounts, sizeof(int) * max_batch * nlevels));
+    CREATE_ALLOC(h->d_outK, oc * sizeof(Keypoint));
+    CREATE_ALLOC(h->d_outLevelK, oc * sizeof(Keypoint));
+    CREATE_ALLOC(h->d_outD, oc * 32);
+    CREATE_ALLOC(h->d_nOut, sizeof(int) * max_batch);
+    CREATE_ALLOC(h->d_monoOut, sizeof(int) * max_batch);
+    CREATE_ALLOC(h->d_outLevelCounts, sizeof(int) * max_batch * nlevels);
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
@@ -1091,14 +1102,15 @@ int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame
         window_size < 0 || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1, negative frame index/step/window or empty bounds");
     if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
-    if (initMatchLdsBytes(capacity) > 160 * 1024 - 512)
-        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (56 bytes per keypoint, 160 KB per CU)");
+    const int slotCap = initMatchSlotCapacity(capacity);
+    if (slotCap < 64)
+        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (4 bytes per keypoint + 52 per level-0 keypoint of frame 2, 160 KB per CU)");
     HIP_TRY(h, hipSetDevice(h->device));
     InitMatchParams p;
     p.minX = bounds4[0]; p.minY = bounds4[2];
     p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
     p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
-    p.r = (float)window_size; p.nnRatio = nn_ratio; p.checkOrientation = check_orientation != 0; p.capacity = capacity;
+    p.r = (float)window_size; p.nnRatio = nn_ratio; p.checkOrientation = check_orientation != 0; p.capacity = capacity; p.slotCapacity = slotCap;
     p.f1First = frame1_first; p.f1Step = frame1_step; p.f2First = frame2_first; p.f2Step = frame2_step;
     {
         Prof pr(h, S_FRAME);

@@ -213,7 +213,10 @@ int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* 
  *   d_prev_matched[(p*capacity + i)*2 + {0,1}] : vbPrevMatched of pair p, in/out (Tracking.cc:2029-2031 seeds it
  *                                      with F1.mvKeysUn[i].pt; matched entries become F2.mvKeysUn[match].pt, :815-817)
  *   d_matches12[p*capacity + i]      : vnMatches12, -1 = unmatched;  d_n_matches[p] : the return value
- * Asynchronous on the handle's stream. */
+ * Frames of the initialisation extractor (ORBextractor(5 * nFeatures), src/Tracking.cc:774: capacity 5000 .. 10 000) are supported: only the
+ * level-0 keypoints of F2 are candidates (:722-726) and only they are staged on chip (52 B each next to 4 B per keypoint of F1 in 160 KB of
+ * LDS).  Should F2 hold more level-0 keypoints than fit (a one-level pyramid with thousands of features), the pair reports
+ * d_n_matches[p] = -1 and an all -1 table.  Asynchronous on the handle's stream. */
 int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame1_first, int frame1_step, int frame2_first,
                                           int frame2_step, const orbx_keypoint* d_kps_un, const uint8_t* d_desc,
                                           const int* d_n_out, int capacity, const int* d_grid_off, const int* d_grid_idx,

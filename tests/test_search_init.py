@@ -240,6 +240,19 @@ def test_gpu_search_equals_oracle_on_stream_pairs(variant, nfeatures, window, nn
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfeatures", [5000, 10000])
+def test_gpu_search_on_initialisation_extractor_frames(nfeatures):
+    """Tracking builds the two initialisation frames with mpIniORBextractor = ORBextractor(5 * nFeatures) (reference src/Tracking.cc:774,
+    :2065): thousands of keypoints per frame, of which only the level-0 fifth are candidates."""
+    fr = []
+    for f, (dx, dy, noise) in enumerate([(9, 4, 0), (-15, 6, 3)]):
+        a, b = shifted_pair(500 + f, dx, dy, noise=noise)
+        fr += [a, b]
+    total, calls = run_gpu_pairs(np.stack(fr), ((0, 2), (1, 2), 2), PINHOLE, nfeatures=nfeatures)
+    assert total / calls > 150
+
+
+@pytest.mark.gpu
 def test_gpu_search_argument_errors():
     ex = X.ORBextractor(1000)
     with pytest.raises(X.OrbxError):
