@@ -12,6 +12,9 @@
 
 namespace orbx {
 
+constexpr size_t kPolluteBytes = 158 * 1024;      // one workgroup per CU (160 KB of LDS each)
+
+
 struct GrayParams {
     int rows, cols, channels, redFirst, aligned;
     long long srcStride, srcFrame, dstStride, dstFrame;
@@ -63,6 +66,21 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ src, u
 
 void launchGray(hipStream_t st, const uint8_t* src, uint8_t* dst, const GrayParams& p, int nFrames) {
     hipLaunchKernelGGL(k_gray, dim3((p.cols / 4 + 256) / 256, p.rows, nFrames), dim3(256), 0, st, src, dst, p);
+}
+
+// Test aid (ORBX_LDS_POLLUTE=<byte>): LDS is not cleared between workgroups, so a kernel that reads LDS it has not written sees whatever
+// the previous workgroup on that CU left — usually harmless leftovers of the same kernel.  This kernel takes a CU's whole LDS per workgroup
+// and fills it with a byte pattern; the pipeline launches it in front of every kernel so that such a read becomes a deterministic failure.
+__global__ __launch_bounds__(256) void k_lds_pollute(unsigned pattern, unsigned* __restrict__ sink) {
+    extern __shared__ unsigned pl[];
+    const int words = (int)(kPolluteBytes / 4);
+    for (int i = threadIdx.x; i < words; i += 256) pl[i] = pattern;
+    __syncthreads();
+    if (pl[(threadIdx.x * 97 + blockIdx.x) % words] != pattern) sink[0] = 1;      // (keeps the stores alive)
+}
+void launchLdsPollute(hipStream_t st, int numCUs, int byte, unsigned* sink) {
+    const unsigned b = (unsigned)byte & 255u;
+    hipLaunchKernelGGL(k_lds_pollute, dim3(4 * numCUs), dim3(256), kPolluteBytes, st, b * 0x01010101u, sink);
 }
 
 }  // namespace orbx

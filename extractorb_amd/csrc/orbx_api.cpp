@@ -24,6 +24,7 @@ void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const R
 struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
+void launchLdsPollute(hipStream_t, int, int, unsigned*);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
@@ -118,6 +119,7 @@ struct orbx_handle {
     int* d_cellOff = nullptr;                             // [frame][cell] offset of the cell in the compacted array
     unsigned short* d_nodeOf = nullptr;
     unsigned* d_candCount = nullptr;
+    unsigned* d_sink = nullptr;         // written by the LDS polluter (test aid)
     uint2* d_sel = nullptr;
     int *d_levelCount = nullptr, *d_levelLap = nullptr, *d_lap = nullptr;
     LevelGeom* d_lv = nullptr;
@@ -163,6 +165,7 @@ struct orbx_handle {
     int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
                                        // chosen by the image area — separate launches per size measured slower)
     int octThreadsForced = 0;          // ORBX_OCT_THREADS
+    int ldsPollute = -1;               // ORBX_LDS_POLLUTE=<byte>: every CU's LDS is filled with the byte in front of every kernel (test aid)
     bool octRoomyForced = false;       // ORBX_OCT_ROOMY: the 128-VGPR variants whatever the batch (tests reach every variant with it)
     int numCUs = 256;
     bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
@@ -212,7 +215,7 @@ int fail(orbx_handle* h, int code, const std::string& msg) {
 int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
-    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sel, h->d_levelCount,
+    void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
@@ -359,17 +362,20 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
     auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
+    auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     auto front = [&](hipStream_t st, int f0, int Bn) {
         // smallest batches (one or two frames): the whole pyramid in ONE launch, every tile of every level derived from the caller's image
         const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
                          (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
         if (all) {
             Prof p(h, S_RESIZE, st);
+            pollute(st);
             launchPyrAll(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_chainAll, (int)g.chainAll.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr,
                          g.chainAllLdsBytes, g.chainAllEvenBytes, g.chainAllPacked && !h->resizeBytewise, f0, Bn);
         } else {
         {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
             Prof p(h, S_LEVEL0, st);
+            pollute(st);
             launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
                            g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
                            g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
@@ -380,10 +386,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                            (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 12LL * h->numCUs);
         if (chain) {
             Prof p(h, S_RESIZE, st);
+            pollute(st);
             launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, g.chainPacked && !h->resizeBytewise, f0, Bn);
         } else {
             for (int l = 2; l < g.nlevels; l++) {
                 Prof p(h, S_RESIZE, st);
+                pollute(st);
                 launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
                              h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
                              g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
@@ -395,6 +403,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
             const int v = blurVariant(Bn);
+            pollute(st);
             launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v ? kBlurBlockRowsSmall : kBlurBlockRows,
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
         }
@@ -403,6 +412,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         {
             Prof p(h, S_FAST, st);
             const bool carry = blurRidesWithFast(Bn);
+            pollute(st);
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
                        h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur);
@@ -417,12 +427,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : (wgs * 256 <= slots ? 256 : 0));
             if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
+            pollute(st);
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena);
         }
         {
             Prof p(h, S_DESCRIBE, st);
+            pollute(st);
             launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
                            h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
         }
@@ -612,6 +624,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_cellOff, sizeof(int) * h->cellCap * max_batch);
     CREATE_ALLOC(h->d_nodeOf, h->candEntries * sizeof(unsigned short));
     CREATE_ALLOC(h->d_candCount, sizeof(unsigned) * max_batch * nlevels);
+    CREATE_ALLOC(h->d_sink, 64);
     CREATE_ALLOC(h->d_sel, h->selEntries * sizeof(uint2));
     if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
     CREATE_ALLOC(h->d_levelCount, sizeof(int) * max_batch * nlevels);
@@ -651,6 +664,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
     h->octRoomyForced = getenv("ORBX_OCT_ROOMY") != nullptr;
+    if (const char* e = getenv("ORBX_LDS_POLLUTE")) h->ldsPollute = atoi(e) & 255;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;

@@ -23,7 +23,9 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            # the pyramid of a single frame as two launches (k_pyr_first + chains from level 1) and as one launch per level
            ({"ORBX_PYR_ALL_WGS": "-1"}, 8, 109), ({"ORBX_PYR_CHAIN": "0"}, 8, 110),
            # every device allocation of the handle filled with a byte pattern: nothing may depend on what hipMalloc returns
-           ({"ORBX_POISON": "165"}, 8, 111), ({"ORBX_POISON": "255"}, 8, 112)]
+           ({"ORBX_POISON": "165"}, 8, 111), ({"ORBX_POISON": "255"}, 8, 112),
+           # ... nor on what the previous workgroup left in LDS (every CU's LDS filled with a byte in front of every kernel)
+           ({"ORBX_LDS_POLLUTE": "165"}, 8, 113), ({"ORBX_LDS_POLLUTE": "255", "ORBX_POISON": "90"}, 8, 114)]
 _totals = []
 
 
