@@ -106,20 +106,22 @@ __device__ void bitonicSort(unsigned long long* key, int n) {
 // (One frame used to take 193 us here with 256 threads, a rank loop of O(i) per word and the norm summed from global memory; the
 // reference's floating-point order leaves exactly one sequential piece, the norm, and that now runs on LDS values.)
 __global__ __launch_bounds__(kReduceThreads) void k_bow_reduce(const uint32_t* __restrict__ featWord, const double* __restrict__ featWeight,
-                                                    const uint32_t* __restrict__ featNode, const int* __restrict__ nOut, int capacity, int P,
+                                                    const uint32_t* __restrict__ featNode, const int* __restrict__ nOut, int capacity, int Pmax,
                                                     int scoring, int weighting, uint32_t* __restrict__ wordIds, double* __restrict__ wordWeights,
                                                     int* __restrict__ nWords, uint32_t* __restrict__ fvNodes, uint32_t* __restrict__ fvIdx,
                                                     int* __restrict__ nFeat) {
     constexpr int T = kReduceThreads;
     extern __shared__ __align__(16) uint8_t smem[];
     unsigned long long* key = (unsigned long long*)smem;
-    // [P] summed weight of word rank r: in LDS while 16 P bytes fit a workgroup, else in the output array itself
-    double* wsum = P <= 8192 ? (double*)(key + P) : wordWeights + (long long)blockIdx.x * capacity;
+    // [Pmax] summed weight of word rank r: in LDS while 16 Pmax bytes fit a workgroup, else in the output array itself
+    double* wsum = Pmax <= 8192 ? (double*)(key + Pmax) : wordWeights + (long long)blockIdx.x * capacity;
     __shared__ int sCount, sWaveSum[T / 64];
     __shared__ double sNorm;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = min(nOut[f], capacity);
     const long long base = (long long)f * capacity;
+    int P = 64;                                           // the sorts run on the next power of two above THIS frame's keypoint count
+    while (P < N) P <<= 1;                                // (<= Pmax, the next power of two above the capacity, which sizes the LDS)
     // ---- BowVector: features with a positive weight, sorted by (word id, feature index) ----
     if (tid == 0) sCount = 0;
     for (int i = tid; i < P; i += T) {
