@@ -130,7 +130,7 @@ struct orbx_handle {
     long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
     size_t chainCap = 0;
     bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
-    long long pyrChainWgs = 0;          // ORBX_PYR_CHAIN_WGS: largest k_pyr_rest grid (workgroups) still preferred to the per-level launches
+    long long pyrChainWgs = 0;          // ORBX_PYR_CHAIN_WGS: largest k_pyr_rest grid (workgroups) still preferred to the per-level launches (default 16 per CU: six 640x480 frames - 112 -> 102 us; eight: equal; twelve: 140 -> 175 us)
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
@@ -383,7 +383,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above), or - while the batch
         // cannot fill the chip anyway - ONE launch in which every tile re-derives what it needs of the levels in between (k_pyr_rest)
         const bool chain = h->pyrChain && g.nlevels > 2 && !g.chain.empty() && g.chainFits && g.chainLdsBytes <= 60 * 1024 &&
-                           (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 12LL * h->numCUs);
+                           (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 16LL * h->numCUs);
         if (chain) {
             Prof p(h, S_RESIZE, st);
             pollute(st);
@@ -641,7 +641,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_chainAll, sizeof(ChainTile) * h->chainCap);
     h->pyrAllWgs = getenv("ORBX_PYR_ALL_WGS") ? atoll(getenv("ORBX_PYR_ALL_WGS")) : 0;
     h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
-    h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 12 workgroups per CU
+    h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 16 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_ALLOC(h->d_foot, sizeof(TileFoot) * h->footCap);
     const size_t oc = (size_t)h->outCap * max_batch;
