@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "orbx_device.hpp"
+#include "k_blur_body.hpp"      // blurBlock: the level a resize tile has staged is blurred out of the same LDS tile
 
 namespace orbx {
 
@@ -27,6 +28,7 @@ constexpr int kPyrRows = kResizeTileRows / 4;   // destination rows per thread
 constexpr int kTileCols = 64;    // dword columns per workgroup tile (256 pixels)
 constexpr int kTileRowGroups = 4;
 constexpr int kTileRows = kPyrRows * kTileRowGroups;   // destination rows per workgroup tile
+constexpr int kFusedBlurRows = 8;                      // output rows per work item of the blur that rides in a resize tile
 
 static __host__ __device__ inline int rowDwords(const LevelGeom& g) { return (kPadL - kEdge + g.w + 2 * kEdge + 3) / 4; }
 
@@ -60,7 +62,8 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <bool PACKED>
 __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d, const ResizeX* __restrict__ xt,
                                            const ResizeX* __restrict__ yt, const TileFoot ft, uint8_t* __restrict__ pyr,
-                                           int tileX, int tileY, int f, uint8_t* tile, int ldsStride) {
+                                           int tileX, int tileY, int f, uint8_t* tile, int ldsStride, const LevelGeom* sg,
+                                           uint8_t* __restrict__ blur) {
     const int tid = threadIdx.x, col = tid & (kTileCols - 1), rgrp = tid / kTileCols;
     const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
     const int dw = tileX * kTileCols + col;
@@ -91,13 +94,13 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
         const int c = tid & 127, rsub = tid >> 7;
         for (int cc = c; cc < nDw; cc += 128) {           // one trip unless a tile's footprint is wider than 512 bytes
             const bool whole = sv.aligned && fx0 + 4 * cc + 3 < sv.readableCols;
-            const unsigned colOff = (unsigned)(fx0 + 4 * cc);
+            const int colOff = fx0 + 4 * cc;                 // (negative inside the source level's left border)
             for (int rb = rsub; rb < nRows; rb += 2 * kStageRows) {
                 unsigned w[kStageRows];
 #pragma unroll
                 for (int k = 0; k < kStageRows; k++) {
                     const int r = min(rb + 2 * k, nRows - 1);     // clamped: every lane loads, only valid rows are stored
-                    const uint8_t* q = sp + ((unsigned)__mul24(fy0 + r, sv.stride) + colOff);      // 24-bit: full-rate multiply
+                    const uint8_t* q = sp + (__mul24(fy0 + r, sv.stride) + colOff);      // 24-bit: full-rate multiply; signed: rows / columns of the border
                     if (whole) {
                         w[k] = *(const unsigned*)q;
                     } else {
@@ -167,8 +170,7 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
             const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
             if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);
         }
-        return;
-    }
+    } else {
     // two rows per trip: enough LDS reads in flight without holding all 128 taps of the thread in registers
 #pragma unroll 2
     for (int r = 0; r < kPyrRows; r++) {
@@ -184,6 +186,32 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
             o |= (unsigned)v << (8 * j);
         }
         if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = o;
+    }
+    }
+    // ---- the 7x7 blur of the SOURCE level (reference :1126-1127) out of the same LDS tile: this tile's share [bx0, bx1) x [by0, by1)
+    //      of level l - 1, in work items of four columns x kFusedBlurRows rows (the tile holds the 3-pixel halo: orbx_geometry.hpp).
+    //      The level is then never read from HBM a second time by k_blur (1.16 MB per 640x480 frame + the 6-in-32 halo rows). ----
+    if (sg != nullptr && ft.bx1 > ft.bx0) {
+        const int gw = (ft.bx1 - ft.bx0 + 3) >> 2, gh = ft.by1 - ft.by0, nrb = (gh + kFusedBlurRows - 1) / kFusedBlurRows;
+        uint8_t* bout = blur + sg->blurOff + (long long)f * sg->blurFrameBytes;
+        const int bstride = sg->blurStride;
+        const float ginv = __frcp_rn((float)gw);
+        for (int item = tid; item < gw * nrb; item += 256) {
+            const int rb = (int)(((float)item + 0.5f) * ginv), cg = item - rb * gw;      // exact: item < 2^12, quotient >= 0.5 / gw away from an integer
+            const int x0 = ft.bx0 + 4 * cg, y0 = ft.by0 + rb * kFusedBlurRows;
+            const uint8_t* lp = tile + (y0 - 3 - fy0) * ldsStride + (x0 - 4 - fx0);         // pixels x0-4 .. of input row y0-3
+            const int lastIn = nRows - 1 - (y0 - 3 - fy0);                                  // rows past the staged tile are clamped (their outputs are not stored)
+            const int rowsValid = min(kFusedBlurRows, ft.by1 - y0);
+            uint8_t* dp = bout + (long long)y0 * bstride + x0;
+            blurBlock<kFusedBlurRows>(
+                [&](int i, unsigned& d0, unsigned& d1, unsigned& d2) {
+                    const unsigned* row = (const unsigned*)(lp + (i < lastIn ? i : lastIn) * ldsStride);
+                    d0 = row[0]; d1 = row[1]; d2 = row[2];
+                },
+                [&](int orow, unsigned w) {
+                    if (orow < rowsValid) *(unsigned*)(dp + orow * bstride) = w;
+                });
+        }
     }
 }
 
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
     } else {
         t -= nTiles0;
         const int tileY = t / tilesX1;
-        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride);
+        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride, nullptr, nullptr);
     }
 }
 
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt,
                                                  const ResizeX* __restrict__ yt, const TileFoot* __restrict__ foot,
-                                                 uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
+                                                 uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
     SrcView sv;
     sv.p = pyr + s.pyrOff + (long long)kEdge * s.pyrStride + kPadL;
@@ -249,7 +277,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int ti
     int t, fr;
     if (!xcdChunkFrame(nFrames, t, fr)) return;   // neighbouring tiles of a frame (overlapping source footprints) on one XCD
     const int tileY = t / tilesX;
-    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
+    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride, blur ? &s : nullptr, blur);
 }
 
 // ---- small batches: levels 2.. in ONE launch --------------------------------------------------------------------------------
@@ -532,12 +560,13 @@ void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long l
     else hipLaunchKernelGGL(k_pyr_first<false>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
                             g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
 }
+// blur != nullptr: the tiles also write their share of the blurred SOURCE level
 void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt,
-                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {
+                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, uint8_t* blur, int ldsStride, int ldsRows, bool packed, int f0, int B) {
     if (packed) hipLaunchKernelGGL(k_resize<true>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                                   tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
+                                   tilesX, xt, yt, foot, pyr, blur, ldsStride, f0, B);
     else hipLaunchKernelGGL(k_resize<false>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                            tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
+                            tilesX, xt, yt, foot, pyr, blur, ldsStride, f0, B);
 }
 
 }  // namespace orbx

@@ -19,7 +19,7 @@ namespace orbx {
 void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
-                  uint8_t*, int, int, bool, int, int);
+                  uint8_t*, uint8_t*, int, int, bool, int, int);
 void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
@@ -136,8 +136,10 @@ struct orbx_handle {
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
     unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
     size_t laneCap = 0;
-    int nBlurLanes[2] = {0, 0};
-    size_t blurItemOff[2] = {0, 0}, blurLaneOff[2] = {0, 0};
+    int nBlurLanes[3] = {0, 0, 0};     // [2]: 32-row blocks of the levels no resize launch blurs (level 0 and the last one)
+    size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
+    bool fuseBlur = false;             // ORBX_FUSE_BLUR=1: large batches blur levels 1 .. n-2 inside the resize launches (HBM traffic 8.56 -> 7.67 MB per frame,
+                                       // but 1.7x the instructions for that share: +2.5 % step time)
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
     uint8_t* d_octArena = nullptr;
@@ -233,7 +235,7 @@ void freeAll(orbx_handle* h) {
 // Uploads the tables of h->geom (already laid out) and checks they fit the arenas.
 int installGeometry(orbx_handle* h, int rows, int cols) {
     FrameGeom g;
-    std::string why = makeFrameGeom(h->tabs, rows, cols, g);
+    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->fuseBlur);
     if (!why.empty()) return fail(h, why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED, why);
     layoutArenas(g, h->maxB);
     const LevelGeom& last = g.lv[g.nlevels - 1];
@@ -272,16 +274,18 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
-        const int blockRows[2] = {kBlurBlockRows, kBlurBlockRowsSmall};
-        for (int v = 0; v < 2; v++) {
+        const int blockRows[3] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows};
+        for (int v = 0; v < 3; v++) {
             const size_t t0 = tiles.size(), l0 = laneItem.size();
             int lanes = 0;
-            for (int l = 0; l < g.nlevels; l++)
+            for (int l = 0; l < g.nlevels; l++) {
+                if (v == 2 && l >= 1 && l <= g.nlevels - 2) continue;      // levels 1 .. n-2 are blurred by the resize launches of levels 2 .. n-1
                 for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
                     laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)(tiles.size() - t0));
                     tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
                     lanes += (g.lv[l].w + 3) / 4;
                 }
+            }
             tiles[t0].count = (int)(tiles.size() - t0);
             if (tiles.size() - t0 > 65535) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
             h->nBlurLanes[v] = lanes; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0;
@@ -364,6 +368,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     auto front = [&](hipStream_t st, int f0, int Bn) {
+        bool fused = false;      // set when the per-level resize launches below also blur their source levels
         // smallest batches (one or two frames): the whole pyramid in ONE launch, every tile of every level derived from the caller's image
         const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
                          (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
@@ -389,11 +394,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, g.chainPacked && !h->resizeBytewise, f0, Bn);
         } else {
+            // large batches: the resize of level l blurs level l - 1 out of the tile it has staged (the blur kernel then only does level 0
+            // and the last level); small batches keep the short-chain blur that rides with FAST
+            fused = h->fuseBlur && g.blurFused && g.nlevels >= 3 && blurVariant(Bn) == 0;
             for (int l = 2; l < g.nlevels; l++) {
                 Prof p(h, S_RESIZE, st);
                 pollute(st);
                 launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
-                             h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows,
+                             h->d_foot + h->footOff[l], h->d_pyr, fused ? h->d_blur : nullptr, g.tileLdsStride, g.tileLdsRows,
                              g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
             }
         }
@@ -402,9 +410,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
         if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
-            const int v = blurVariant(Bn);
+            const int v = fused ? 2 : blurVariant(Bn);
             pollute(st);
-            launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v ? kBlurBlockRowsSmall : kBlurBlockRows,
+            launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows,
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
         }
     };
@@ -564,7 +572,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->scaleFactor = scale_factor;
     h->maxW = max_width; h->maxH = max_height; h->maxB = max_batch;
     h->tabs = makeScaleTables(nfeatures, scale_factor, nlevels);
-    std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom);
+    std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom, true);      // (sizes the LDS tile for either form)
     if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
     layoutArenas(h->maxGeom, max_batch);
     const FrameGeom& mg = h->maxGeom;
@@ -576,8 +584,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->selEntries = (size_t)(mg.selPerFrame + 8 * nlevels) * max_batch;
     h->cellCap = roomy(mg.cells.size());
     h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
-    h->tileCap = roomy((size_t)((max_height + 31) / 32 + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 2) * nlevels);
-    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * ((max_height + 31) / 32 + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 2) * nlevels);
+    h->tileCap = roomy((size_t)(2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
+    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * (2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
     // quad-tree LDS: M nodes (multiple of 8), P = next power of two for the bitonic sort
     int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
     M = (M + 7) / 8 * 8;
@@ -664,6 +672,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
     h->octRoomyForced = getenv("ORBX_OCT_ROOMY") != nullptr;
+    h->fuseBlur = getenv("ORBX_FUSE_BLUR") && atoi(getenv("ORBX_FUSE_BLUR")) != 0;
     if (const char* e = getenv("ORBX_LDS_POLLUTE")) h->ldsPollute = atoi(e) & 255;
     {
         int cus = 0;

@@ -66,7 +66,10 @@ constexpr int kBlurBlockRowsSmall = ORBX_BLUR_SMALL_ROWS;   // ... in small batc
 constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
 
 // Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
-struct TileFoot { short fx0, nDw, fy0, nRows; };   // first source column (multiple of 4), dwords per row, first row, rows
+// A resize tile's staged source rectangle: first column (a multiple of 4; negative = inside the level's border), dwords per row, first
+// row, rows — the tile's tap footprint, widened (levels >= 2) by the part of the SOURCE level this tile blurs: [bx0, bx1) x [by0, by1)
+// (bx multiples of 4; the tiles' blur rectangles partition the source level; empty when the tile blurs nothing) plus the blur's halo.
+struct TileFoot { short fx0, nDw, fy0, nRows, bx0, bx1, by0, by1; };
 
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
 

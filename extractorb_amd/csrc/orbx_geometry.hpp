@@ -117,6 +117,7 @@ struct FrameGeom {
     std::vector<ChainTile> chain;            // tiles of levels 2.. for the small-batch pyramid kernel (k_pyr_rest)
     bool chainFits = true;                   // every intermediate region within kChainMaxW x kChainMaxH
     bool chainPacked = true;                 // the 8 taps of any four adjacent columns of a level >= 2 lie within 8 source bytes (k_pyr_rest<true>)
+    bool blurFused = false;                  // the resize tiles of levels >= 2 carry blur rectangles of their source levels
     std::vector<ChainTile> chainAll;         // tiles of EVERY level for the one-launch pyramid (k_pyr_all: regions down to the caller's image)
     bool chainAllFits = true, chainAllPacked = true;
     int chainAllLdsBytes = 0, chainAllEvenBytes = 0;
@@ -124,7 +125,8 @@ struct FrameGeom {
 };
 
 // Returns an empty string on success, else the reason the geometry is unsupported.
-inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g) {
+// fuseBlur: the resize tiles of levels >= 2 also carry the blur of their source level (wider staged rectangles, blur rectangles set)
+inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, bool fuseBlur = false) {
     g = FrameGeom();
     g.rows = rows; g.cols = cols; g.nlevels = t.nlevels;
     for (int l = 0; l < t.nlevels; l++) {
@@ -213,26 +215,58 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (hi - lo > 7) packed = false;
                 }
                 g.packedTaps[l] = packed;
+                // tap footprints per tile column / tile row (they factor: x taps depend on tx only, y taps on ty only)
+                std::vector<int> fx0(g.tilesX[l]), fx1(g.tilesX[l]), fy0(g.tilesY[l]), fy1(g.tilesY[l]);
+                for (int tx = 0; tx < g.tilesX[l]; tx++) {
+                    int sx0 = 1 << 30, sx1 = -1;
+                    for (int dw = tx * 64; dw < tx * 64 + 64; dw++) {
+                        const int bc0 = 4 * (dw < nd ? dw : nd - 1);
+                        for (int j = 0; j < 4; j++) {
+                            int bx = bc0 + j - (kPadL - kEdge);
+                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                            const ResizeX& c = g.rx[l][refl(bx - kEdge, L.w)];
+                            sx0 = c.sx0 < sx0 ? c.sx0 : sx0; sx1 = c.sx1 > sx1 ? c.sx1 : sx1;
+                        }
+                    }
+                    fx0[tx] = sx0; fx1[tx] = sx1;
+                }
+                for (int ty = 0; ty < g.tilesY[l]; ty++) {
+                    int sy0 = 1 << 30, sy1 = -1;
+                    for (int by = ty * kResizeTileRows; by < (ty + 1) * kResizeTileRows; by++) {
+                        const int b = by < L.pyrRows ? by : L.pyrRows - 1;
+                        const ResizeX& c = g.ry[l][refl(b - kEdge, L.h)];
+                        sy0 = c.sx0 < sy0 ? c.sx0 : sy0; sy1 = c.sx1 > sy1 ? c.sx1 : sy1;
+                    }
+                    fy0[ty] = sy0; fy1[ty] = sy1;
+                }
+                // levels >= 2: the resize of level l also blurs level l - 1 out of the tile it has staged.  The tiles' blur rectangles
+                // partition the source level along the footprints' first columns / rows (monotone; x boundaries multiples of 4).
+                const LevelGeom& S = g.lv[l - 1];
+                const bool fuse = fuseBlur && l >= 2;
+                g.blurFused = fuseBlur;
+                std::vector<int> X(g.tilesX[l] + 1, 0), Y(g.tilesY[l] + 1, 0);
+                for (int tx = 1; tx < g.tilesX[l]; tx++) X[tx] = std::min(std::max(X[tx - 1], fx0[tx] & ~3), S.w);
+                X[g.tilesX[l]] = S.w;
+                for (int ty = 1; ty < g.tilesY[l]; ty++) Y[ty] = std::min(std::max(Y[ty - 1], fy0[ty]), S.h);
+                Y[g.tilesY[l]] = S.h;
                 for (int ty = 0; ty < g.tilesY[l]; ty++)
                     for (int tx = 0; tx < g.tilesX[l]; tx++) {
-                        int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
-                        for (int dw = tx * 64; dw < tx * 64 + 64; dw++) {
-                            const int bc0 = 4 * (dw < nd ? dw : nd - 1);
-                            for (int j = 0; j < 4; j++) {
-                                int bx = bc0 + j - (kPadL - kEdge);
-                                bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
-                                const ResizeX& c = g.rx[l][refl(bx - kEdge, L.w)];
-                                sx0 = c.sx0 < sx0 ? c.sx0 : sx0; sx1 = c.sx1 > sx1 ? c.sx1 : sx1;
-                            }
+                        TileFoot t{};
+                        int x0 = fx0[tx] & ~3, x1 = fx1[tx] + 1, y0 = fy0[ty], y1 = fy1[ty] + 1;      // [x0, x1) x [y0, y1)
+                        if (fuse && X[tx + 1] > X[tx] && Y[ty + 1] > Y[ty]) {
+                            t.bx0 = (short)X[tx]; t.bx1 = (short)X[tx + 1]; t.by0 = (short)Y[ty]; t.by1 = (short)Y[ty + 1];
+                            // the blur reads pixels x-4 .. x+7 of every four-column group and rows y-3 .. y+3; row blocks of
+                            // kFusedBlurRows rows: the last block of the rectangle may run up to kFusedBlurRows - 1 rows past it
+                            x0 = std::min(x0, X[tx] - 4);
+                            x1 = std::max(x1, ((X[tx + 1] + 3) & ~3) + 4);
+                            y0 = std::min(y0, Y[ty] - 3);
+                            y1 = std::max(y1, Y[ty + 1] + 3);
                         }
-                        for (int by = ty * kResizeTileRows; by < (ty + 1) * kResizeTileRows; by++) {
-                            const int b = by < L.pyrRows ? by : L.pyrRows - 1;
-                            const ResizeX& c = g.ry[l][refl(b - kEdge, L.h)];
-                            sy0 = c.sx0 < sy0 ? c.sx0 : sy0; sy1 = c.sx1 > sy1 ? c.sx1 : sy1;
-                        }
-                        TileFoot t;
-                        t.fx0 = (short)(sx0 & ~3); t.nDw = (short)((sx1 - t.fx0 + 4) >> 2);
-                        t.fy0 = (short)sy0; t.nRows = (short)(sy1 - sy0 + 1);
+                        // the bordered source holds columns -19 .. w+18 (dword-aligned reads: -16 .. ((w+19) & ~3) - 1) and rows -19 .. h+18
+                        x0 = std::max(x0, -16); x1 = std::min(x1, (S.w + kEdge) & ~3);
+                        y0 = std::max(y0, -kEdge); y1 = std::min(y1, S.h + kEdge);
+                        t.fx0 = (short)x0; t.nDw = (short)((x1 - x0 + 3) >> 2);
+                        t.fy0 = (short)y0; t.nRows = (short)(y1 - y0);
                         g.foot[l].push_back(t);
                         if (t.nDw * 4 > g.tileLdsStride) g.tileLdsStride = (t.nDw * 4 + 15) / 16 * 16;
                         if (t.nRows > g.tileLdsRows) g.tileLdsRows = t.nRows;

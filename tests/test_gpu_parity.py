@@ -380,6 +380,28 @@ def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B,
     assert_same_result(out[B - 1][:3], want, "last frame of %d vs oracle" % B)
 
 
+@pytest.mark.parametrize("B,shape,split", [(72, (240, 320), False), (40, (480, 640), False), (300, (240, 320), True), (24, (333, 517), False)])
+def test_blur_inside_the_resize_launches(B, shape, split, monkeypatch):
+    """ORBX_FUSE_BLUR=1: in large batches the resize of level l also blurs level l - 1 out of the tile it has staged (k_blur is left with
+    level 0 and the last level): every blurred level and the final arrays against the oracle."""
+    monkeypatch.setenv("ORBX_FUSE_BLUR", "1")
+    monkeypatch.setenv("ORBX_SPLIT_MIN_MPX" if split else "ORBX_SPLIT", "0")
+    fr = synth.frames("textured", 41, B, *shape)
+    ex = X.ORBextractor(700, max_width=shape[1], max_height=shape[0], max_batch=B)
+    out = ex.extract_batch(fr)
+    prof_before = None
+    for f in (0, B // 2, B - 1):
+        o, want = oracle_run(fr[f], 700)
+        assert_same_result(out[f][:3], want, "frame %d of %d" % (f, B))
+        for l in range(8):
+            assert np.array_equal(ex.debug_blurred(l, f), o.blurred(l)), "blur level %d of frame %d" % (l, f)
+    ex.profile(True)
+    ex.extract_batch(fr)
+    p = ex.profile_read()
+    ex.profile(False)
+    assert p["k_resize"][1] == 6 and p["k_blur"][1] == 1      # the fused form really ran: six resize launches, one (short) blur launch
+
+
 @pytest.mark.parametrize("shape,nf", [((480, 640), 10000), ((376, 1241), 10000), ((480, 640), 25000), ((480, 752), 6000)])
 def test_initialisation_extractor_quotas(shape, nf):
     # the reference builds its monocular initialisation extractor with 5 * nFeatures (Tracking.cc:774): 5 x 2000 = 10000 for a
