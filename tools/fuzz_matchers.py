@@ -12,6 +12,8 @@ import numpy as np
 n, s0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 20), (int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
 import test_search_projection as P
 import test_search_bow as W
+import test_search_init as I
+from extractorb_amd import synth
 t0 = time.time()
 done = 0
 for k in range(n):
@@ -25,5 +27,9 @@ for k in range(n):
                 n_nodes=int(rng.choice([3, 60, 400, 2000])), tie_heavy=bool(rng.random() < 0.3))
     W.test_gpu_search_by_bow_equals_oracle(case)
     W.test_gpu_keyframe_search_by_bow_equals_oracle(case)
+    if k % 5 == 0:      # SearchForInitialization on a freshly extracted stream (heavier: six frames through the HIP path and the oracle)
+        frames = synth.frames(["textured", "noise", "sparse", "natural"][int(rng.integers(0, 4))], seed, 6, 480, 640)
+        I.run_gpu_pairs(frames, ((0, 1), (1, 1), 5), I.PINHOLE, int(rng.choice([300, 1000, 2000, 5000])), int(rng.choice([30, 100, 300])),
+                        float(rng.choice([0.6, 0.9, 1.3])), bool(rng.integers(0, 2)), rounds=int(rng.integers(1, 3)))
     done += 1
-print("matcher soak: %d seeds x 4 matcher parity bodies bit-exact, %.0f s" % (done, time.time() - t0))
+print("matcher soak: %d seeds x 4 matcher parity bodies (+ SearchForInitialization every fifth seed) bit-exact, %.0f s" % (done, time.time() - t0))
