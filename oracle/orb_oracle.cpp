@@ -3,13 +3,19 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 // The product path (extractorb_amd/, liborbx.so) never links, imports or calls it.
 //
-// PARITY UNPINNED: the reference (/root/reference/src/orb_extractor/ORBextractor.cc) delegates all
-// pixel arithmetic to OpenCV 3 (CMakeLists.txt:23), which is neither vendored in the reference nor
-// installed in this image, and the reference ships no tests or golden vectors.
-// This file therefore restates (a) the control flow, constants, float/int conversion points and
+// PARITY: PINNED FOR DETECTION BY ONE REFERENCE-HELD COUNT, UNPINNED FOR THE REST.  The reference
+// (/root/reference/src/orb_extractor/ORBextractor.cc) delegates all pixel arithmetic to OpenCV 3 (CMakeLists.txt:23), which is
+// neither vendored in the reference nor installed in this image, and the reference ships no tests or golden vectors
+// (SURVEY.md §4, §8c).  It holds one recorded result: img_folder/Screenshot.png, "ORB_SLAM3 has total 1420 keypoints", printed by
+// src/orb_extractor/main_orb_extractor.cpp:34-53 (nFeatures 1500) on pic/TUM/dataset-room4_512_16/.../1520531124150444163.png.
+// This file returns exactly 1420 there (tests/test_reference_pin.py); `enum Mutation` below measures which restated semantics
+// that count decides (resize rounding, level chain and sizes, FAST strictness, per-cell strict NMS, threshold retry, 30-px grid,
+// the ">= N" stop rule) and which it does not.  PARITY UNPINNED for: keypoint order, GaussianBlur taps, fastAtan2, cosf/sinf, the
+// rBRIEF rounding, undistortPoints and every "next"-row function — no reference-held vector exists for them.
+// This file restates (a) the control flow, constants, float/int conversion points and
 // container order of ORBextractor.cc, each function citing the lines it follows, and (b) the
 // published OpenCV 3.4 generic-C++ semantics of the seven primitives the reference calls
-// (SURVEY.md Appendix A).  The primitives are pinned by independent definitions in tests/
+// (SURVEY.md Appendix A).  The primitives are additionally checked against independent definitions in tests/
 // (brute-force FAST-9 predicate/score, scipy mirror convolution for the blur, double-precision
 // atan2, exhaustive glibc sinf/cosf comparison), not by a real OpenCV run.
 //
@@ -47,6 +53,33 @@ inline short saturateShort(float v) {
     return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sensitivity knob (tests/test_reference_pin.py, tools/pin_sensitivity.py): 0 = the faithful restatement.  A non-zero value
+// swaps exactly ONE restated semantic for a plausible alternative, so that the reference-held known answer
+// (img_folder/Screenshot.png: 1420 keypoints) can be shown to move — or not — with that semantic.  Set per
+// extract() call from Oracle::mutation; never set by anything but those two files.
+// ---------------------------------------------------------------------------------------------
+enum Mutation {
+    MUT_NONE = 0,
+    MUT_RESIZE_TRUNC = 1,        // A.1: vertical pass without the "+2" rounding term
+    MUT_RESIZE_FROM_LEVEL0 = 2,  // :1183 resizes level l-1; mutation: every level straight from level 0
+    MUT_RESIZE_NO_RIGHT_CLAMP = 3,  // A.1: the sx >= sw-1 column keeps its fractional weight (reads the clamped neighbour)
+    MUT_LEVEL_SIZE_FLOOR = 4,    // :1171 cvRound of the level size; mutation: truncation
+    MUT_FAST_GE = 5,             // A.3: arc pixels strictly beyond v±t; mutation: >=
+    MUT_NMS_GE = 6,              // A.3: strict 3x3 maximum; mutation: >= (ties survive)
+    MUT_NMS_ACROSS_ROI = 7,      // A.3: NMS sees only the cell ROI's own scores; mutation: one score map per level
+    MUT_NO_MIN_TH_RETRY = 8,     // :835-838 empty cell -> minThFAST; mutation: no retry
+    MUT_SKIP_X_MINUS3 = 9,       // :802 iniX >= maxBorderX-6 skips the column; mutation: -3 as for rows
+    MUT_STOP_GT_N = 10,          // :674 / :735 stop at size >= N; mutation: > N
+    MUT_PHASE2_GE_N = 11,        // :678 enters the sorted phase when size + 3*nToExpand > N; mutation: >=
+    MUT_TIE_OLDEST_FIRST = 12,   // :689 sort ties (heap address in the reference; oracle: newest first); mutation: oldest first
+    MUT_HALF_FLOOR = 13,         // :488-489 ceil of the half extent; mutation: floor
+    MUT_CELL_W_35 = 14,          // :777 W = 30; mutation: 35 (OpenCV-ORB-like grid)
+    MUT_16BIT_SCALED = 15,       // (input decode, applied in Python) 16-bit PNG -> 8 bit by v*255/65535 instead of the high byte
+    MUT_COUNT
+};
+thread_local int g_mut = MUT_NONE;
+
 const int PATCH_SIZE = 31;        // ORBextractor.cc:70
 const int HALF_PATCH_SIZE = 15;   // ORBextractor.cc:71
 const int EDGE_THRESHOLD = 19;    // ORBextractor.cc:72
@@ -82,7 +115,7 @@ void resizeLinear8u(const uint8_t* src, int sw, int sh, int sstride,
         int sx = cvFloorF(fx);
         fx -= sx;
         if (sx < 0) { fx = 0; sx = 0; }
-        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        if (sx >= sw - 1) { if (g_mut != MUT_RESIZE_NO_RIGHT_CLAMP) fx = 0; sx = sw - 1; }
         xofs[dx] = sx;
         alpha[2 * dx] = saturateShort((1.f - fx) * 2048);
         alpha[2 * dx + 1] = saturateShort(fx * 2048);
@@ -100,7 +133,7 @@ void resizeLinear8u(const uint8_t* src, int sw, int sh, int sstride,
         const uint8_t* S = src + (size_t)sy * sstride;
         for (int dx = 0; dx < dw; dx++) {
             int sx = xofs[dx];
-            if (sx >= sw - 1) out[dx] = S[sx] * 2048;   // right-clamped columns use one tap
+            if (sx >= sw - 1) out[dx] = g_mut == MUT_RESIZE_NO_RIGHT_CLAMP ? S[sw - 1] * (alpha[2 * dx] + alpha[2 * dx + 1]) : S[sx] * 2048;   // right-clamped columns use one tap
             else out[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
         }
     };
@@ -112,7 +145,7 @@ void resizeLinear8u(const uint8_t* src, int sw, int sh, int sstride,
         int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
         uint8_t* D = dst + (size_t)dy * dstride;
         for (int dx = 0; dx < dw; dx++)
-            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + (g_mut == MUT_RESIZE_TRUNC ? 0 : 2)) >> 2);
     }
 }
 
@@ -190,7 +223,7 @@ inline int fastScoreAt(const uint8_t* p, int stride, int t, bool* isCorner) {
         sBright = std::max(sBright, -mx);  // all -d > t <=> ring brighter than v + t
     }
     int s = std::max(sDark, sBright);
-    *isCorner = s > t;
+    *isCorner = g_mut == MUT_FAST_GE ? s >= t : s > t;
     return std::max(t, s) - 1;
 }
 
@@ -212,8 +245,12 @@ void fastDetect(const Gray& roi, int threshold, bool nms, std::vector<KeyPoint>&
             int s = score[(size_t)y * W + x];
             if (nms) {
                 const uint8_t* c = &score[(size_t)y * W + x];
-                if (!(s > c[-1] && s > c[1] && s > c[-W - 1] && s > c[-W] && s > c[-W + 1] &&
-                      s > c[W - 1] && s > c[W] && s > c[W + 1]))
+                if (g_mut == MUT_NMS_GE) {
+                    if (!(s >= c[-1] && s >= c[1] && s >= c[-W - 1] && s >= c[-W] && s >= c[-W + 1] &&
+                          s >= c[W - 1] && s >= c[W] && s >= c[W + 1]))
+                        continue;
+                } else if (!(s > c[-1] && s > c[1] && s > c[-W - 1] && s > c[-W] && s > c[-W + 1] &&
+                             s > c[W - 1] && s > c[W] && s > c[W + 1]))
                     continue;
             }
             out.push_back(KeyPoint{(float)x, (float)y, 7.f, -1.f, (float)s, 0, -1});
@@ -306,8 +343,8 @@ struct Node {
     long seq = 0;   // creation order: the oracle's declared tie-break for the sort at :689
 
     void divide(Node& n1, Node& n2, Node& n3, Node& n4) const {
-        const int halfX = (int)std::ceil(static_cast<float>(UR.x - UL.x) / 2);
-        const int halfY = (int)std::ceil(static_cast<float>(BR.y - UL.y) / 2);
+        const int halfX = g_mut == MUT_HALF_FLOOR ? (UR.x - UL.x) / 2 : (int)std::ceil(static_cast<float>(UR.x - UL.x) / 2);
+        const int halfY = g_mut == MUT_HALF_FLOOR ? (BR.y - UL.y) / 2 : (int)std::ceil(static_cast<float>(BR.y - UL.y) / 2);
         n1.UL = UL;
         n1.UR = Pt2i{UL.x + halfX, UL.y};
         n1.BL = Pt2i{UL.x, UL.y + halfY};
@@ -394,14 +431,20 @@ std::vector<KeyPoint> distributeOctTree(const std::vector<KeyPoint>& vToDistribu
             pushChildren(n1, n2, n3, n4, &nToExpand);
             lit = lNodes.erase(lit);
         }
-        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+        const int stopAt = g_mut == MUT_STOP_GT_N ? N + 1 : N;
+        if ((int)lNodes.size() >= stopAt || (int)lNodes.size() == prevSize) {
             bFinish = true;
-        } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+        } else if (((int)lNodes.size() + nToExpand * 3) > (g_mut == MUT_PHASE2_GE_N ? N - 1 : N)) {
             while (!bFinish) {
                 prevSize = (int)lNodes.size();
                 std::vector<SizeSeqNode> vPrev = vSizeAndPointerToNode;
                 vSizeAndPointerToNode.clear();
                 // reference: sort by (size, heap pointer); oracle: by (size, creation seq)
+                if (g_mut == MUT_TIE_OLDEST_FIRST)
+                    std::sort(vPrev.begin(), vPrev.end(), [](const SizeSeqNode& a, const SizeSeqNode& b) {
+                        return a.first.first != b.first.first ? a.first.first < b.first.first : a.first.second > b.first.second;
+                    });
+                else
                 std::sort(vPrev.begin(), vPrev.end(),
                           [](const SizeSeqNode& a, const SizeSeqNode& b) { return a.first < b.first; });
                 for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
@@ -409,9 +452,9 @@ std::vector<KeyPoint> distributeOctTree(const std::vector<KeyPoint>& vToDistribu
                     vPrev[j].second->divide(n1, n2, n3, n4);
                     pushChildren(n1, n2, n3, n4, nullptr);
                     lNodes.erase(vPrev[j].second->lit);
-                    if ((int)lNodes.size() >= N) break;
+                    if ((int)lNodes.size() >= stopAt) break;
                 }
-                if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+                if ((int)lNodes.size() >= stopAt || (int)lNodes.size() == prevSize) bFinish = true;
             }
         }
     }
@@ -446,6 +489,7 @@ struct Oracle {
     std::vector<Level> pyr;
     std::vector<std::vector<uint8_t>> blurred;
     std::vector<std::vector<KeyPoint>> candidates, levelKeys;
+    int mutation = MUT_NONE;   // sensitivity knob, see enum Mutation
 
     Oracle(int nf, float sf, int nl, int ini, int mn)
         : nfeatures(nf), nlevels(nl), iniThFAST(ini), minThFAST(mn), scaleFactor(sf) {
@@ -495,11 +539,11 @@ struct Oracle {
         for (int level = 0; level < nlevels; ++level) {
             float scale = mvInvScaleFactor[level];
             Level& L = pyr[level];
-            L.w = cvRoundF((float)image.w * scale);
-            L.h = cvRoundF((float)image.h * scale);
+            L.w = g_mut == MUT_LEVEL_SIZE_FLOOR ? (int)((float)image.w * scale) : cvRoundF((float)image.w * scale);
+            L.h = g_mut == MUT_LEVEL_SIZE_FLOOR ? (int)((float)image.h * scale) : cvRoundF((float)image.h * scale);
             L.buf.assign((size_t)(L.w + 2 * EDGE_THRESHOLD) * (L.h + 2 * EDGE_THRESHOLD), 0);
             if (level != 0) {
-                const Level& P = pyr[level - 1];
+                const Level& P = pyr[g_mut == MUT_RESIZE_FROM_LEVEL0 ? 0 : level - 1];
                 resizeLinear8u(P.interior(), P.w, P.h, P.stride(), L.interior(), L.w, L.h, L.stride());
             } else {
                 for (int y = 0; y < L.h; y++)
@@ -539,7 +583,7 @@ struct Oracle {
 
     // ORBextractor.cc:773-888
     void computeKeyPointsOctTree() {
-        const float W = 30;
+        const float W = g_mut == MUT_CELL_W_35 ? 35 : 30;
         for (int level = 0; level < nlevels; ++level) {
             const Level& L = pyr[level];
             const int minBorderX = EDGE_THRESHOLD - 3;
@@ -554,6 +598,15 @@ struct Oracle {
             const int nRows = (int)(height / W);
             const int wCell = (int)std::ceil(width / nCols);
             const int hCell = (int)std::ceil(height / nRows);
+            // MUT_NMS_ACROSS_ROI: one FAST + NMS over the whole active rectangle per threshold, dealt to the cells afterwards
+            std::vector<KeyPoint> wholeIni, wholeMin;
+            if (g_mut == MUT_NMS_ACROSS_ROI) {
+                Gray all;
+                all.w = maxBorderX - minBorderX; all.h = maxBorderY - minBorderY; all.stride = L.stride();
+                all.p = L.interior() + (size_t)minBorderY * L.stride() + minBorderX;
+                fastDetect(all, iniThFAST, true, wholeIni);
+                fastDetect(all, minThFAST, true, wholeMin);
+            }
             for (int i = 0; i < nRows; i++) {
                 const float iniY = (float)(minBorderY + i * hCell);
                 float maxY = iniY + hCell + 6;
@@ -562,7 +615,7 @@ struct Oracle {
                 for (int j = 0; j < nCols; j++) {
                     const float iniX = (float)(minBorderX + j * wCell);
                     float maxX = iniX + wCell + 6;
-                    if (iniX >= maxBorderX - 6) continue;
+                    if (iniX >= maxBorderX - (g_mut == MUT_SKIP_X_MINUS3 ? 3 : 6)) continue;
                     if (maxX > maxBorderX) maxX = (float)maxBorderX;
                     Gray roi;
                     roi.w = (int)maxX - (int)iniX;
@@ -570,8 +623,17 @@ struct Oracle {
                     roi.stride = L.stride();
                     roi.p = L.interior() + (size_t)(int)iniY * L.stride() + (int)iniX;
                     std::vector<KeyPoint> vKeysCell;
+                    if (g_mut == MUT_NMS_ACROSS_ROI) {
+                        // the cell's own pixels: ROI interior [3, w-3) x [3, h-3), in rectangle coordinates
+                        const int x0 = j * wCell + 3, x1 = j * wCell + roi.w - 3, y0 = i * hCell + 3, y1 = i * hCell + roi.h - 3;
+                        for (int pass = 0; pass < 2 && vKeysCell.empty(); pass++)
+                            for (const KeyPoint& kp : (pass ? wholeMin : wholeIni))
+                                if (kp.x >= x0 && kp.x < x1 && kp.y >= y0 && kp.y < y1) vKeysCell.push_back(kp);
+                        for (auto& kp : vKeysCell) vToDistributeKeys.push_back(kp);
+                        continue;
+                    }
                     fastDetect(roi, iniThFAST, true, vKeysCell);
-                    if (vKeysCell.empty()) fastDetect(roi, minThFAST, true, vKeysCell);
+                    if (vKeysCell.empty() && g_mut != MUT_NO_MIN_TH_RETRY) fastDetect(roi, minThFAST, true, vKeysCell);
                     for (auto& kp : vKeysCell) {
                         kp.x += j * wCell;
                         kp.y += i * hCell;
@@ -619,6 +681,7 @@ struct Oracle {
     // value of the reference's operator().
     int extract(const Gray& image, int lap0, int lap1, KeyPoint* outK, uint8_t* outD, int capacity, int* mono) {
         if (image.w <= 0 || image.h <= 0 || !image.p) { *mono = -1; return -1; }
+        struct MutScope { MutScope(int m) { g_mut = m; } ~MutScope() { g_mut = MUT_NONE; } } mutScope(mutation);
         computePyramid(image);
         computeKeyPointsOctTree();
         int nkeypoints = 0;
@@ -660,6 +723,8 @@ void* oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, in
     return new Oracle(nfeatures, scaleFactor, nlevels, iniTh, minTh);
 }
 void oracle_destroy(void* h) { delete (Oracle*)h; }
+// sensitivity knob for the reference-held pin (enum Mutation); 0 = faithful.  Returns the number of defined mutations.
+int oracle_set_mutation(void* h, int m) { ((Oracle*)h)->mutation = (m > 0 && m < MUT_COUNT) ? m : MUT_NONE; return MUT_COUNT; }
 
 int oracle_extract(void* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
                    void* kps, uint8_t* desc, int capacity, int* mono_index) {

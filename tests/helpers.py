@@ -19,7 +19,7 @@ def load_case(case):
                 level_counts=z["level_counts"], candidate_counts=z["candidate_counts"])
 
 
-GOLDEN_CASES = ["luna_1000", "luna_1000_lap00", "luna_7500", "robot_865_1000", "robot_865_1200_lap", "tum_corridor_1000"]
+GOLDEN_CASES = ["luna_1000", "luna_1000_lap00", "luna_7500", "robot_865_1000", "robot_865_1200_lap", "tum_corridor_1000", "tum_room4_1500"]
 
 
 def sort_kps(k):

@@ -38,6 +38,8 @@ def lib():
         L.oracle_create.restype = vp
         L.oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.oracle_destroy.argtypes = [vp]
+        L.oracle_set_mutation.restype = C.c_int
+        L.oracle_set_mutation.argtypes = [vp, C.c_int]
         L.oracle_extract.restype = C.c_int
         L.oracle_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
         L.oracle_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -119,6 +121,10 @@ class Oracle:
             self.L.oracle_destroy(self.h)
         except Exception:
             pass
+
+    def set_mutation(self, m):
+        """Sensitivity knob for tests/test_reference_pin.py (oracle/orb_oracle.cpp `enum Mutation`); 0 = the faithful restatement."""
+        return self.L.oracle_set_mutation(self.h, int(m))
 
     def extract(self, image, lapping=(0, 1000)):
         """Returns (mono_index, keypoints[structured], descriptors[n,32]); mono_index -1 for empty."""

@@ -1,0 +1,105 @@
+"""The one known answer the reference itself holds for this path.
+
+/root/reference/img_folder/Screenshot.png is a capture of the author's IDE after running the demo main
+(src/orb_extractor/main_orb_extractor.cpp:34-53: nFeatures = 1500, scale 1.2, 8 levels, FAST 20/7; ComputePyramid +
+ComputeKeyPointsOctTree; the sum of the per-level vector sizes is printed).  Its console pane reads
+
+    The ../pic/TUM/dataset-room4_512_16/ma...     (image path, cut off by the pane)
+    ORB_SLAM3 has total 1420 keypoints
+
+The frame is pic/TUM/dataset-room4_512_16/mav0/cam0/data/1520531124150444163.png (16-bit PNG; imread(IMREAD_GRAYSCALE) keeps the high
+byte), committed as tests/golden/tum_room4_gray.png.  1420 is a number produced by the REAL reference on REAL OpenCV: it is the only
+reference-held pin of the oracle.  What it pins and what it does not is measured below, one restated semantic at a time
+(`enum Mutation` in oracle/orb_oracle.cpp; table in DESIGN.md §2, printed by tools/pin_sensitivity.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import load_case, load_gray
+
+REFERENCE_TOTAL = 1420           # img_folder/Screenshot.png
+REFERENCE_PARAMS = (1500, 1.2, 8, 20, 7)    # main_orb_extractor.cpp:34-38
+
+# mutation id -> (name, does the reference's 1420 move?)  Kept in step with `enum Mutation`.
+MUTATIONS = {
+    1: ("resize: no +2 rounding term in the vertical pass", True),
+    2: ("pyramid: every level resized from level 0 instead of level l-1", True),
+    3: ("resize: right-clamped column keeps its fractional weight", False),
+    4: ("level size: truncation instead of cvRound", True),
+    5: ("FAST: arc pixels >= threshold instead of >", True),
+    6: ("NMS: >= instead of strict >", True),
+    7: ("NMS over the whole level instead of per cell ROI", True),
+    8: ("no minThFAST retry for empty cells", True),
+    9: ("column skip at maxBorderX-3 instead of -6", False),
+    10: ("quad-tree stops at size > N instead of >= N", True),
+    11: ("sorted phase entered at size+3*nToExpand >= N instead of > N", False),
+    12: ("sort ties: oldest node first instead of newest", False),
+    13: ("DivideNode: floor instead of ceil of the half extent", False),
+    14: ("cell width W = 35 instead of 30", True),
+}
+
+
+def total_with(mutation, image):
+    o = O.Oracle(*REFERENCE_PARAMS)
+    assert o.set_mutation(mutation) == 16
+    o.extract(image, (0, 1000))
+    return [len(o.level_keypoints(l)) for l in range(8)]
+
+
+def test_oracle_reproduces_the_reference_screenshot_count():
+    counts = total_with(0, load_gray("tum_room4_gray.png"))
+    assert sum(counts) == REFERENCE_TOTAL, counts
+    # levels 0-4 stop at their quota exactly (326, 271, 226, 189, 157: the `size >= N` exits of :674 / :735), levels 5-7 keep every
+    # FAST candidate (127, 63, 61 < quota): the sum tests both regimes
+    o = O.Oracle(*REFERENCE_PARAMS)
+    assert counts[:5] == o.features_per_level[:5].tolist() and all(c < q for c, q in zip(counts[5:], o.features_per_level[5:]))
+
+
+def test_golden_file_of_the_pinned_frame_sums_to_the_reference_count():
+    c = load_case("tum_room4_1500")
+    assert int(c["level_counts"].sum()) == REFERENCE_TOTAL == len(c["keypoints"])
+
+
+@pytest.mark.parametrize("mutation", sorted(MUTATIONS))
+def test_what_the_count_pins(mutation):
+    """Each semantic marked True is one the reference count decides between the restated form and the alternative (the mutated
+    oracle no longer returns 1420); each marked False is NOT pinned by it on this frame and stays on the independent pins."""
+    name, moves = MUTATIONS[mutation]
+    got = sum(total_with(mutation, load_gray("tum_room4_gray.png")))
+    assert (got != REFERENCE_TOTAL) == moves, "%s: %d" % (name, got)
+
+
+def test_decode_of_the_16_bit_frame_is_only_weakly_pinned():
+    """imread(IMREAD_GRAYSCALE) of a 16-bit PNG strips to the high byte.  A scaled conversion (v*255/65535, rounded) changes three
+    levels' counts (125, 62, 64 instead of 127, 63, 61) whose sum happens to be the same 251: a sum is a weak hash and the file says so."""
+    from PIL import Image
+    import os
+    if not os.path.exists("/root/reference/pic/TUM"):
+        pytest.skip("needs the 16-bit original under /root/reference (build container only)")
+    a = np.array(Image.open("/root/reference/pic/TUM/dataset-room4_512_16/mav0/cam0/data/1520531124150444163.png")).astype(np.uint32)
+    assert np.array_equal((a >> 8).astype(np.uint8), load_gray("tum_room4_gray.png"))
+    scaled = ((a * 255 + 32767) // 65535).astype(np.uint8)
+    counts = total_with(0, scaled)
+    assert counts[5:] == [125, 62, 64] and sum(counts) == REFERENCE_TOTAL
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_reference_screenshot_count():
+    """The HIP path on the reference's frame with the reference's parameters: 1420 keypoints, and bit for bit the oracle's."""
+    import extractorb_amd as X
+    img = load_gray("tum_room4_gray.png")
+    ex = X.ORBextractor(*REFERENCE_PARAMS, max_width=512, max_height=512)
+    mono, k, d, lvl = ex(img, None, (0, 1000))
+    assert sum(len(x) for x in lvl) == REFERENCE_TOTAL == len(k)
+    o = O.Oracle(*REFERENCE_PARAMS)
+    wmono, wk, wd = o.extract(img, (0, 1000))
+    assert mono == wmono and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
+    for l in range(8):
+        assert lvl[l].tobytes() == o.level_keypoints(l).tobytes()
+        assert ex.debug_candidates(l).tobytes() == o.candidates(l).tobytes()
+    # the demo's second call shape: ORBextractor(5 * nFeatures) (main_orb_extractor.cpp:43 today): every candidate survives
+    ex5 = X.ORBextractor(7500, 1.2, 8, 20, 7, max_width=512, max_height=512)
+    _, k5, _, lvl5 = ex5(img, None, (0, 1000))
+    o5 = O.Oracle(7500, 1.2, 8, 20, 7)
+    _, wk5, _ = o5.extract(img, (0, 1000))
+    assert len(k5) == 1547 and k5.tobytes() == wk5.tobytes()

@@ -7,6 +7,9 @@ depend on a JPEG decoder:
   pic/luna.jpg                       -> luna_gray.png        (512x512, Y channel)
   pic/robot/865_im.jpg               -> robot_865_gray.png   (640x480)
   pic/TUM/dataset-corridor2_512_16/* -> tum_corridor_gray.png (512x512, 16-bit -> high byte)
+  pic/TUM/dataset-room4_512_16/mav0/cam0/data/1520531124150444163.png -> tum_room4_gray.png (512x512, 16-bit -> high byte):
+      the frame of the reference's ONE recorded result, img_folder/Screenshot.png ("ORB_SLAM3 has total 1420 keypoints",
+      printed by src/orb_extractor/main_orb_extractor.cpp:34-53 with nFeatures = 1500): tests/test_reference_pin.py
 Expected outputs: the CPU oracle's results on those inputs (oracle/orb_oracle.cpp), one .npz per case.
 The reference ships no golden vectors and cannot be built here (no OpenCV), so these pin the oracle
 against itself over time ("parity unpinned") and give the GPU box known-answer files.
@@ -45,6 +48,7 @@ CASES = [
     ("robot_865_1000", "robot_865_gray.png", 1000, (0, 1000)),
     ("robot_865_1200_lap", "robot_865_gray.png", 1200, (200, 400)),   # fisheye-style lapping band
     ("tum_corridor_1000", "tum_corridor_gray.png", 1000, (0, 1000)),
+    ("tum_room4_1500", "tum_room4_gray.png", 1500, (0, 1000)),         # the Screenshot.png frame and parameters: 1420 keypoints
 ]
 
 
@@ -55,6 +59,7 @@ def main():
         "robot_865_gray.png": os.path.join(REF, "robot", "865_im.jpg"),
         "tum_corridor_gray.png": sorted(glob.glob(os.path.join(REF, "TUM", "dataset-corridor2_512_16", "**", "*.png"),
                                                   recursive=True))[0],
+        "tum_room4_gray.png": os.path.join(REF, "TUM", "dataset-room4_512_16", "mav0", "cam0", "data", "1520531124150444163.png"),
     }
     for name, src in srcs.items():
         g = gray8(src)
