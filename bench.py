@@ -9,6 +9,10 @@ RCCL inside the timed region (BASELINE.json north_star; disable with --no-gather
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mono640|hd1080|stereo640] [--batch B]
 
+`python bench.py --gpus N` works as typed: when no launcher has set RANK, the process — before it imports torch or touches the
+GPU in any way — starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD, relays rank 0's JSON line and
+exits with the child's code (`spawn_command`).  Under a launcher (RANK set) it is one of the N ranks.
+
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
 import argparse
@@ -77,6 +81,46 @@ def _search_rounds():
     return list(out)
 
 
+def spawn_command(argv, gpus, port=None):
+    """The command the parent runs when `python bench.py --gpus N` is typed without a launcher: one rank per GPU of this node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve).  `argv` = bench.py's own arguments, passed through unchanged
+    (minus --spawn, which only forces this path at N = 1 for the test)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:          # a free port; no GPU or torch involved
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    rest = [a for a in argv if a != "--spawn"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def spawn_ranks(argv, gpus):
+    """Parent side of `--gpus N` without a launcher.  Nothing here imports torch or initialises HIP: the ranks are CHILD processes
+    (never an exec of a process that has touched the GPU).  Relays the ranks' output, prints rank 0's JSON line last, returns the
+    launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = spawn_command(argv, gpus)
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")            # rank 0's result: printed once, last
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +135,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures of the default line (host-to-host rate, 1080p)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even at N = 1 (what --gpus N > 1 does "
+                    "by itself when no launcher set RANK)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed slab")
     args = ap.parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        return spawn_ranks(sys.argv[1:], args.gpus)      # BEFORE torch / HIP are imported: the parent never touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -107,7 +156,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
     if world != N:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (N, world))
+        raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (N, world))
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run (any world size)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
@@ -134,6 +183,8 @@ def main():
     if color:      # channel c of frame f = gray frame (f + c) of the stream: three different planes, interleaved
         d_color = torch.stack([torch.roll(d_img, -c, 0) for c in range(color)], dim=-1).contiguous()
     nH = max(1, args.handles)
+    if nH > 1 and any(wl.get(k) for k in ("match", "init_match", "track", "bow", "refkf")):
+        raise SystemExit("--handles > 1 is for the plain extraction workloads: the next-row scratch arrays of %s are one set per process" % args.workload)
     exs = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank) for _ in range(nH)]
     ex = exs[0]
     stream = torch.cuda.current_stream()
@@ -289,6 +340,77 @@ def main():
     n_host = slabs[0][off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
     fps = N * B * args.steps / elapsed
 
+    # ---- BASELINE.json configs[4] as a secondary figure of every N > 1 line: 64 frames per GPU per step (512 frames on 8 GPUs),
+    #      result slabs gathered to rank 0; same step / fence / max-over-ranks rules as the main figure ----
+    cfg5 = None
+    if distributed and N > 1 and args.workload == "mono640" and not args.no_extras:
+        B5 = min(64, B)
+        e5 = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B5, device=local_rank)
+        e5.set_stream(stream.cuda_stream)
+        l5 = sharding.slab_layout(B5, cap)
+        s5 = [torch.zeros(l5["bytes"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+        g5 = [[torch.empty_like(s5[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
+        p5 = [None, None]
+
+        def step5(i):
+            k5 = i & 1
+            if p5[k5] is not None:
+                p5[k5].wait()
+                p5[k5] = None
+            b5 = s5[k5].data_ptr()
+            e5.extract_batch_device(d_img, B5, rows, cols, b5 + l5["keypoints"], b5 + l5["descriptors"], b5 + l5["n"], b5 + l5["mono"], cap,
+                                    lapping=wl["lapping"])
+            if gather:
+                p5[k5] = dist.gather(s5[k5], g5[k5] if rank == 0 else None, dst=0, async_op=True)
+
+        def fence5():
+            for i5 in range(2):
+                if p5[i5] is not None:
+                    p5[i5].wait()
+                    p5[i5] = None
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+        for i in range(4):
+            step5(i)
+        fence5()
+        K5 = max(args.steps, 20)
+        t5 = time.perf_counter()
+        for i in range(K5):
+            step5(i)
+        fence5()
+        dt5 = torch.tensor([time.perf_counter() - t5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt5, op=dist.ReduceOp.MAX)
+        dt5 = float(dt5.item())
+        cfg5 = dict(frames_per_gpu_per_step=B5, global_frames_per_step=N * B5, steps=K5, fps=round(N * B5 * K5 / dt5, 1),
+                    ms_per_step=round(dt5 / K5 * 1e3, 4), note="BASELINE.json configs[4]: %d frames sharded 64 per GPU, result slabs gathered to rank 0%s"
+                    % (N * B5, "" if gather else " (gather disabled)"))
+        del e5
+
+    # ---- what was timed is what is checked: frames of the LAST timed step's slab against the oracle, after the timed region ----
+    verified = None
+    if rank == 0 and not args.no_verify and args.steps > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O      # the checker; never the product path
+        last = slabs[(counter[0] - 1) % len(slabs)]
+        picks = sorted({0, max(B // 2 - 1, 0), min(B // 2, B - 1), B - 1})       # first / last frame of each half-batch
+        h_n = last[off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
+        h_m = last[off_m:off_m + 4 * B].cpu().numpy().view(np.int32)
+        orc = O.Oracle(nf, 1.2, 8, 20, 7)
+        bad = []
+        for f in picks:
+            img = d_img[f].cpu().numpy()        # the gray frame the timed step read (for *_bgr: what k_gray wrote)
+            wm, wk, wd = orc.extract(img, wl["lapping"])
+            n = int(h_n[f])
+            gk = last[off_k + f * cap * 28: off_k + f * cap * 28 + n * 28].cpu().numpy().tobytes()
+            gd = last[off_d + f * cap * 32: off_d + f * cap * 32 + n * 32].cpu().numpy().tobytes()
+            if not (n == len(wk) and int(h_m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
+                bad.append(f)
+        verified = dict(frames=picks, of_step="last timed step (slab %d)" % ((counter[0] - 1) % len(slabs)), against="oracle (CPU restatement)",
+                        compared="n, mono index, keypoints (28 B each), descriptors (32 B each)", keypoints=int(sum(int(h_n[f]) for f in picks)),
+                        bit_exact=not bad, mismatching_frames=bad)
+        if bad:
+            print("bench.py: TIMED RESULTS DIFFER FROM THE ORACLE on frames %s" % bad, file=sys.stderr, flush=True)
+
     result = None
     if rank == 0:
         # ---- per-kernel durations, HIP events on the handle's stream (separate, untimed pass) ----
@@ -327,8 +449,8 @@ def main():
 
         def pmc_entry(name):
             path = os.path.join(ROOT, "profiles", name)
-            if not (os.path.exists(path) and default_variant):
-                return None
+            if not (os.path.exists(path) and default_variant) or os.environ.get("ORBX_LIBRARY"):
+                return None          # (counters belong to the in-tree build; another .so is another kernel)
             try:
                 e = json.load(open(path)).get(args.workload, {}).get(str(B), {})
             except Exception:
@@ -349,7 +471,8 @@ def main():
                         peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
                         full_rate_share=round(full, 3), frac_lower=round(g_instr * (1 - full / 2) / VALU_PEAK_GINSTR, 4),
                         note="issue-slot occupancy of the dominant kernel: frac prices every instruction at the 4-cycle class "
-                             "(upper bound), frac_lower prices its full-rate share at 2 cycles; profiles/r02_valu_issue_rate.md")
+                             "(upper bound); frac_lower prices its full-rate share at 2 cycles, where the share is a STATIC census of "
+                             "the kernel's ISA (every instruction counted once, tools/valu_census.py), not a dynamic mix: an estimate")
         roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),
@@ -359,19 +482,35 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O      # the checker, timed as the CPU baseline; never the product path
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            sample = 24 * threads if rows * cols <= 640 * 480 else 4 * threads     # about 25 CPU-seconds of work
-            cf = synth.frames(variant, 0, min(sample, 64), rows, cols)
-            cf = np.concatenate([cf] * ((sample + len(cf) - 1) // len(cf)))[:sample]
-            sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=threads)
-            n1 = 16 if rows * cols <= 640 * 480 else 3      # the reference runs one extractor on one thread (Frame.cc:419-427)
-            sec1, _ = O.time_frames(cf[:n1], nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=1)
-            cpu = dict(value=round(sample / sec, 2), unit="frames/s", cores=os.cpu_count() or 1, threads=threads, kind="port",
-                       single_thread_value=round(n1 / sec1, 2),
-                       sample="%d %s frames %dx%d, one oracle extractor per thread, %.1f s wall (single thread: %d frames, %.1f s); "
+            # one frame per thread over ALL host cores.  A GPU box may show every core of the host (256) while its
+            # cgroup grants the job a CPU share (16 per GPU on this pool): threads beyond the share only add switching.  So the baseline is
+            # timed twice — all visible cores, and the cgroup's share (or 16) — and the better rate is the reported one; both are in `runs`.
+            ncpu = os.cpu_count() or 1
+            share = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    share = max(1, int(round(int(q) / int(per))))
+            except Exception:
+                pass
+            small = rows * cols <= 640 * 480
+            counts = [args.cpu_threads] if args.cpu_threads else sorted({ncpu, min(ncpu, share or 16)})
+            cf0 = synth.frames(variant, 0, 64 if small else 8, rows, cols)
+            runs = []
+            for th in counts:
+                smp = min(max(64, 8 * th), 1024) if small else min(max(16, 2 * th), 128)     # 10-30 s of CPU work per 16 cores
+                cf = np.concatenate([cf0] * ((smp + len(cf0) - 1) // len(cf0)))[:smp]
+                sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=th)
+                runs.append(dict(threads=th, frames=smp, seconds=round(sec, 2), fps=round(smp / sec, 2)))
+            bestrun = max(runs, key=lambda r: r["fps"])
+            n1 = 16 if small else 3      # the reference runs one extractor on one thread (Frame.cc:419-427)
+            sec1, _ = O.time_frames(cf0[:n1], nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=1)
+            cpu = dict(value=bestrun["fps"], unit="frames/s", cores=ncpu, cgroup_cpu_share=share, threads=bestrun["threads"], kind="port",
+                       single_thread_value=round(n1 / sec1, 2), runs=runs,
+                       sample="%d %s frames %dx%d, one oracle extractor per thread, %d threads, %.1f s wall (single thread: %d frames, %.1f s); "
                               "scalar C++ -O3 restatement of ORBextractor.cc + OpenCV primitives (not OpenCV's SIMD build); cores = "
-                              "host cores of the box, threads = oracle threads used"
-                              % (sample, variant, cols, rows, sec, n1, sec1))
+                              "host cores visible to the box, cgroup_cpu_share = CPUs the box's cgroup grants, threads = oracle threads of the best run"
+                              % (bestrun["frames"], variant, cols, rows, bestrun["threads"], bestrun["seconds"], n1, sec1))
         extras = {}
         if N == 1 and args.workload == "mono640" and not args.no_extras and not distributed:
             # (a) PCIe-inclusive rate (SURVEY.md §8d "end-to-end"): pinned host frames in, host arrays out, two handles used alternately
@@ -382,7 +521,7 @@ def main():
             for a in pin:
                 a[...] = frames[:Bh]
             hx[0].extract_batch_begin(pin[0]); hx[1].extract_batch_begin(pin[1]); hx[0].extract_batch_end(); hx[1].extract_batch_end()
-            reps = 16
+            reps = 64
             t1 = time.perf_counter()
             hx[0].extract_batch_begin(pin[0], lapping=wl["lapping"])
             for i in range(1, reps):
@@ -460,7 +599,8 @@ def main():
                        **({"mean_bow_matches_per_pair": round(float(d_nmb.float().mean().item()), 1)} if refkf else {}),
                        "handles_per_gpu": nH,
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "secondary": extras or None,
+            "verified": verified, "roofline": roofline, "cpu_baseline": cpu,
+            "secondary": ({**extras, **({"configs4_64_per_gpu": cfg5} if cfg5 else {})}) or None,
         }
         print(json.dumps(result), flush=True)
     if distributed:

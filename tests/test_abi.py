@@ -66,3 +66,27 @@ def test_bad_arguments_rejected_before_touching_the_gpu():
     assert L.orbx_create(ctypes.byref(h), 1000, 1.2, 8, 20, 0, 640, 480, 1, -1) == -2
     assert L.orbx_create(None, 1000, 1.2, 8, 20, 7, 640, 480, 1, -1) == -2
     assert h.value is None
+
+
+def test_a_parity_failure_describes_itself(tmp_path, monkeypatch):
+    """helpers.dump_failure: what a failing GPU comparison leaves behind (inputs, ORBX_* switches, both arrays)."""
+    import json
+    import numpy as np
+    import helpers
+    monkeypatch.setattr(helpers, "ROOT", str(tmp_path))
+    monkeypatch.setenv("ORBX_OCT_THREADS", "512")
+    helpers.LAST_INPUT.clear(); helpers.LAST_INPUT.update(images=np.zeros((4, 5), np.uint8), nfeatures=77)
+    k = np.zeros(2, helpers_keypoint_dtype()); k2 = k.copy(); k2["x"][1] = 3
+    with pytest.raises(AssertionError) as e:
+        helpers.assert_same_result((0, k, np.zeros((2, 32), np.uint8)), (0, k2, np.zeros((2, 32), np.uint8)), "case A")
+    assert "replay file" in str(e.value)
+    files = list((tmp_path / "gpurun_out").glob("fail_*.npz"))
+    assert len(files) == 1
+    z = np.load(files[0])
+    assert json.loads(str(z["orbx_env"]))["ORBX_OCT_THREADS"] == "512" and int(z["in_nfeatures"]) == 77
+    assert z["in_images"].shape == (4, 5) and z["want_keypoints"]["x"][1] == 3 and "case A" in str(z["what"])
+
+
+def helpers_keypoint_dtype():
+    import oracle_lib
+    return oracle_lib.KEYPOINT_DTYPE

@@ -8,7 +8,7 @@ import pytest
 import oracle_lib as O
 import extractorb_amd as X
 from extractorb_amd import synth
-from helpers import GOLDEN_CASES, assert_same_result, load_case, load_gray, sort_kps
+from helpers import GOLDEN_CASES, assert_same_result, fail_with_dump, load_case, load_gray, sort_kps
 
 pytestmark = pytest.mark.gpu
 
@@ -19,16 +19,31 @@ def oracle_run(img, nf=1000, lap=(0, 1000), nlevels=8, sf=1.2, ini=20, mn=7):
 
 
 def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
+    """Every stage boundary of one frame against the oracle.  The first mismatch raises with a replay file (helpers.dump_failure) that holds
+    the inputs, the ORBX_* switches and, for EVERY level, both sides' candidates and kept keypoints — not only the arrays that differed."""
+    def fail(msg):
+        both = {}
+        for l in range(nlevels):
+            both["gpu_candidates_%d" % l], both["oracle_candidates_%d" % l] = ex.debug_candidates(l, frame), o.candidates(l)
+            both["gpu_level_keys_%d" % l], both["oracle_level_keys_%d" % l] = lvl_gpu[l], o.level_keypoints(l)
+            both["gpu_pyramid_%d" % l], both["oracle_pyramid_%d" % l] = ex.image_pyramid_level(l, frame), o.level(l)
+        fail_with_dump(msg, frame=frame, quotas=o.features_per_level, **both)
+
     for l in range(nlevels):
-        assert np.array_equal(ex.image_pyramid_level(l, frame), o.level(l)), "pyramid level %d" % l
-        assert np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)), "border %d" % l
+        if not np.array_equal(ex.image_pyramid_level(l, frame), o.level(l)):
+            fail("pyramid level %d" % l)
+        if not np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)):
+            fail("border %d" % l)
         if len(o.level_keypoints(l)):      # the reference only blurs levels that hold keypoints (:1122-1127)
-            assert np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)), "blur level %d" % l
+            if not np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)):
+                fail("blur level %d" % l)
         # k_fast's per-cell segments, read segment by segment, ARE vToDistributeKeys in the reference's order (cell row,
         # cell column, then raster order inside the cell, ORBextractor.cc:797-864): compared without sorting
         cg, co = ex.debug_candidates(l, frame), o.candidates(l)
-        assert cg.tobytes() == co.tobytes(), "FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co))
-        assert lvl_gpu[l].tobytes() == o.level_keypoints(l).tobytes(), "quad-tree/orientation level %d" % l
+        if cg.tobytes() != co.tobytes():
+            fail("FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co)))
+        if lvl_gpu[l].tobytes() != o.level_keypoints(l).tobytes():
+            fail("quad-tree/orientation level %d" % l)
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
