@@ -488,9 +488,19 @@ def main():
             ncpu = os.cpu_count() or 1
             share = None
             try:
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
                 if q != "max":
                     share = max(1, int(round(int(q) / int(per))))
+            except Exception:
+                try:                                                                             # cgroup v1
+                    q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if q > 0:
+                        share = max(1, int(round(q / per)))
+                except Exception:
+                    pass
+            try:
+                share = min(share or 1 << 30, len(os.sched_getaffinity(0)))
             except Exception:
                 pass
             small = rows * cols <= 640 * 480

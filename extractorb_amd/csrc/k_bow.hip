@@ -107,7 +107,8 @@ __device__ void bitonicSort(unsigned long long* key, int n) {
 // reference's floating-point order leaves exactly one sequential piece, the norm, and that now runs on LDS values.)
 __global__ __launch_bounds__(kReduceThreads) void k_bow_reduce(const uint32_t* __restrict__ featWord, const double* __restrict__ featWeight,
                                                     const uint32_t* __restrict__ featNode, const int* __restrict__ nOut, int capacity, int Pmax,
-                                                    int scoring, int weighting, uint32_t* __restrict__ wordIds, double* __restrict__ wordWeights,
+                                                    int scoring, int weighting, uint32_t* __restrict__ wordIds,
+                                                    double* wordWeights /* beyond 8192 slots also the workgroup's wsum scratch (thread to thread): not __restrict__ */,
                                                     int* __restrict__ nWords, uint32_t* __restrict__ fvNodes, uint32_t* __restrict__ fvIdx,
                                                     int* __restrict__ nFeat) {
     constexpr int T = kReduceThreads;
@@ -202,7 +203,7 @@ void launchBow(hipStream_t st, const VocabDevice& V, const uint8_t* desc, const 
                double* featWeight, uint32_t* featNode, uint32_t* wordIds, double* wordWeights, int* nWords, uint32_t* fvNodes, uint32_t* fvIdx,
                int* nFeat, int B) {
     hipLaunchKernelGGL(k_bow_words, dim3((capacity + 15) / 16, B), dim3(256), 0, st, V, desc, nOut, capacity, levelsUp, featWord, featWeight, featNode);
-    int P = 1;
+    int P = 64;                       // the kernel never sorts fewer than 64 keys: the LDS block and the wsum offset follow the same minimum
     while (P < capacity) P <<= 1;
     hipLaunchKernelGGL(k_bow_reduce, dim3(B), dim3(kReduceThreads), (size_t)P * (P <= 8192 ? 16 : 8), st, featWord, featWeight, featNode, nOut, capacity, P, V.scoring, V.weighting,
                        wordIds, wordWeights, nWords, fvNodes, fvIdx, nFeat);

@@ -181,6 +181,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
     b += (size_t)M * sizeof(int);                   // keepIdx
     b += (size_t)R * kHistPerRoot * sizeof(int);    // hist
     b += (size_t)R * kLeaves * sizeof(unsigned);    // leafBest | cell
+    b += 9 * kOctPad;                               // (host emulation only: red zones behind the sub-arrays)
     return b + 64;
 }
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,

@@ -586,27 +586,17 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
     h->tileCap = roomy((size_t)(2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
     h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * (2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
-    // quad-tree LDS: M nodes (multiple of 8), P = next power of two for the bitonic sort
-    int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
-    M = (M + 7) / 8 * 8;
-    h->octM = M; h->octP = nextPow2(M);
-    // dense phase of the quad-tree: count pyramids for the roots of the widest level and coordinate tables for the
-    // largest rectangle; dropped (the kernel then sweeps the keys every pass) when LDS is short
-    h->octR = 1;
-    for (int l = 0; l < nlevels; l++) h->octR = mg.lv[l].nIni > h->octR ? mg.lv[l].nIni : h->octR;
-    h->octXT = ((mg.lv[0].rectW > mg.lv[0].rectH ? mg.lv[0].rectW : mg.lv[0].rectH) + 15) / 16 * 16;
-    const int denseR = h->octR <= 7 ? h->octR : 0, denseXT = h->octR <= 7 ? h->octXT : 0;
-    if (h->octR > 7 || octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) { h->octR = 0; h->octXT = 0; }
-    if (octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) > 158 * 1024) {
-        // per-level quotas in the thousands (the reference builds its initialisation extractor with 5 * nFeatures,
-        // Tracking.cc:774): the node arrays of a level no longer fit a CU's LDS; they move to an HBM arena, one slice per
-        // (frame, level) workgroup (k_octree_1024g), where size does not matter and the dense phase is available again
-        if (h->octM > 65535) { h->err = "orbx_create: more than 65535 quad-tree nodes per level"; return bail(ORBX_ERR_UNSUPPORTED); }
-        h->octR = denseR; h->octXT = denseXT;
-        h->octArenaSlice = (octreeLdsBytes(h->octM, h->octP, h->octR, h->octXT) + 255) & ~(size_t)255;
-        if ((double)h->octArenaSlice * max_batch * nlevels > 16e9) {
-            h->err = "orbx_create: quad-tree node arena for this nfeatures x max_batch exceeds 16 GB; lower max_batch";
-            return bail(ORBX_ERR_UNSUPPORTED);
+    // quad-tree node arrays: LDS, or an HBM arena when the per-level quotas run into the thousands (orbx_geometry.hpp: octreeSizing)
+    {
+        const OctSizing z = octreeSizing(mg, nlevels, octreeLdsBytes);
+        if (z.err) { h->err = std::string("orbx_create: ") + z.err; return bail(ORBX_ERR_UNSUPPORTED); }
+        h->octM = z.M; h->octP = z.P; h->octR = z.R; h->octXT = z.XT;
+        if (z.arena) {
+            h->octArenaSlice = z.arenaSlice;
+            if ((double)h->octArenaSlice * max_batch * nlevels > 16e9) {
+                h->err = "orbx_create: quad-tree node arena for this nfeatures x max_batch exceeds 16 GB; lower max_batch";
+                return bail(ORBX_ERR_UNSUPPORTED);
+            }
         }
     }
     h->outCap = mg.selPerFrame + 8 * nlevels;
@@ -1242,6 +1232,8 @@ int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int
         else if (!cnt[n]) { g_createError = "orbx_vocabulary_create: an inner node without children (the reference would treat it as a word without an id)"; return ORBX_ERR_BAD_ARGUMENT; }
     }
     if (!cnt[0]) { g_createError = "orbx_vocabulary_create: the root has no children"; return ORBX_ERR_BAD_ARGUMENT; }
+    for (int n = 0; n < n_nodes; n++)      // k_bow_words packs (distance << 8 | child rank): a node's fan-out must fit the rank byte
+        if (cnt[n] > 256) { g_createError = "orbx_vocabulary_create: a node with more than 256 children (the header's k allows at most 20)"; return ORBX_ERR_BAD_ARGUMENT; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_createError = "orbx_vocabulary_create: no HIP device (this library has no CPU path)"; return ORBX_ERR_NO_DEVICE; }
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return ORBX_ERR_HIP;

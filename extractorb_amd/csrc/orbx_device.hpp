@@ -1,5 +1,6 @@
 // orbx_device.hpp — plain-old-data shared by the host geometry code and the HIP kernels.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace orbx {
@@ -83,6 +84,18 @@ struct ChainRegion { short x0, y0, w, h; };
 struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };
 
 #ifdef __HIPCC__
+// The dynamically sized LDS block of a kernel.  (tools/octree_emu compiles k_octree.hip for the HOST to run it under sanitizers; its
+// shim defines this as a pointer to an exactly sized heap block, and ORBX_OCT_EMU_PAD > 0 puts poisoned red zones between the
+// quad-tree's LDS sub-arrays.  In the product build the pad is 0 and the macro is the HIP declaration.)
+#ifndef ORBX_DYNAMIC_LDS
+#define ORBX_DYNAMIC_LDS(name) extern __shared__ __align__(16) uint8_t name[]
+#endif
+#ifndef ORBX_OCT_EMU_PAD
+#define ORBX_OCT_EMU_PAD 0
+#define ORBX_OCT_REDZONE(ptr) do {} while (0)
+#endif
+constexpr size_t kOctPad = ORBX_OCT_EMU_PAD;
+
 // Inclusive prefix sum over the 64 lanes of a wave, every lane active: row_shr 1/2/4/8 inside the rows of 16, then lane 15 of
 // rows 0 and 2 broadcast into rows 1 and 3, lane 31 into rows 2 and 3 (DPP: six vector adds, no LDS round trip — a __shfl_up
 // ladder is six dependent ds_bpermute).  A lane with no source takes 0 (`old` of v_mov_dpp with bound_ctrl off).

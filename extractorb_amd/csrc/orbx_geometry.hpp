@@ -353,6 +353,34 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
     return std::string();
 }
 
+// Quad-tree node-array sizing of a handle (from its LARGEST geometry): M nodes (multiple of 8), P = next power of two (bitonic sort),
+// R roots / XT coordinates covered by the dense phase (0 = no dense phase), arena = the arrays exceed a CU's LDS and live in HBM
+// (per-level quotas in the thousands: the reference builds its initialisation extractor with 5 * nFeatures, Tracking.cc:774).
+// ldsBytes = octreeLdsBytes of k_octree.hip.  Shared by orbx_create and the host emulation of the kernel (tools/octree_emu).
+struct OctSizing { int M = 0, P = 0, R = 0, XT = 0; bool arena = false; size_t arenaSlice = 0; const char* err = nullptr; };
+inline OctSizing octreeSizing(const FrameGeom& mg, int nlevels, size_t (*ldsBytes)(int, int, int, int)) {
+    OctSizing z;
+    int M = mg.maxNodes + 8;   // +8: tall/narrow sub-images may add a root
+    M = (M + 7) / 8 * 8;
+    z.M = M;
+    z.P = 1;
+    while (z.P < M) z.P <<= 1;
+    // dense phase: count pyramids for the roots of the widest level and coordinate tables for the largest rectangle; dropped
+    // (the kernel then sweeps the keys every pass) when LDS is short
+    z.R = 1;
+    for (int l = 0; l < nlevels; l++) z.R = mg.lv[l].nIni > z.R ? mg.lv[l].nIni : z.R;
+    z.XT = ((mg.lv[0].rectW > mg.lv[0].rectH ? mg.lv[0].rectW : mg.lv[0].rectH) + 15) / 16 * 16;
+    const int denseR = z.R <= 7 ? z.R : 0, denseXT = z.R <= 7 ? z.XT : 0;
+    if (z.R > 7 || ldsBytes(z.M, z.P, z.R, z.XT) > 158 * 1024) { z.R = 0; z.XT = 0; }
+    if (ldsBytes(z.M, z.P, z.R, z.XT) > 158 * 1024) {
+        if (z.M > 65535) { z.err = "more than 65535 quad-tree nodes per level"; return z; }
+        z.arena = true;
+        z.R = denseR; z.XT = denseXT;
+        z.arenaSlice = (ldsBytes(z.M, z.P, z.R, z.XT) + 255) & ~(size_t)255;
+    }
+    return z;
+}
+
 // Level-major arenas: all frames of level 0, then all frames of level 1, ...
 inline void layoutArenas(FrameGeom& g, int maxBatch) {
     long long pyr = 0, blur = 0, cand = 0;

@@ -310,7 +310,8 @@ int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_fram
  *   nn_ratio = mfNNratio, th_low = ORBmatcher::TH_LOW (50), check_orientation = mbCheckOrientation
  *   d_matches[p*capacity + i]          : out, the keyframe keypoint whose MapPoint keypoint i of the frame receives, -1 = none
  *   d_n_matches[p]                     : out, the return value
- * Asynchronous on the handle's stream.  Errors: ORBX_ERR_UNSUPPORTED if 17 * capacity bytes of LDS do not fit a workgroup. */
+ * Asynchronous on the handle's stream.  Errors: ORBX_ERR_UNSUPPORTED if the tables (22 bytes per slot of the capacity rounded up to 16, + 64) do not fit a workgroup's LDS
+ * (with 64 more bytes per slot the descriptors are staged in LDS too; without them they are read from L2). */
 int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step,
                               const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags,
                               const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
