@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
-                                               BlurTail tail) {
+                                               BlurTail tail, LeafTables lt) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
     constexpr int DW = TS / 4;                        // dwords per tile row
@@ -383,6 +383,28 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
     const unsigned segCap = (unsigned)(((cw + 1) >> 1) * ((ch + 1) >> 1));
     const int th = useIni ? iniTh : minTh;
+    // Small batches: the quad-tree's first sweep is done here, by 800 waves instead of one workgroup per level (k_octree_body.inc,
+    // preCounted): every kept key adds 1 to its leaf cell of its root's 32 x 32 grid and offers (response, then smallest segment slot = first
+    // in the reference's vector) as the leaf's best key.  Both operations commute, so the order of the cells' waves does not matter.  A cell
+    // touches only a small rectangle of leaf cells (x / y path codes are monotone), so the wave first collects them in LDS (the score tile
+    // is dead by now) and sends ONE pair of L2 atomics per touched leaf instead of one per key (100 k keys per frame otherwise: the L2
+    // atomics on a few hundred hot lines cost more than the sweep they replace).
+    const bool leaf = lt.hist != nullptr && g.leafOK && f < lt.frames;      // wave-uniform
+    constexpr int kLeafCap = kScoreBytes / 8;
+    unsigned *tHist = (unsigned*)score, *tBest = tHist + kLeafCap;
+    int xc0 = 0, yc0 = 0, nxl = 1, nLeafLocal = 0;
+    const uint8_t *xcode = nullptr, *ycode = nullptr;
+    if (leaf) {
+        xcode = lt.xcode + c.level * lt.XT; ycode = lt.ycode + c.level * lt.XT;
+        const int xa = min(c.shiftX + 3, g.rectW - 1), xb = min(c.shiftX + roiW - 4, g.rectW - 1);
+        const int ya = min(c.shiftY + 3, g.rectH - 1), yb = min(c.shiftY + roiH - 4, g.rectH - 1);
+        xc0 = xcode[xa]; yc0 = ycode[ya];
+        nxl = (int)xcode[xb] - xc0 + 1;
+        const int nyl = (int)ycode[yb] - yc0 + 1;
+        nLeafLocal = nxl * nyl <= kLeafCap ? nxl * nyl : 0;      // 0: a cell over too many leaf cells (tiny leaves) goes to L2 key by key
+        for (int e = lane; e < nLeafLocal; e += 64) { tHist[e] = 0u; tBest[e] = 0u; }
+        waveLdsSync();
+    }
     for (int i0 = 0; i0 < nMin; i0 += 64) {
         const unsigned e = i0 + lane < nMin ? list[i0 + lane] : 0u;
         const int s = (int)(e >> 12), x = (int)(e & 63), y = (int)((e >> 6) & 63);
@@ -390,16 +412,45 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const unsigned at = base + __popcll(m & ((1ull << lane) - 1));
-            if (at < segCap)
-                outPos[at] = (unsigned)(c.shiftX + x + 3) | ((unsigned)(c.shiftY + y + 3) << 12) | ((unsigned)(s - 1) << 24);   // response = S - 1
+            if (at < segCap) {
+                const unsigned kx = (unsigned)(c.shiftX + x + 3), ky = (unsigned)(c.shiftY + y + 3);
+                const unsigned w = kx | (ky << 12) | ((unsigned)(s - 1) << 24);   // response = S - 1
+                outPos[at] = w;
+                if (leaf) {
+                    const int xc = xcode[min((int)kx, g.rectW - 1)], yc = ycode[min((int)ky, g.rectH - 1)];
+                    const unsigned val = (w & 0xff000000u) | (0xffffffu - ((unsigned)c.segOff + at));
+                    if (nLeafLocal) {
+                        const int li = (yc - yc0) * nxl + (xc - xc0);
+                        atomicAdd(&tHist[li], 1u);
+                        atomicMax(&tBest[li], val);
+                    } else {
+                        const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                        atomicAdd(lt.hist + cellOfRoot, 1);
+                        atomicMax(lt.best + cellOfRoot, val);
+                    }
+                }
+            }
         }
         base += __popcll(m);
+    }
+    if (nLeafLocal) {
+        waveLdsSync();
+        for (int e = lane; e < nLeafLocal; e += 64) {
+            const unsigned n = tHist[e];
+            if (n) {
+                const int xc = xc0 + e % nxl, yc = yc0 + e / nxl;
+                const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                atomicAdd(lt.hist + cellOfRoot, (int)n);
+                atomicMax(lt.best + cellOfRoot, tBest[e]);
+            }
+        }
     }
 }
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
-                bool prefilter, int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur) {
+                bool prefilter, int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur,
+                LeafTables lt) {
     const int fastChunks = (nCells + kFastWaves - 1) / kFastWaves;
     const dim3 block(256);
     BlurTail tail{blurItems, blurLaneItem, blurLanes, blur, fastChunks};
@@ -407,17 +458,17 @@ void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGe
     if (maxRoiW <= 45 && maxRoiH <= 45) {
         if (blurItems) {      // small batch: the blur's lanes ride in the same launch
             const dim3 grid = xcdGrid(fastChunks + (blurLanes + 255) / 256, B);
-            if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
-            else hipLaunchKernelGGL((k_fast<48, 45, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+            if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+            else hipLaunchKernelGGL((k_fast<48, 45, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
             return;
         }
         const dim3 grid = xcdGrid(fastChunks, B);
-        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
-        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
     } else {   // cells up to 63 px (the geometry code rejects larger ones)
         const dim3 grid = xcdGrid(fastChunks, B);
-        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
-        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail);
+        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
     }
 }
 bool fastCanCarryBlur(int maxRoiW, int maxRoiH) { return maxRoiW <= 45 && maxRoiH <= 45; }

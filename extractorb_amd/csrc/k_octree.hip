@@ -47,26 +47,16 @@ constexpr int kOctUnroll = 4;   // keys per thread per sweep iteration (memory-l
 // child counts are table look-ups.  The keys are visited again only to take the final arg-max (node found through
 // a leaf-cell -> node table), or — when a node at depth kD0 must split — once to materialise their node ids,
 // after which the passes continue with one rename+count sweep each.
-constexpr int kD0 = 5;
-constexpr int kLeaves = 1 << (2 * kD0);                       // 1024 leaf cells per root
+constexpr int kD0 = kOctDepth;
+constexpr int kLeaves = kOctLeaves;                           // 1024 leaf cells per root
 constexpr int kHistPerRoot = (4 * kLeaves - 4) / 3;           // 4 + 16 + ... + 4^kD0 = 1364 counters per root
 __device__ __forceinline__ int histOff(int depth) { return ((1 << (2 * depth)) - 4) / 3; }   // depth 1..kD0
 // node descriptor in the dense phase: root << 24 | depth << 20 | ypath << 10 | xpath  (paths hold `depth` bits)
 __device__ __forceinline__ unsigned nodeKey(int root, int depth, int yp, int xp) {
     return ((unsigned)root << 24) | ((unsigned)depth << 20) | ((unsigned)yp << 10) | (unsigned)xp;
 }
-// left/right (or up/down) decisions of DivideNode along one axis for coordinate v in the box [b0, b1)
-__device__ __forceinline__ int axisPath(int v, int b0, int b1) {
-    int path = 0;
-#pragma unroll
-    for (int d = 0; d < kD0; d++) {
-        const int c = b0 + ((b1 - b0 + 1) >> 1);    // UL + ceil(extent/2)  (:488-489)
-        const int bit = v < c ? 0 : 1;               // kp.pt.x < n1.UR.x  (:520)
-        path = 2 * path + bit;
-        if (bit) b0 = c; else b1 = c;
-    }
-    return path;
-}
+// left/right (or up/down) decisions of DivideNode along one axis for coordinate v in the box [b0, b1): orbx_device.hpp
+__device__ __forceinline__ int axisPath(int v, int b0, int b1) { return octAxisPath(v, b0, b1); }
 
 __device__ __forceinline__ int quadrantOf(int x, int y, short4 b /* x0,x1,y0,y1 */) {
     const int cx = b.x + ((b.y - b.x + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)   (:488)
@@ -187,12 +177,12 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
                   const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
                   unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
-                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B, uint8_t* nodeArena) {
+                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B, uint8_t* nodeArena, LeafTables lt) {
     const size_t bytes = octreeLdsBytes(M, P, R, XT);
     if (nodeArena) {      // node arrays in HBM: one launch, 1024 threads per (frame, level)
         hipLaunchKernelGGL(k_octree_1024g, dim3(B, nlevels), dim3(1024), 0, st, lv, nlevels, cells, nCellsTotal, candSeg, cellCount,
                            cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT, 0, f0,
-                           nodeArena, (unsigned long long)((bytes + 255) & ~(size_t)255));
+                           nodeArena, (unsigned long long)((bytes + 255) & ~(size_t)255), lt);
         return;
     }
     // consecutive levels with the same workgroup size share a launch; the smallest levels (many short workgroups) go
@@ -206,7 +196,7 @@ void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDe
                           : (T == 256 ? k_octree_256 : (T == 512 ? k_octree_512 : k_octree_1024));
         hipLaunchKernelGGL(kern, dim3(B, hi - lo), dim3(T), bytes, st, lv, nlevels, cells, nCellsTotal,
                            candSeg, cellCount, cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap,
-                           lapArea, M, P, R, XT, lo, f0, (uint8_t*)nullptr, 0ull);
+                           lapArea, M, P, R, XT, lo, f0, (uint8_t*)nullptr, 0ull, lt);
         hi = lo;
     }
 }

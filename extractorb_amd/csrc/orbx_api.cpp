@@ -28,11 +28,11 @@ void launchLdsPollute(hipStream_t, int, int, unsigned*);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*);
+                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables);
 bool fastCanCarryBlur(int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*);
+                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*, LeafTables);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int, int);
 hipError_t uploadUmax(const int* umax16);
@@ -144,6 +144,12 @@ struct orbx_handle {
     size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
     uint8_t* d_octArena = nullptr;
     int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
+    // small batches: per-(frame, level, root) leaf counters / best keys filled by k_fast's emit, consumed and cleared by k_octree
+    // (orbx_device.hpp: LeafTables); d_leafCode = [2][nlevels][octXT] host-built x / y path codes of the current geometry
+    int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 8; 0 = off)
+    int* d_leafHist = nullptr;
+    unsigned* d_leafBest = nullptr;
+    uint8_t* d_leafCode = nullptr;
     // outputs of the host path
     int outCap = 0;
     Keypoint *d_outK = nullptr, *d_outLevelK = nullptr;
@@ -219,7 +225,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
-                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
+                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->statEvent) (void)hipEventDestroy(h->statEvent);
@@ -257,6 +263,17 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
         xo += g.rx[l].size(); yo += g.ry[l].size();
+    }
+    if (h->leafFrames) {      // x / y path codes of every level the quad-tree's dense phase covers (k_octree_body.inc: `dense`)
+        std::vector<uint8_t> code((size_t)2 * g.nlevels * h->octXT, 0);
+        for (int l = 0; l < g.nlevels; l++) {
+            LevelGeom& L = g.lv[l];
+            L.leafOK = L.nIni <= h->octR && L.rectW <= h->octXT && L.rectH <= h->octXT ? 1 : 0;
+            if (!L.leafOK) continue;
+            for (int x = 0; x < L.rectW; x++) code[(size_t)l * h->octXT + x] = (uint8_t)octXCode(x, L.hX, L.nIni);
+            for (int y = 0; y < L.rectH; y++) code[(size_t)(g.nlevels + l) * h->octXT + y] = (uint8_t)octAxisPath(y, 0, L.rectH);
+        }
+        HIP_TRY(h, hipMemcpy(h->d_leafCode, code.data(), code.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
@@ -417,13 +434,17 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) {
+        // small batches: k_fast's emit does the quad-tree's first sweep (leaf counters and best keys in L2); k_octree loads and clears them
+        LeafTables lt{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+        if (h->leafFrames && f0 + Bn <= h->leafFrames)
+            lt = LeafTables{h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_leafCode + (size_t)g.nlevels * h->octXT, h->octR, h->octXT, g.nlevels, h->leafFrames};
         {
             Prof p(h, S_FAST, st);
             const bool carry = blurRidesWithFast(Bn);
             pollute(st);
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
-                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur);
+                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt);
         }
         {
             Prof p(h, S_OCTREE, st);
@@ -438,7 +459,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena);
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
         }
         {
             Prof p(h, S_DESCRIBE, st);
@@ -625,6 +646,17 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_sink, 64);
     CREATE_ALLOC(h->d_sel, h->selEntries * sizeof(uint2));
     if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
+    h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 8;
+    if (h->leafFrames > max_batch) h->leafFrames = max_batch;
+    if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree
+    if (h->leafFrames) {
+        const size_t n = (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves;
+        CREATE_ALLOC(h->d_leafHist, n * sizeof(int));
+        CREATE_ALLOC(h->d_leafBest, n * sizeof(unsigned));
+        CREATE_TRY(hipMemset(h->d_leafHist, 0, n * sizeof(int)));          // the tables are zero between calls (also under ORBX_POISON)
+        CREATE_TRY(hipMemset(h->d_leafBest, 0, n * sizeof(unsigned)));
+        CREATE_ALLOC(h->d_leafCode, (size_t)2 * nlevels * h->octXT);
+    }
     CREATE_ALLOC(h->d_levelCount, sizeof(int) * max_batch * nlevels);
     CREATE_ALLOC(h->d_levelLap, sizeof(int) * max_batch * nlevels);
     CREATE_ALLOC(h->d_lap, sizeof(int) * 2 * max_batch);

@@ -46,6 +46,7 @@ struct LevelGeom {
     int patchSize;            // keypoint size written to the output
     int cellFirst, cellCount; // this level's cells inside the per-frame cell table
     int rxOff, ryOff;         // this level's resize coefficient records inside the handle's x / y tables (level >= 1)
+    int leafOK;               // 1: the quad-tree's dense phase covers this level, so in small batches k_fast may histogram its keys (LeafTables)
 };
 
 struct CellDesc {             // one FAST cell == one cv::FAST call of the reference (ORBextractor.cc:818-819)
@@ -58,6 +59,44 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
     int segOff;               // first slot of this cell's candidate segment inside the level's per-frame arena
 };
 static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
+
+// ---- quad-tree dense phase: leaf grid of a root (k_octree.hip) -------------------------------------------------------------------
+// DivideNode's boxes depend only on the root box, and its x and y decisions are independent, so a key's quadrant path of length
+// kOctDepth below its root is two table look-ups.  Shared by the kernels (k_octree builds the tables in LDS; k_fast reads the host-built
+// copies in small batches) and the host.
+constexpr int kOctDepth = 5;
+constexpr int kOctLeaves = 1 << (2 * kOctDepth);      // 1024 leaf cells per root
+#ifdef __HIPCC__
+#define ORBX_HD __host__ __device__
+#else
+#define ORBX_HD
+#endif
+// left/right (or up/down) decisions of DivideNode along one axis for coordinate v in the box [b0, b1)
+ORBX_HD inline int octAxisPath(int v, int b0, int b1) {
+    int path = 0;
+    for (int d = 0; d < kOctDepth; d++) {
+        const int c = b0 + ((b1 - b0 + 1) >> 1);    // UL + ceil(extent/2)  (ORBextractor.cc:488-489)
+        const int bit = v < c ? 0 : 1;               // kp.pt.x < n1.UR.x  (:520)
+        path = 2 * path + bit;
+        if (bit) b0 = c; else b1 = c;
+    }
+    return path;
+}
+// root << kOctDepth | x path of rectangle column x (vpIniNodes[kp.pt.x / hX], :574; IEEE single division on host and device alike)
+ORBX_HD inline int octXCode(int x, float hX, int nIni) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r = (int)__fdiv_rn((float)x, hX);
+#else
+    int r = (int)((float)x / hX);
+#endif
+    r = r > nIni - 1 ? nIni - 1 : r;
+    return (r << kOctDepth) | octAxisPath(x, (int)(hX * (float)r), (int)(hX * (float)(r + 1)));
+}
+// Small batches (one (frame, level) quad-tree problem per CU cannot hide its first sweep over ~60 k keys): k_fast's emit adds every kept key
+// to its leaf's counter and best key in these L2-resident tables, and k_octree starts from them instead of sweeping the segments.
+//   hist / best : [frame][level][R][kOctLeaves]   (zero between calls: k_octree clears what it loads)
+//   xcode / ycode : [level][XT] host-built octXCode / octAxisPath of every rectangle column / row
+struct LeafTables { int* hist; unsigned* best; const uint8_t* xcode; const uint8_t* ycode; int R, XT, nlevels, frames; };
 
 constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (plus a 6-row halo)
 #ifndef ORBX_BLUR_SMALL_ROWS

@@ -46,11 +46,11 @@ CASES = {
 }
 
 
-def run(bins, kind, img, nf, nlevels, sf, T, roomy, poison, tmp_path, lap=(0, 1000)):
+def run(bins, kind, img, nf, nlevels, sf, T, roomy, poison, tmp_path, lap=(0, 1000), leaf_tables=False):
     o = O.Oracle(nf, sf, nlevels, 20, 7)
     o.extract(img, lap)
     case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
-    E.write_case(case, o, img.shape[0], img.shape[1], nf, sf, nlevels, T, roomy, lap, poison)
+    E.write_case(case, o, img.shape[0], img.shape[1], nf, sf, nlevels, T, roomy, lap, poison, leaf_tables=leaf_tables)
     rc, err = E.run_case(bins[kind], case, out, timeout=600, env={"ASAN_OPTIONS": "detect_leaks=0", "TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0"})
     return o, rc, err, (E.read_result(out, nlevels) if rc in (0, 66) else None)
 
@@ -62,6 +62,17 @@ def test_kernel_source_on_the_host_under_asan_ubsan(bins, name, T, roomy, tmp_pa
     o, rc, err, res = run(bins, "asan", img, nf, nlevels, sf, T, roomy, 0xA5, tmp_path)
     assert rc == 0, err[-3000:]                                   # any sanitizer report ends the run with a non-zero code
     assert E.check(o, nlevels, (0, 1000), res) == []
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_small_batch_form_starting_from_the_leaf_tables(bins, name, tmp_path):
+    """Small batches: k_fast's emit leaves per-leaf counters and best keys in L2 (LeafTables) and the kernel starts from them instead of
+    sweeping the segments; the emulator builds the same tables on the host.  Same lists, tables cleared afterwards, no sanitizer report."""
+    img, nf, nlevels, sf = CASES[name]()
+    for kind, T, roomy in (("asan", 512, 1), ("asan", 1024, 1), ("tsan", 256, 1)):
+        o, rc, err, res = run(bins, kind, img, nf, nlevels, sf, T, roomy, 0xA5, tmp_path, leaf_tables=True)
+        assert rc == 0, err[-3000:]
+        assert E.check(o, nlevels, (0, 1000), res) == []
 
 
 @pytest.mark.parametrize("name", ["sparse_517x333", "clustered_400x300"])

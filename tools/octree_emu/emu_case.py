@@ -15,11 +15,12 @@ def build(kinds=("plain", "asan", "tsan")):
     return {k: os.path.join(BUILD, "emu_%s" % k) for k in kinds}
 
 
-def write_case(path, oracle, rows, cols, nfeatures, scale, nlevels, threads, roomy, lapping=(0, 1000), poison=0xA5, max_rows=None, max_cols=None):
+def write_case(path, oracle, rows, cols, nfeatures, scale, nlevels, threads, roomy, lapping=(0, 1000), poison=0xA5, max_rows=None, max_cols=None,
+               leaf_tables=False):
     """`oracle`: an oracle_lib.Oracle that has just extracted the image."""
     with open(path, "wb") as f:
         f.write(struct.pack("<12if3i", 0x4f435445, nfeatures, nlevels, rows, cols, max_rows or rows, max_cols or cols, threads, int(roomy),
-                            int(lapping[0]), int(lapping[1]), poison, scale, 0, 0, 0))
+                            int(lapping[0]), int(lapping[1]), poison, scale, int(leaf_tables), 0, 0))
         for l in range(nlevels):
             c = oracle.candidates(l)
             w = (c["x"].astype(np.uint32) | (c["y"].astype(np.uint32) << 12) | (c["response"].astype(np.uint32) << 24)).astype("<u4")

@@ -156,12 +156,45 @@ int main(int argc, char** argv) {
     }
     fclose(fi);
 
+    // reserved[0] != 0: the small-batch form — the leaf counters / best keys k_fast's emit would have left in L2 (orbx_device.hpp:
+    // LeafTables), built here from the same segments with the host-side code tables of installGeometry
+    LeafTables lt{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    Exact<int> leafHist(H.reserved[0] ? (size_t)H.nlevels * (size_t)z.R * kOctLeaves : 0);
+    Exact<unsigned> leafBest(H.reserved[0] ? (size_t)H.nlevels * (size_t)z.R * kOctLeaves : 0);
+    Exact<uint8_t> leafCode(H.reserved[0] ? (size_t)2 * H.nlevels * (size_t)z.XT : 0);
+    if (H.reserved[0] && z.R > 0 && !z.arena) {
+        memset(leafHist.p, 0, leafHist.n * sizeof(int));
+        memset(leafBest.p, 0, leafBest.n * sizeof(unsigned));
+        for (int l = 0; l < H.nlevels; l++) {
+            LevelGeom& L = lv.p[l];
+            L.leafOK = L.nIni <= z.R && L.rectW <= z.XT && L.rectH <= z.XT ? 1 : 0;
+            if (!L.leafOK) continue;
+            uint8_t *xc = leafCode.p + (size_t)l * z.XT, *yc = leafCode.p + (size_t)(H.nlevels + l) * z.XT;
+            for (int x = 0; x < L.rectW; x++) xc[x] = (uint8_t)octXCode(x, L.hX, L.nIni);
+            for (int y = 0; y < L.rectH; y++) yc[y] = (uint8_t)octAxisPath(y, 0, L.rectH);
+            for (int c = 0; c < L.cellCount; c++) {
+                const CellDesc& cd = g.cells[(size_t)(L.cellFirst + c)];
+                for (unsigned k = 0; k < cellCount.p[(size_t)(L.cellFirst + c)]; k++) {
+                    const unsigned slot = (unsigned)cd.segOff + k, w = candSeg.p[(size_t)L.candOff + slot];
+                    const unsigned x = w & 0xfff, y = (w >> 12) & 0xfff;
+                    const unsigned cx = xc[std::min((int)x, L.rectW - 1)], cy = yc[std::min((int)y, L.rectH - 1)];
+                    const size_t at = ((size_t)l * z.R + (cx >> kOctDepth)) * kOctLeaves + ((cy << kOctDepth) | (cx & ((1u << kOctDepth) - 1u)));
+                    leafHist.p[at]++;
+                    leafBest.p[at] = std::max(leafBest.p[at], (w & 0xff000000u) | (0xffffffu - slot));
+                }
+            }
+        }
+        lt = LeafTables{leafHist.p, leafBest.p, leafCode.p, leafCode.p + (size_t)H.nlevels * z.XT, z.R, z.XT, H.nlevels, 1};
+    }
     int threadsOfLevel[kMaxLevels];
     for (int l = 0; l < H.nlevels; l++) threadsOfLevel[l] = H.threads;
     Exact<uint8_t> arena(z.arena ? z.arenaSlice * (size_t)H.nlevels : 0);
     launchOctree(nullptr, lv.p, H.nlevels, cells.p, nCells, candSeg.p, cellCount.p, cellOff.p, candPos.p, candCount.p, nodeOf.p, sel.p,
                  g.selPerFrame, levelCount.p, levelLap.p, lapArea.p, z.M, z.P, z.R, z.XT, threadsOfLevel, H.roomy != 0, 0, 1,
-                 z.arena ? arena.p : nullptr);
+                 z.arena ? arena.p : nullptr, lt);
+    if (lt.hist)      // the kernel clears what it loads: the tables are zero again for the next call
+        for (size_t i = 0; i < leafHist.n; i++)
+            if (leafHist.p[i] != 0 || leafBest.p[i] != 0) { fprintf(stderr, "leaf table entry %zu not cleared\n", i); return 4; }
 
 #ifdef ORBX_OCT_TRACE
     if (argc > 3) {      // (investigation builds only: the per-pass node lists of one level, written by a patched kernel copy)
