@@ -327,8 +327,12 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
     if constexpr (FROM_IMAGE) {
         if (level == 0) {      // bordered level 0 = the caller's image with a 19-px REFLECT_101 frame (:1213-1215), one dword per thread
-            const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col, row = ct.tileY * kChainTileRows + (tid >> 4);
-            if (tid < kChainTileDw * kChainTileRows && dw < nd && row < d.pyrRows) {
+            const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col;
+            static_assert(kChainTile0Rows % (kChainThreads / kChainTileDw) == 0, "level-0 tile rows per pass");
+#pragma unroll
+            for (int rr = 0; rr < kChainTile0Rows; rr += kChainThreads / kChainTileDw) {      // all of a thread's loads in flight together
+                const int row = ct.tileY * kChainTile0Rows + rr + (tid >> 4);
+                if (dw < nd && row < d.pyrRows) {
                 const int bc0 = 4 * dw, x0 = bc0 - kPadL;       // interior x of the dword's first byte (a multiple of 4)
                 const uint8_t* srow = img.p + (long long)f * img.frame + (long long)reflect101(row - kEdge, d.h) * img.stride;
                 unsigned o;
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
                     }
                 }
                 *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + bc0) = o;
+                }
             }
             return;
         }

@@ -187,6 +187,7 @@ struct orbx_handle {
     bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
+    unsigned statCalls = 0;
     int statB = 0;
     // ComputeBoW scratch (allocated on first use): per-feature word id / weight / node
     size_t bowEntries = 0;
@@ -493,7 +494,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         front(h->aux, B0, B - B0);
         back(h->aux, B0, B - B0);
     }
-    if (h->fastMode < 0 && !h->statPending) {   // statistics for the next batches' kernel choice; nobody waits for this copy
+    // statistics for the next batches' kernel choice; nobody waits for this copy.  Once a density is known the stream is sampled every 32nd
+    // call only: the copy is a 4-us blit kernel on the stream, 7 % of a single-frame call
+    if (h->fastMode < 0 && !h->statPending && (h->candDensity < 0.f || (h->statCalls++ & 31) == 0)) {
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipEventRecord(h->statEvent, st));
         h->statPending = true;

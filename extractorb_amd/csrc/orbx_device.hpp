@@ -118,6 +118,8 @@ struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) an
 // rectangle of level j's interior the tile needs: x0 (a multiple of 4 for j = 1), y0, width, height.
 constexpr int kChainTileDw = 16;     // dword columns per tile
 constexpr int kChainTileRows = 16;
+constexpr int kChainTile0Rows = 64;  // rows of a LEVEL-0 tile of the one-launch pyramid: a bordered copy needs no LDS staging, and 363 sixteen-row
+                                     // workgroups pushed the grid (1261) past the 1024 that fit the chip at once; 99 tall ones keep it in one round
 constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainMaxH0 = 96, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
 struct ChainRegion { short x0, y0, w, h; };
 struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };

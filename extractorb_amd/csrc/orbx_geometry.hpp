@@ -284,7 +284,8 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
             for (int l = t.nlevels - 1; l >= start; l--) {      // coarsest level first: its tiles have the longest chains and should start first
                 const LevelGeom& L = g.lv[l];
                 const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
-                const int tx = (nd + kChainTileDw - 1) / kChainTileDw, ty = (L.pyrRows + kChainTileRows - 1) / kChainTileRows;
+                const int tileRows = (l == 0) ? kChainTile0Rows : kChainTileRows;      // (level-0 tiles exist only in the from-image list)
+                const int tx = (nd + kChainTileDw - 1) / kChainTileDw, ty = (L.pyrRows + tileRows - 1) / tileRows;
                 if (l == start && start != 0) break;            // (the loaded level itself is written by k_pyr_first)
                 for (int iy = 0; iy < ty; iy++)
                     for (int ix = 0; ix < tx; ix++) {
@@ -298,7 +299,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                             const int v = refl(bx - kEdge, L.w);
                             x0 = std::min(x0, v); x1 = std::max(x1, v);
                         }
-                        for (int r = iy * kChainTileRows; r < (iy + 1) * kChainTileRows; r++) {
+                        for (int r = iy * tileRows; r < (iy + 1) * tileRows; r++) {
                             const int br = r < L.pyrRows ? r : L.pyrRows - 1;
                             const int v = refl(br - kEdge, L.h);
                             y0 = std::min(y0, v); y1 = std::max(y1, v);

@@ -90,6 +90,10 @@ inline int __shfl_up(int v, unsigned delta) {      // a lane with no source keep
     return lane >= (int)delta ? (int)(unsigned)emu::peek(s, lane - (int)delta) : v;
 }
 inline unsigned __shfl_up(unsigned v, unsigned delta) { return (unsigned)__shfl_up((int)v, delta); }
+inline int __shfl_xor(int v, int laneMask) {
+    const unsigned long long* s = emu::exchange((unsigned)v);
+    return (int)(unsigned)emu::peek(s, ((int)threadIdx.x & 63) ^ (laneMask & 63));
+}
 inline int emu_readlane(int v, int lane) { return __shfl(v, lane); }
 #define __builtin_amdgcn_readlane emu_readlane
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

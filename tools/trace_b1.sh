@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # take a window in the middle of the timed region: find sequences starting with k_pyr_first
 names = [r["Kernel_Name"].split("(")[0].replace("orbx::","").replace("void ","").split("<")[0] for r in rows]
-starts = [i for i, n in enumerate(names) if n.startswith("k_pyr_first")]
+starts = [i + 1 for i, n in enumerate(names[:-1]) if n.startswith("k_describe")]      # a call's first kernel follows the previous call's last
 i0 = starts[len(starts)//2]
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end = None
