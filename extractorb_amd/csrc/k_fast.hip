@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     {
         // wave-uniform base + 32-bit lane offsets; rows / dword columns past the ROI are clamped, not predicated (their
         // tile bytes are never read by an interior pixel)
-        const uint8_t* sp = pyr + g.pyrOff + (long long)f * g.pyrFrameBytes + (long long)(kEdge + c.y0) * g.pyrStride + (gx1 - gsh);
+        const uint8_t* sp = pyr + c.pyrOff + (long long)f * c.pyrFrameBytes + (long long)(kEdge + c.y0) * c.pyrStride + (gx1 - gsh);
         const int dcol = lane & (LPR - 1), rsub = lane / LPR;
         const unsigned colOff = 4u * (unsigned)min(dcol, (gsh + roiW) >> 2);    // last dword holding a needed byte
-        const unsigned off0 = (unsigned)__mul24(rsub, g.pyrStride) + colOff, offMax = (unsigned)__mul24(roiH - 1, g.pyrStride) + colOff;
-        const unsigned stepOff = (unsigned)(RPI * g.pyrStride);
+        const unsigned off0 = (unsigned)__mul24(rsub, c.pyrStride) + colOff, offMax = (unsigned)__mul24(roiH - 1, c.pyrStride) + colOff;
+        const unsigned stepOff = (unsigned)(RPI * c.pyrStride);
         unsigned w[STEPS];
 #pragma unroll
         for (int s = 0; s < STEPS; s++)

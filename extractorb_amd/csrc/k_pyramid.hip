@@ -323,8 +323,8 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     const ChainTile& ct = tiles[t];
     const int level = ct.level;
     uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // region j lives in buf[j & 1]
-    const LevelGeom d = lv[level];
-    const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
+    struct { int w, h, pyrRows, pyrStride; long long pyrOff, pyrFrameBytes; } d{ct.w, ct.h, ct.pyrRows, ct.pyrStride, ct.pyrOff, ct.pyrFrameBytes};
+    const int nd = (kPadL - kEdge + d.w + 2 * kEdge + 3) / 4, wB = d.w + 2 * kEdge;      // dwords of a bordered row (rowDwords)
     if constexpr (FROM_IMAGE) {
         if (level == 0) {      // bordered level 0 = the caller's image with a 19-px REFLECT_101 frame (:1213-1215), one dword per thread
             const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col;
@@ -352,11 +352,19 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
             return;
         }
     }
+    // the first eight steps' rectangles and table offsets are read with STATIC indices, i.e. as one batch of wave-uniform loads issued
+    // together (and here, ahead of the region's address arithmetic); indexed by a running j, every step waited for its own load (7 steps
+    // x one L2 round trip)
+    constexpr int kStatic = 8;
+    ChainRegion rj[kStatic + 1];
+    int xo[kStatic + 1], yo[kStatic + 1];
+#pragma unroll
+    for (int j = kStart; j <= kStatic; j++) { rj[j] = ct.region[j]; xo[j] = ct.rxOff[j]; yo[j] = ct.ryOff[j]; }
     // ---- every load of the tile is issued up front: the first region (aligned dwords of level 1's bordered buffer, or of the
     //      caller's image) and the coefficient records of ALL steps (x records of step j at coef[xo_j ..], y records behind them):
     //      fetched step by step, each step would start with an L2 round trip ----
     {
-        const ChainRegion r = ct.region[kStart];
+        const ChainRegion r = rj[kStart];
         const int nDw = r.w >> 2, total = nDw * r.h;
         const uint8_t* src;
         int srcStride;
@@ -364,11 +372,11 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
             src = img.p + (long long)f * img.frame + (long long)r.y0 * img.stride + r.x0;
             srcStride = img.stride;
         } else {
-            const LevelGeom g1 = lv[1];
-            src = pyr + g1.pyrOff + (long long)f * g1.pyrFrameBytes + (long long)(kEdge + r.y0) * g1.pyrStride + kPadL + r.x0;
-            srcStride = g1.pyrStride;
+            src = pyr + ct.srcOff + (long long)f * ct.srcFrameBytes + (long long)(kEdge + r.y0) * ct.srcStride + kPadL + r.x0;
+            srcStride = ct.srcStride;
         }
         unsigned* dst = (unsigned*)buf[kStart & 1];
+        CSTAMP(20);
         // the region's dwords are dealt flat (dword i of the region = row i / nDw, column i % nDw; the LDS copy is contiguous in i)
         constexpr int kLoads = ((FROM_IMAGE ? kChainMaxH0 : kChainMaxH) * kChainMaxW / 4 + kChainThreads - 1) / kChainThreads;
         const float inv = __frcp_rn((float)nDw);
@@ -392,30 +400,49 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
         // coefficient records: the steps' records form one flat list (x records of step j, then its y records, step after step;
         // step `level` is the tile itself); a thread fetches entries tid, tid + T, ... — all loads are issued before the first
         // result is stored, whichever step an entry belongs to
+        CSTAMP(21);
         constexpr int kPerThread = (kChainCoefMax + kChainThreads - 1) / kChainThreads;
-        ResizeX cv[kPerThread];
+        // which record a thread's slot holds is settled in registers first (a walk over the <= 7 steps with wave-uniform bounds: selects,
+        // no memory), THEN every slot issues its one load: a conditional load per step and slot serialised the steps' memory round trips
+        // (a level-7 tile: 2.1 us before its region could be stored)
+        int sel[kPerThread];                                 // element of rxAll (>= 0) or ~element of ryAll (< 0); INT_MIN: no record
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) sel[k] = (int)0x80000000;
         int off = 0;
-        for (int j = kStart + 1; j <= level; j++) {         // thread-uniform walk over the steps
-            const int nx = j < level ? ct.region[j].w : 4 * kChainTileDw, ny = j < level ? ct.region[j].h : kChainTileRows;
-            const int rx0 = j < level ? ct.region[j].x0 : 0, ry0 = j < level ? ct.region[j].y0 : 0;
-            const ResizeX *xt = rxAll + lv[j].rxOff, *yt = ryAll + lv[j].ryOff;
+        auto walk = [&](int j, const ChainRegion rj, int xo, int yo) {
+            const int nx = j < level ? rj.w : 4 * kChainTileDw, ny = j < level ? rj.h : kChainTileRows;
+            const int rx0 = j < level ? rj.x0 : 0, ry0 = j < level ? rj.y0 : 0;
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) {
                 const int i = tid + k * kChainThreads - off;
                 if (i >= 0 && i < nx + ny) {
-                    if (j < level) cv[k] = i < nx ? xt[rx0 + i] : yt[ry0 + i - nx];
+                    if (j < level) sel[k] = i < nx ? xo + rx0 + i : ~(yo + ry0 + i - nx);
                     else if (i < nx) {
                         int bx = 4 * ct.tileX * kChainTileDw + i - (kPadL - kEdge);
                         bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);            // bytes of a dword outside the bordered row are padding
-                        cv[k] = xt[reflect101(bx - kEdge, d.w)];
-                    } else cv[k] = yt[reflect101(min(ct.tileY * kChainTileRows + i - nx, d.pyrRows - 1) - kEdge, d.h)];
+                        sel[k] = xo + reflect101(bx - kEdge, d.w);
+                    } else sel[k] = ~(yo + reflect101(min(ct.tileY * kChainTileRows + i - nx, d.pyrRows - 1) - kEdge, d.h));
                 }
             }
             off += nx + ny;
+        };
+        {
+#pragma unroll
+            for (int j = kStart + 1; j <= kStatic; j++)
+                if (j <= level) walk(j, rj[j], xo[j], yo[j]);            // wave-uniform
+            for (int j = kStatic + 1; j <= level; j++) walk(j, ct.region[j], ct.rxOff[j], ct.ryOff[j]);      // (more than nine levels)
         }
+        ResizeX cv[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            const ResizeX* q = sel[k] >= 0 ? rxAll + sel[k] : ryAll + ~sel[k];
+            cv[k] = sel[k] != (int)0x80000000 ? *q : ResizeX{0, 0, 0, 0};
+        }
+        CSTAMP(22);
 #pragma unroll
         for (int k = 0; k < kPerThread; k++)
             if (tid + k * kChainThreads < off) coef[tid + k * kChainThreads] = cv[k];
+        CSTAMP(23);
 #pragma unroll
         for (int i = 0; i < kLoads; i++)
             if (tid + i * kChainThreads < total) dst[tid + i * kChainThreads] = w[i];
@@ -424,8 +451,9 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     CSTAMP(1);
     // ---- the levels in between: interior pixels only ----
     int off = 0;
+    ChainRegion rs = ct.region[kStart], rd = ct.region[kStart + 1 < kMaxLevels ? kStart + 1 : kStart];
     for (int j = kStart + 1; j < level; j++) {
-        const ChainRegion rs = ct.region[j - 1], rd = ct.region[j];
+        const ChainRegion rnext = ct.region[j + 1 < kMaxLevels ? j + 1 : j];      // requested a step ahead: no wait at the top of the next step
         const int ss = (rs.w + 3) & ~3, ds = (rd.w + 3) & ~3;
         const uint8_t* S = buf[(j - 1) & 1];
         uint8_t* D = buf[j & 1];
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
         }
         }
         off += rd.w + rd.h;
+        rs = rd; rd = rnext;
         __syncthreads();
         CSTAMP(j);
     }

@@ -285,6 +285,14 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
         fo += g.foot[l].size();
     }
+    for (std::vector<ChainTile>* list : {&g.chain, &g.chainAll})      // the tiles carry what they need of the level tables (orbx_device.hpp: ChainTile)
+        for (ChainTile& c : *list) {
+            const LevelGeom& L = g.lv[c.level];
+            c.w = L.w; c.h = L.h; c.pyrRows = L.pyrRows; c.pyrStride = L.pyrStride; c.pyrOff = L.pyrOff; c.pyrFrameBytes = L.pyrFrameBytes;
+            const LevelGeom& S = g.lv[g.nlevels > 1 ? 1 : 0];
+            c.srcOff = S.pyrOff; c.srcFrameBytes = S.pyrFrameBytes; c.srcStride = S.pyrStride; c.pad2 = 0;
+            for (int j = 0; j < kMaxLevels; j++) { c.rxOff[j] = j < g.nlevels ? g.lv[j].rxOff : 0; c.ryOff[j] = j < g.nlevels ? g.lv[j].ryOff : 0; }
+        }
     if (g.chain.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
     if (!g.chain.empty()) HIP_TRY(h, hipMemcpy(h->d_chain, g.chain.data(), sizeof(ChainTile) * g.chain.size(), hipMemcpyHostToDevice));
     if (g.chainAll.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");

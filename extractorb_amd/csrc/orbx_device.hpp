@@ -57,8 +57,12 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
     short pad;
     int cellId;               // i*nCols + j: raster rank of the cell inside its level
     int segOff;               // first slot of this cell's candidate segment inside the level's per-frame arena
+    // where the cell's level lives in the pyramid arena (copied from LevelGeom by installGeometry): k_fast's staging loads then depend on
+    // ONE wave-uniform load (this record), not on a second look-up in the level table — a memory round trip off a single frame's critical path
+    int pyrStride, pad2;
+    long long pyrOff, pyrFrameBytes;
 };
-static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
+static_assert(sizeof(CellDesc) == 48, "CellDesc layout");
 
 // ---- quad-tree dense phase: leaf grid of a root (k_octree.hip) -------------------------------------------------------------------
 // DivideNode's boxes depend only on the root box, and its x and y decisions are independent, so a key's quadrant path of length
@@ -122,7 +126,17 @@ constexpr int kChainTile0Rows = 64;  // rows of a LEVEL-0 tile of the one-launch
                                      // workgroups pushed the grid (1261) past the 1024 that fit the chip at once; 99 tall ones keep it in one round
 constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainMaxH0 = 96, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
 struct ChainRegion { short x0, y0, w, h; };
-struct ChainTile { short level, tileX, tileY, pad; ChainRegion region[kMaxLevels]; };
+// (everything the kernel needs of the level tables rides in the tile record itself, filled by installGeometry: one wave-uniform load, then
+// the region and coefficient loads can all be issued — a look-up in the level table first cost a third dependent memory round trip)
+struct ChainTile {
+    short level, tileX, tileY, pad;
+    ChainRegion region[kMaxLevels];
+    int w, h, pyrRows, pyrStride;                 // the tile's own level
+    long long pyrOff, pyrFrameBytes;
+    long long srcOff, srcFrameBytes;              // level 1 (the source of the chains that start there)
+    int srcStride, pad2;
+    int rxOff[kMaxLevels], ryOff[kMaxLevels];     // first coefficient record of level j in the handle's x / y tables
+};
 
 #ifdef __HIPCC__
 // The dynamically sized LDS block of a kernel.  (tools/octree_emu compiles k_octree.hip for the HOST to run it under sanitizers; its

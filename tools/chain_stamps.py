@@ -14,6 +14,9 @@ L = X.load_library()
 buf = np.zeros(32, np.uint64)
 L.orbx_debug_chain_stamps(buf.ctypes.data_as(C.c_void_p))
 t = buf.astype(np.int64)
-names = ["start", "loads issued + level-1 region + coefficients in LDS"] + ["level %d region" % j for j in range(2, 7)] + ["tile written"]
-for i in range(1, 8):
-    print("%-55s %8.2f us" % (names[i], (t[i] - t[i - 1]) / 100.0))
+names = ["start", "loads issued + first region + coefficients in LDS"] + ["step to level %d" % j for j in range(2, 8)] + ["tile written"]
+n = max(i for i in range(20) if t[i] > 0)
+for i in range(1, n + 1):
+    print("%-55s %8.2f us" % (names[min(i, len(names) - 1)], (t[i] - t[i - 1]) / 100.0))
+print("first stage: tile record read %.2f, region loads issued %.2f, coefficient loads issued %.2f, coefficients stored %.2f, region stored + barrier %.2f us" % tuple((a - b) / 100.0 for a, b in ((t[20], t[0]), (t[21], t[20]), (t[22], t[21]), (t[23], t[22]), (t[1], t[23]))))
+print("total %.2f us" % ((t[n] - t[0]) / 100.0))

@@ -9,17 +9,17 @@ import extractorb_amd as X
 from extractorb_amd import synth
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 fr = synth.frames("noise", 0, B, 480, 640)
-ex = X.ORBextractor(1000, max_batch=B)
+ex = X.ORBextractor(int(sys.argv[3]) if len(sys.argv) > 3 else 1000, max_batch=B)
 for _ in range(3):
     ex.extract_batch(fr)
 L = X.load_library()
 buf = np.zeros(128, np.uint64)
 L.orbx_debug_oct_stamps(buf.ctypes.data_as(C.c_void_p))
 n = int(buf[0])
-names = {0: "start", 1: "count pyramid + first size", 2: "node-level(ph1)", 3: "node-level(ph2)", 4: "build", 5: "sweep(if any)", 6: "final", 7: "scan+roots+tables", 8: "sweep0", 9: "pyramid"}
+names = {0: "start", 1: "count pyramid + first size", 2: "node-level(ph1)", 3: "node-level(ph2)", 4: "build", 5: "sweep(if any)", 6: "final", 7: "scan+roots+tables", 8: "sweep0", 9: "pyramid", 10: "ph2: child look-ups + rank counting -> barrier", 11: "ph2: growth scan -> barrier", 12: "ph2: break rank -> barrier", 13: "ph2: creation offsets -> barrier", 14: "ph2: kept scan -> barrier", 15: "ph2: node creation -> barrier"}
 prev = None
 for i in range(n):
     t, sid = int(buf[1 + i]) >> 8, int(buf[1 + i]) & 0xff
     if prev is not None:
-        print("%-18s %8.2f us" % (names[sid], (t - prev) / 100.0))   # s_memrealtime ticks at 100 MHz
+        print("%-48s %8.2f us" % (names[sid], (t - prev) / 100.0))   # s_memrealtime ticks at 100 MHz
     prev = t

@@ -96,6 +96,11 @@ inline int __shfl_xor(int v, int laneMask) {
 }
 inline int emu_readlane(int v, int lane) { return __shfl(v, lane); }
 #define __builtin_amdgcn_readlane emu_readlane
+// v_mbcnt_lo / _hi: base + bits of the mask below this lane (low / high half of the wave)
+inline int emu_mbcnt_lo(unsigned mask, int base) { const int l = (int)threadIdx.x & 63; return base + __builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u))); }
+inline int emu_mbcnt_hi(unsigned mask, int base) { const int l = (int)threadIdx.x & 63; return base + (l > 32 ? __builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0); }
+#define __builtin_amdgcn_mbcnt_lo emu_mbcnt_lo
+#define __builtin_amdgcn_mbcnt_hi emu_mbcnt_hi
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 // v_mov_b32_dpp: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane whose row / bank is masked off or whose
