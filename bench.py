@@ -70,6 +70,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 # Pricing every instruction at 4 cycles is therefore an UPPER bound of the issue time (exact for an all-half-rate kernel);
 # `frac_lower` prices the kernel's full-rate share (static census of its ISA, tools/valu_census.py) at 2 cycles.
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
+# ... and the ceiling as MEASURED (profiles/r03_valu_issue_rate.md): the half-rate class takes 4.14 true cycles per wave64 instruction, and k_fast's
+# waves run at 2.375 GHz in the benchmark's launch shape (tools/fast_clock.py, -DORBX_FAST_CLOCK build): 1024 x 2.375 / 4.14
+VALU_MEASURED_GINSTR = 1024 * 2.375 / 4.14
 
 
 def _search_rounds():
@@ -469,10 +472,13 @@ def main():
             full = float(vj.get("full_rate_share", 0.0))          # static ISA census: share of 2-cycle-class instructions
             valu = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
                         peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
+                        measured_ceiling_ginstr_s=round(VALU_MEASURED_GINSTR, 1), frac_of_measured_ceiling=round(g_instr / VALU_MEASURED_GINSTR, 4),
                         full_rate_share=round(full, 3), frac_lower=round(g_instr * (1 - full / 2) / VALU_PEAK_GINSTR, 4),
                         note="issue-slot occupancy of the dominant kernel: frac prices every instruction at the 4-cycle class "
                              "(upper bound); frac_lower prices its full-rate share at 2 cycles, where the share is a STATIC census of "
-                             "the kernel's ISA (every instruction counted once, tools/valu_census.py), not a dynamic mix: an estimate")
+                             "the kernel's ISA (every instruction counted once, tools/valu_census.py), not a dynamic mix: an estimate; "
+                             "frac_of_measured_ceiling prices the half-rate class at its measured 4.14 cycles and k_fast's measured 2.375 GHz "
+                             "(profiles/r03_valu_issue_rate.md)")
         roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),

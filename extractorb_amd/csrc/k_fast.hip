@@ -151,6 +151,23 @@ __device__ __forceinline__ int fastScore(const uint8_t* c) {
     return (int)max(maxMin - v, v - minMax);
 }
 
+#ifdef ORBX_FAST_CLOCK
+// diagnostic build only (tools/fast_clock.py): the clock k_fast's waves actually run at = sum of delta s_memtime / sum of delta s_memrealtime
+// x 100 MHz over every cell-wave (MI355X_MICROARCH.md, DVFS give-back (6)); the stamps go to a buffer nothing else reads
+constexpr int kFastClockSlots = 4096;      // one sampled wave per slot: plain stores (an atomic per wave would BE the load)
+__device__ unsigned long long g_fastClock[2 * kFastClockSlots];
+extern "C" int orbx_debug_fast_clock(unsigned long long* out, int reset) {
+    if (reset) return (int)hipMemset((void*)nullptr, 0, 0) + (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fastClock), out, sizeof(unsigned long long) * 2 * kFastClockSlots);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastClock), sizeof(unsigned long long) * 2 * kFastClockSlots);
+}
+#define FAST_CLOCK_BEGIN const unsigned long long fcR0 = __builtin_amdgcn_s_memrealtime(), fcT0 = __builtin_amdgcn_s_memtime();
+#define FAST_CLOCK_END do { const unsigned long long fcT1 = __builtin_amdgcn_s_memtime(), fcR1 = __builtin_amdgcn_s_memrealtime(); \
+        const unsigned fcW = (unsigned)(f * nCells + ci); \
+        if (lane == 0 && (fcW & 63u) == 0u) { g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1))] = fcT1 - fcT0; g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1)) + 1] = fcR1 - fcR0; } } while (0)
+#else
+#define FAST_CLOCK_BEGIN
+#define FAST_CLOCK_END do {} while (0)
+#endif
 constexpr int kFastWaves = 4;
 #ifndef ORBX_FAST_WAVES
 #define ORBX_FAST_WAVES 4   // waves per SIMD the packed (non-prefilter) variant is compiled for
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     }
     const int ci = chunk * kFastWaves + wave, f = f0 + fr;
     if (ci >= nCells) return;   // wave-uniform; the kernel has no workgroup barrier
+    FAST_CLOCK_BEGIN
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
     uint8_t* tile = smem + 16 + wave * (kTileBytes + kScoreBytes + kPassBytes);
@@ -378,6 +396,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     // => at most ceil(cw/2)*ceil(ch/2) of them), so the emit needs no atomic; the quad-tree kernel compacts the
     // segments in cell order, which is the reference's vToDistributeKeys order (cell row, cell column, y, x)
     if (lane == 0) cellCount[(long long)f * nCells + ci] = (unsigned)total;
+    FAST_CLOCK_END;
     if (total == 0) return;
     unsigned base = 0;
     unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;

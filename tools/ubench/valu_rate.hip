@@ -9,13 +9,17 @@
 // Reported per (instruction, shape, waves per SIMD): SIMD cycles per wave64 instruction two ways —
 //   "ev"  from HIP-event time at the nominal 2.4 GHz, and
 //   "mt"  from s_memtime ticks measured inside the waves (the guide: one tick = one shader cycle), which does not
-//         depend on the clock the chip actually ran at.
+//         depend on the clock the chip actually ran at,
+// and "ghz", the clock each cell actually ran at: delta s_memtime / delta s_memrealtime x 100 MHz inside the same waves
+// (MI355X_MICROARCH.md, DVFS give-back (6)).  ev x ghz / 2.4 must then equal mt: if it does, the ev / mt gap is the chip
+// holding its clock down under a VALU-dense load, not an accounting error.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate [csv]
 #include <hip/hip_runtime.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 enum Op {
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned long long* tick
     unsigned long long a2[NACC], b2 = ((unsigned long long)__float_as_uint(1.0f) << 32) | __float_as_uint(0.5f);
 #pragma unroll
     for (int i = 0; i < NACC; i++) { a[i] = (threadIdx.x + i * 977u) & 0x00ff00ffu; a2[i] = b2 + i; }
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -181,14 +186,18 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned long long* tick
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     unsigned r = 0;
 #pragma unroll
     for (int i = 0; i < NACC; i++) r ^= a[i] ^ (unsigned)a2[i] ^ (unsigned)(a2[i] >> 32);
     if (r == 0x12345678u) out[threadIdx.x] = r;
-    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6), n = gridDim.x * 4;
+        ticks[w] = t1 - t0; ticks[n + w] = r1 - r0; ticks[2 * n + w] = r0; ticks[3 * n + w] = r1;      // (absolute stamps: when was the wave resident?)
+    }
 }
 
-struct Res { double evCycles, mtCycles; };
+struct Res { double evCycles, mtCycles, ghz, resident; };
 
 template <int OP, int NACC, int DEP>
 Res run(unsigned* d, unsigned long long* dT, int blocks, int wavesPerSimd) {
@@ -204,14 +213,21 @@ Res run(unsigned* d, unsigned long long* dT, int blocks, int wavesPerSimd) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
-    std::vector<unsigned long long> t((size_t)blocks * 4);
+    std::vector<unsigned long long> t((size_t)blocks * 16);
     hipMemcpy(t.data(), dT, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double sum = 0;
-    for (auto v : t) sum += (double)v;
+    double sum = 0, sumReal = 0;
+    for (size_t i = 0; i < (size_t)blocks * 4; i++) { sum += (double)t[i]; sumReal += (double)t[(size_t)blocks * 4 + i]; }
     const double instrPerWave = 8.0 * NACC * iters;
     Res r;
     r.evCycles = ms * 1e6 / (instrPerWave * wavesPerSimd) * 2.4;                 // ns per wave-instr per SIMD x 2.4 GHz
-    r.mtCycles = sum / t.size() / (instrPerWave * wavesPerSimd);                 // a wave's ticks cover wavesPerSimd waves' instructions
+    r.mtCycles = sum / ((double)blocks * 4) / (instrPerWave * wavesPerSimd);     // a wave's ticks cover wavesPerSimd waves' instructions
+    r.ghz = sum / sumReal * 0.1;                                                 // s_memrealtime ticks at 100 MHz
+    // how many waves were resident per SIMD on average while the kernel ran: sum of wave lifetimes / (first start .. last end) / 1024 SIMDs.
+    // Below the nominal waves per SIMD the grid did not run as one resident set (the dispatcher placed it in rounds), and "mt" - a wave's
+    // own ticks spread over the NOMINAL number of co-resident waves - under-states the cycles a SIMD spent per instruction
+    unsigned long long first = ~0ull, last = 0;
+    for (size_t i = 0; i < (size_t)blocks * 4; i++) { first = std::min(first, t[(size_t)blocks * 8 + i]); last = std::max(last, t[(size_t)blocks * 12 + i]); }
+    r.resident = sumReal / (double)(last - first) / 1024.0;
     return r;
 }
 
@@ -221,9 +237,9 @@ void runOp(unsigned* d, unsigned long long* dT, bool csv) {
         const int blocks = 256 * wavesPerSimd;     // 256 CUs x (4 waves per block = 1 per SIMD) x wavesPerSimd
         const Res a8 = run<OP, 8, 1>(d, dT, blocks, wavesPerSimd), a16 = run<OP, 16, 1>(d, dT, blocks, wavesPerSimd),
                   in = run<OP, 8, 0>(d, dT, blocks, wavesPerSimd);
-        if (csv) printf("%s,%d,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f\n", kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles);
-        else printf("%-20s waves/SIMD %d   acc8 ev %6.2f mt %6.2f   acc16 ev %6.2f mt %6.2f   indep ev %6.2f mt %6.2f  cycles per wave64 instr per SIMD\n",
-                    kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles);
+        if (csv) printf("%s,%d,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.2f,%.2f,%.2f\n", kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles, a8.ghz, a16.ghz, in.ghz, a8.resident, a16.resident, in.resident);
+        else printf("%-20s waves/SIMD %d   acc8 ev %6.2f mt %6.2f   acc16 ev %6.2f mt %6.2f   indep ev %6.2f mt %6.2f  cycles per wave64 instr per SIMD; clock %.2f / %.2f / %.2f GHz; waves resident per SIMD %.2f / %.2f / %.2f\n",
+                    kNames[OP], wavesPerSimd, a8.evCycles, a8.mtCycles, a16.evCycles, a16.mtCycles, in.evCycles, in.mtCycles, a8.ghz, a16.ghz, in.ghz, a8.resident, a16.resident, in.resident);
         fflush(stdout);
     }
 }
@@ -237,8 +253,8 @@ int main(int argc, char** argv) {
     const bool csv = argc > 1 && !strcmp(argv[1], "csv");
     unsigned* d; unsigned long long* dT;
     hipMalloc(&d, 4096);
-    hipMalloc(&dT, 256 * 8 * 4 * sizeof(unsigned long long));
-    if (csv) printf("instruction,waves_per_simd,acc8_ev,acc8_mt,acc16_ev,acc16_mt,indep_ev,indep_mt\n");
+    hipMalloc(&dT, 256 * 8 * 4 * 4 * sizeof(unsigned long long));
+    if (csv) printf("instruction,waves_per_simd,acc8_ev,acc8_mt,acc16_ev,acc16_mt,indep_ev,indep_mt,acc8_ghz,acc16_ghz,indep_ghz,acc8_resident,acc16_resident,indep_resident\n");
     runAll<0>(d, dT, csv);
     return 0;
 }
