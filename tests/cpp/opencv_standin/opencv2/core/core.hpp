@@ -1,0 +1,62 @@
+// STAND-IN for <opencv2/core/core.hpp> — TEST INFRASTRUCTURE, not OpenCV.
+//
+// This image has no OpenCV, so the `orbx::CvTraits` branch of include/orbx_extractor.hpp (the one a maintainer of the reference compiles)
+// had never been seen by a compiler.  This header declares, with OpenCV 3's public names and signatures, exactly the parts of cv::Mat /
+// cv::KeyPoint / the CV_* macros that branch and the reference's call site (src/Frame.cc:419-427) use, so that
+// tests/cpp/cvtraits_typecheck.cpp type-checks (and, on the GPU box, runs) the drop-in name ORB_SLAM3::ORBextractor.  It implements
+// just enough behaviour (a reference-counted byte buffer) for that program; it is not used to build or imitate the reference.
+#pragma once
+#define OPENCV_CORE_HPP          // the include guard of OpenCV >= 3.2, which orbx_extractor.hpp looks for
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define CV_8U 0
+#define CV_CN_SHIFT 3
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << CV_CN_SHIFT))
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
+
+namespace cv {
+typedef unsigned char uchar;
+struct Point2f { float x = 0, y = 0; };
+class KeyPoint {          // modules/core/include/opencv2/core/types.hpp: pt, size, angle, response, octave, class_id — 28 bytes
+public:
+    Point2f pt;
+    float size = 0, angle = -1, response = 0;
+    int octave = 0, class_id = -1;
+};
+struct MatStep {           // Mat::step converts to size_t
+    size_t v = 0;
+    operator size_t() const { return v; }
+};
+class Mat {
+public:
+    Mat() {}
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, void* ext, size_t stepBytes) : rows(r), cols(c), data((uchar*)ext), flags_(type) { step.v = stepBytes; }   // a view: no ownership
+    void create(int r, int c, int type) {
+        const int cn = (type >> CV_CN_SHIFT) + 1;
+        own_ = std::make_shared<std::vector<uchar>>((size_t)r * c * cn);
+        rows = r; cols = c; flags_ = type; step.v = (size_t)c * cn; data = own_->data();
+    }
+    void release() { own_.reset(); rows = cols = 0; data = nullptr; step.v = 0; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int type() const { return flags_; }
+    Mat clone() const {
+        Mat m;
+        if (empty()) return m;
+        m.create(rows, cols, flags_);
+        for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step.v, data + (size_t)y * step.v, m.step.v);
+        return m;
+    }
+    int rows = 0, cols = 0;
+    uchar* data = nullptr;
+    MatStep step;
+private:
+    int flags_ = 0;
+    std::shared_ptr<std::vector<uchar>> own_;
+};
+}  // namespace cv

@@ -176,6 +176,56 @@ def test_gpu_bow_equals_oracle(cfg, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cap,ns", [(8, [8, 3]), (16, [16, 1]), (24, [20, 24]), (40, [33, 40])])
+def test_gpu_bow_with_very_small_capacities(cap, ns):
+    """The per-frame sort never runs on fewer than 64 keys; its LDS block and the offset of the weight sums must follow that minimum
+    (capacity <= 16 used to give a 256-byte allocation for 512 bytes of keys: round-2 advisor finding)."""
+    import torch
+    rng = np.random.default_rng(cap)
+    v = make_vocab(rng, k=4, L=3)
+    B = len(ns)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    for f in range(B):
+        desc[f, :ns[f]] = _descriptors(v, rng, 64)[:ns[f]]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_wid = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_ww = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
+    d_nw = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_fn = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_fi = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    d_nf = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex = X.ORBextractor(1000)
+    ex.compute_bow_device(X.Vocabulary(arrays=v), B, dev(desc), dev(np.array(ns, np.int32)), cap, d_wid, d_ww, d_nw, d_fn, d_fi, d_nf, levels_up=1)
+    ex.synchronize()
+    for f in range(B):
+        wid, ww, fn, fi = O.compute_bow(v, desc[f, :ns[f]], 1)
+        nw, nf = int(d_nw[f]), int(d_nf[f])
+        assert nw == len(wid) and nf == len(fi)
+        assert d_wid[f, :nw].cpu().numpy().astype(np.uint32).tolist() == wid.tolist() and d_ww[f, :nw].cpu().numpy().tobytes() == ww.tobytes()
+        assert d_fn[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fn.tolist() and d_fi[f, :nf].cpu().numpy().astype(np.uint32).tolist() == fi.tolist()
+
+
+@pytest.mark.gpu
+def test_vocabulary_file_that_ends_in_a_newline(tmp_path):
+    """Declared divergence: the reference's loader loops `while(!f.eof())` (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1378-1419),
+    so the empty line after the last node of a real ORBvoc.txt appends ONE MORE node under the root — parent 0 from a failed extraction, a
+    descriptor read from an empty string, i.e. whatever the matrix's memory held (undefined).  orbx_vocabulary_load_text stops at the end of
+    the data: files with no, one or several trailing newlines load as the same tree, with exactly the nodes the file lists."""
+    rng = np.random.default_rng(9)
+    v = make_vocab(rng, k=5, L=2)
+    base = tmp_path / "v0.txt"
+    write_text(v, base)
+    text = open(base).read()
+    assert text.endswith("\n")
+    infos = []
+    for i, tail in enumerate(["", "\n", "\n\n\n", "  \n"]):
+        p = tmp_path / ("v%d.txt" % (i + 1))
+        open(p, "w").write(text.rstrip("\n") + tail)
+        infos.append(X.Vocabulary(path=p).info())
+    assert all(x == infos[0] for x in infos) and infos[0]["n_nodes"] == len(v["parent"])
+    rooted = sum(1 for n in range(1, len(v["parent"])) if v["parent"][n] == 0)
+    assert rooted == v["k"]                                  # the root keeps its k children: no phantom node joins them
+
+
+@pytest.mark.gpu
 def test_gpu_bow_on_extracted_frames():
     """ComputeBoW fed straight from the extraction's device buffers (the Frame constructor's order: ExtractORB, then ComputeBoW on demand)."""
     import torch
@@ -217,3 +267,7 @@ def test_vocabulary_errors(tmp_path):
                desc=np.zeros((3, 32), np.uint8), weight=np.ones(3))
     with pytest.raises(X.OrbxError):
         X.Vocabulary(arrays=bad)                             # parent after child
+    wide = dict(k=10, L=1, scoring=0, weighting=0, parent=np.zeros(301, np.int32), is_leaf=np.r_[0, np.ones(300)].astype(np.uint8),
+                desc=np.zeros((301, 32), np.uint8), weight=np.ones(301))
+    with pytest.raises(X.OrbxError):
+        X.Vocabulary(arrays=wide)                            # 300 children under one node: the child rank is packed into a byte

@@ -20,6 +20,38 @@ def _build(tmp_path, name="shim_test"):
     return exe
 
 
+def _build_cv(tmp_path):
+    exe = str(tmp_path / "cvtraits_typecheck")
+    libdir = os.path.dirname(X.library_path())
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "tests", "cpp", "opencv_standin"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "cvtraits_typecheck.cpp"), "-o", exe,
+                           "-L" + libdir, "-lorbx", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_drop_in_name_compiles_against_opencv_shaped_headers(tmp_path):
+    """ORB_SLAM3::ORBextractor = BasicORBextractor<CvTraits>: the branch a maintainer with OpenCV compiles, type-checked here against a stand-in
+    header with OpenCV 3's names (C++11, as the reference builds: CMakeLists.txt:10-12)."""
+    assert os.path.exists(_build_cv(tmp_path))
+
+
+@pytest.mark.gpu
+def test_drop_in_name_runs_the_frame_call_shape(tmp_path):
+    import oracle_lib as O
+    from extractorb_amd import synth
+    exe = _build_cv(tmp_path)
+    img = synth.frames("textured", 12, 1, 480, 640)[0]
+    (tmp_path / "in.gray").write_bytes(img.tobytes())
+    out = tmp_path / "out.bin"
+    subprocess.check_call([exe, str(tmp_path / "in.gray"), "480", "640", "1000", str(out)])
+    raw = out.read_bytes()
+    mono, n = np.frombuffer(raw[:8], np.int32)
+    k = np.frombuffer(raw[8:8 + 28 * n], X.KEYPOINT_DTYPE)
+    d = np.frombuffer(raw[8 + 28 * n:8 + 60 * n], np.uint8).reshape(n, 32)
+    wm, wk, wd = O.Oracle(1000).extract(img, (0, 1000))
+    assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
+
+
 def test_thread_program_compiles(tmp_path):
     assert os.path.exists(_build(tmp_path, "shim_threads_test"))
 

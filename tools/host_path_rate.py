@@ -18,7 +18,7 @@ from extractorb_amd import synth
 
 def main():
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    for B in (1, 8, 64, 256):
+    for B in [int(b) for b in os.environ.get("HOST_RATE_BATCHES", "1,8,64,256").split(",")]:
         fr = synth.frames("noise", 0, min(B, 64), 480, 640)
         fr = np.concatenate([fr] * ((B + len(fr) - 1) // len(fr)))[:B]
         ex = X.ORBextractor(1000, max_batch=B)
@@ -46,7 +46,9 @@ def main():
         assert outs[0][2].tolist() == n.tolist() and np.array_equal(outs[1][1], desc)
         vk, vd, vn, vm, vc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
         end = lambda i: exs[i]._L.orbx_extract_batch_end_view(exs[i]._h, C.byref(vk), C.byref(vd), C.byref(vc), C.byref(vn), C.byref(vm))   # zero-copy
-        reps2 = max(4, 512 // B)
+        for k in range(4):                      # the timed call shape once more, untimed (begin / end_view on both handles)
+            assert begin(k & 1) == 0 and end(k & 1) == 0
+        reps2 = max(16, 512 // B)
         t = time.perf_counter()
         assert begin(0) == 0
         for k in range(1, reps2):
