@@ -346,7 +346,7 @@ def main():
     # ---- BASELINE.json configs[4] as a secondary figure of every N > 1 line: 64 frames per GPU per step (512 frames on 8 GPUs),
     #      result slabs gathered to rank 0; same step / fence / max-over-ranks rules as the main figure ----
     cfg5 = None
-    if distributed and N > 1 and args.workload == "mono640" and not args.no_extras:
+    if distributed and (N > 1 or os.environ.get("ORBX_BENCH_CONFIGS4_AT_ANY_N")) and args.workload == "mono640" and not args.no_extras:      # (the env switch: the test reaches this code on a one-GPU box)
         B5 = min(64, B)
         e5 = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B5, device=local_rank)
         e5.set_stream(stream.cuda_stream)

@@ -200,9 +200,10 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
     constexpr int DW = TS / 4;                        // dwords per tile row
-    constexpr int LPR = DW <= 16 ? 16 : 32;           // lanes per row while staging
+    constexpr int LPR = DW <= 16 ? 8 : 16;            // lanes per row while staging: a lane moves TWO dwords (one 8-byte load, one 8-byte LDS store)
     constexpr int RPI = 64 / LPR;                     // rows per staging step
     constexpr int STEPS = (ROWS + RPI - 1) / RPI;
+    static_assert(DW % 2 == 0 && TS % 8 == 0, "dword pairs per tile row");
     constexpr int kMaxPix = (ROWS - 6) * (ROWS - 6);  // interior pixels of the largest cell
     constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
     // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword
@@ -236,19 +237,22 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         // wave-uniform base + 32-bit lane offsets; rows / dword columns past the ROI are clamped, not predicated (their
         // tile bytes are never read by an interior pixel)
         const uint8_t* sp = pyr + c.pyrOff + (long long)f * c.pyrFrameBytes + (long long)(kEdge + c.y0) * c.pyrStride + (gx1 - gsh);
-        const int dcol = lane & (LPR - 1), rsub = lane / LPR;
-        const unsigned colOff = 4u * (unsigned)min(dcol, (gsh + roiW) >> 2);    // last dword holding a needed byte
+        const int dcol = lane & (LPR - 1), rsub = lane / LPR;                    // dcol: the lane's dword PAIR of the row
+        const unsigned colOff = 8u * (unsigned)min(dcol, (gsh + roiW) >> 3);    // last pair holding a needed byte (its second dword still lies inside the bordered row)
         const unsigned off0 = (unsigned)__mul24(rsub, c.pyrStride) + colOff, offMax = (unsigned)__mul24(roiH - 1, c.pyrStride) + colOff;
         const unsigned stepOff = (unsigned)(RPI * c.pyrStride);
-        unsigned w[STEPS];
+        uint2 w[STEPS];
 #pragma unroll
-        for (int s = 0; s < STEPS; s++)
-            w[s] = (ORBX_FAST_SKIP & 4) ? 0u : *(const unsigned*)(sp + min(off0 + s * stepOff, offMax));
+        for (int s = 0; s < STEPS; s++) {
+            if (ORBX_FAST_SKIP & 4) w[s] = uint2{0u, 0u};
+            else __builtin_memcpy(&w[s], sp + min(off0 + s * stepOff, offMax), 8);      // (4-byte aligned: one global_load_dwordx2)
+        }
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             const int r = s * RPI + rsub;
-            const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[s], 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, true);
-            if (dcol < DW && r < ROWS) *(unsigned*)(tile + r * TS + 4 * dcol) = __builtin_amdgcn_alignbyte(next, w[s], (unsigned)gsh);
+            const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[s].x, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, true);
+            if (dcol < DW / 2 && r < ROWS)
+                *(uint2*)(tile + r * TS + 8 * dcol) = uint2{__builtin_amdgcn_alignbyte(w[s].y, w[s].x, (unsigned)gsh), __builtin_amdgcn_alignbyte(next, w[s].y, (unsigned)gsh)};
         }
     }
     // zero the score tile (its 1-px apron stands for "outside the ROI interior")

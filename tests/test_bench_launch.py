@@ -57,11 +57,14 @@ def test_spawn_path_end_to_end_on_one_gpu():
     -> rank -> RCCL process group -> HIP kernels -> gather -> one JSON line relayed by the parent; the line carries the oracle check
     of the slab it timed."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ORBX_BENCH_CONFIGS4_AT_ANY_N"] = "1"            # the N > 1 line's secondary figure (BASELINE.json configs[4]) at the world size this box has
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "64",
-                        "--no-extras", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 0 and "RCCL gather" in j["config"]["parallelism"]
     assert j["verified"]["bit_exact"] is True and len(j["verified"]["frames"]) == 4
+    c4 = j["secondary"]["configs4_64_per_gpu"]
+    assert c4["frames_per_gpu_per_step"] == 64 and c4["fps"] > 0 and "gathered to rank 0" in c4["note"]

@@ -186,7 +186,7 @@ def test_gpu_bow_with_very_small_capacities(cap, ns):
     B = len(ns)
     desc = np.zeros((B, cap, 32), np.uint8)
     for f in range(B):
-        desc[f, :ns[f]] = _descriptors(v, rng, 64)[:ns[f]]
+        desc[f, :ns[f]] = _descriptors(v, rng, 100)[:ns[f]]
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d_wid = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_ww = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
     d_nw = torch.zeros(B, dtype=torch.int32, device="cuda")

@@ -1,6 +1,6 @@
 """Bounded, seeded randomised parity sweep under -m gpu: tools/fuzz_parity.py's generator (random image sizes, feature counts,
 level counts, scale factors 1.1-2.0, thresholds, lapping areas, content), every stage and the final arrays against the oracle,
-under each kernel-variant switch.  The totals are written to gpurun_out/r02_fuzz_parity.json on the GPU box (copied to
+under each kernel-variant switch.  The totals are written to gpurun_out/r03_fuzz_parity.json on the GPU box (copied to
 profiles/r02_fuzz_parity.md)."""
 import json
 import os
@@ -25,7 +25,11 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            # every device allocation of the handle filled with a byte pattern: nothing may depend on what hipMalloc returns
            ({"ORBX_POISON": "165"}, 8, 111), ({"ORBX_POISON": "255"}, 8, 112),
            # ... nor on what the previous workgroup left in LDS (every CU's LDS filled with a byte in front of every kernel)
-           ({"ORBX_LDS_POLLUTE": "165"}, 8, 113), ({"ORBX_LDS_POLLUTE": "255", "ORBX_POISON": "90"}, 8, 114)]
+           ({"ORBX_LDS_POLLUTE": "165"}, 8, 113), ({"ORBX_LDS_POLLUTE": "255", "ORBX_POISON": "90"}, 8, 114),
+           # small batches start the quad-tree from k_fast's leaf tables by default (round 3); these keep the kernel's own first sweep under test
+           ({"ORBX_LEAF_FRAMES": "0"}, 8, 115), ({"ORBX_LEAF_FRAMES": "0", "ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
+           # ... and the leaf tables with poisoned allocations (they must be zero between calls whatever hipMalloc returned)
+           ({"ORBX_POISON": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116)]
 _totals = []
 
 
@@ -41,6 +45,6 @@ def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        json.dump(_totals, open(os.path.join(out, "r02_fuzz_parity.json"), "w"), indent=1)
+        json.dump(_totals, open(os.path.join(out, "r03_fuzz_parity.json"), "w"), indent=1)
     except OSError:
         pass

@@ -444,3 +444,18 @@ def test_scale_factor_two_uses_the_byte_gather_resize():
     mono, k, d, lvl = ex(img)
     check_stages(ex, o, lvl, 3)
     assert_same_result((mono, k, d), want, "scale 2.0")
+
+
+@pytest.mark.parametrize("B", [1, 2, 7, 8, 9, 12])
+def test_small_batches_around_the_leaf_table_limit(B):
+    """Up to ORBX_LEAF_FRAMES (8) frames per call k_fast's emit builds the quad-tree's leaf tables and k_octree starts from them; one frame more
+    and the kernel sweeps the segments itself.  Both sides of the limit, twice in a row on one handle (the tables must be clean again), every
+    frame against the oracle."""
+    frames = np.concatenate([synth.frames("noise", 3, (B + 1) // 2, 480, 640), synth.frames("sparse", 5, B // 2 + 1, 480, 640)])[:B]
+    ex = X.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=12)
+    for rep in range(2):
+        out = ex.extract_batch(frames if rep == 0 else frames[::-1].copy())
+        src = frames if rep == 0 else frames[::-1]
+        for f in range(B):
+            o, want = oracle_run(src[f], 1000)
+            assert_same_result(out[f][:3], want, "B=%d rep %d frame %d" % (B, rep, f))
