@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the emulated quad-tree kernel over the GPU fuzz corpus (tools/fuzz_parity.py's generator, the seeds of tests/test_gpu_fuzz.py):
 every case through every compiled variant of k_octree_body.inc (256 / 512 / 1024 threads, queued and scratch-free "r" forms, which differ
-in the short phase-2 pass) under AddressSanitizer + UBSan, a subset under ThreadSanitizer, two poison bytes; results vs the oracle.
+in the short phase-2 pass; with and without the small-batch start from k_fast's leaf tables) under AddressSanitizer + UBSan, a subset under
+ThreadSanitizer, several poison bytes; results vs the oracle.
 usage: soak.py [cases_per_seed] [seed ...]        writes a markdown summary to stdout"""
 import os
 import sys
@@ -38,9 +39,12 @@ def main():
             ncand = sum(len(o.candidates(l)) for l in range(c["nlevels"]))
             what = "seed %d case %d: %dx%d nf=%d levels=%d sf=%.1f %s, %d candidates" % (seed, t, c["cols"], c["rows"], c["nf"], c["nlevels"], c["sf"], c["variant"], ncand)
             res = []
-            for kind, T, roomy, poison in ([("asan", T, r, 0xA5) for T in (256, 512, 1024) for r in (0, 1)] + [("plain", 512, 0, 0x00), ("plain", 512, 1, 0xFF)]
-                                           + ([("tsan", 256, 1, 0xA5), ("tsan", 512, 0, 0xA5)] if ncand < 40000 else [])):
-                E.write_case(case, o, c["rows"], c["cols"], c["nf"], c["sf"], c["nlevels"], T, roomy, c["lap"], poison)
+            # (kind, threads, scratch-free variant, poison byte, start from k_fast's leaf tables = the small-batch form)
+            variants = ([("asan", T, r, 0xA5, False) for T in (256, 512, 1024) for r in (0, 1)] + [("plain", 512, 0, 0x00, False), ("plain", 512, 1, 0xFF, False)]
+                        + [("asan", 1024, 1, 0xA5, True), ("asan", 256, 1, 0x3C, True)]
+                        + ([("tsan", 256, 1, 0xA5, False), ("tsan", 512, 0, 0xA5, False), ("tsan", 512, 1, 0xA5, True)] if ncand < 40000 else []))
+            for kind, T, roomy, poison, leaf in variants:
+                E.write_case(case, o, c["rows"], c["cols"], c["nf"], c["sf"], c["nlevels"], T, roomy, c["lap"], poison, leaf_tables=leaf)
                 try:
                     rc, err = E.run_case(bins[kind], case, out, timeout=900, env={"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0",
                                                                                     "ASAN_OPTIONS": "detect_leaks=0"})
@@ -55,7 +59,7 @@ def main():
                 else:
                     bad = E.check(o, c["nlevels"], c["lap"], E.read_result(out, c["nlevels"])) if rc == 0 else ["rc %d: %s" % (rc, err.strip().splitlines()[:12])]
                 if bad:
-                    res.append("%s T=%d r=%d poison=%02x: %s" % (kind, T, roomy, poison, bad))
+                    res.append("%s T=%d r=%d poison=%02x leaf=%d: %s" % (kind, T, roomy, poison, leaf, bad))
             rows.append((what, res))
             print("%-100s %s   [%.0f s]" % (what, "ok" if not res else res, time.time() - t0), file=sys.stderr, flush=True)
     print("| case | result |\n|---|---|")
