@@ -42,7 +42,7 @@ out = ["# SQ counters per launch - %s (%s, %s frames per launch); kernel sources
        "SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY`.\n\n",
        open(os.path.join(src, "sq_summary.md")).read(),
        "\n## Vector-instruction issue roofline\n\n",
-       "gfx950 has two issue classes (`profiles/r02_valu_issue_rate.md`): ~2 cycles per wave64 instruction for v_fma_f32 / v_add_f32 / v_mul_f32 / v_add_u32 /\n"
+       "gfx950 has two issue classes (`profiles/r03_valu_issue_rate.md`): ~2 cycles per wave64 instruction for v_fma_f32 / v_add_f32 / v_mul_f32 / v_add_u32 /\n"
        "v_sub_u32 / v_and_b32 / v_or_b32 / v_mov_b32, ~4 cycles for everything else these kernels use.  `upper` prices every instruction at 4 cycles\n"
        "(peak %.0f G wave-instr/s = 1024 SIMDs x 2.4 GHz / 4); `lower` prices the kernel's full-rate share (static census of its ISA, `tools/valu_census.py`)\n"
        "at 2 cycles.  The true issue-slot occupancy lies between the two.  Duration = average of the same kernel in the kernel stats of this state.\n\n" % peak,
