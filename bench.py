@@ -514,7 +514,7 @@ def main():
             cf0 = synth.frames(variant, 0, 64 if small else 8, rows, cols)
             runs = []
             for th in counts:
-                smp = min(max(64, 8 * th), 1024) if small else min(max(16, 2 * th), 128)     # 10-30 s of CPU work per 16 cores
+                smp = min(max(64, 24 * th), 1024) if small else min(max(16, 4 * th), 128)     # 10-30 CPU-seconds on a 16-CPU share
                 cf = np.concatenate([cf0] * ((smp + len(cf0) - 1) // len(cf0)))[:smp]
                 sec, _ = O.time_frames(cf, nf, 1.2, 8, 20, 7, wl["lapping"], nthreads=th)
                 runs.append(dict(threads=th, frames=smp, seconds=round(sec, 2), fps=round(smp / sec, 2)))

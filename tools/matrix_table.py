@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""gpurun_out/matrix.jsonl (tools/bench_matrix.sh) -> markdown table.  usage: matrix_table.py > profiles/r02_bench_matrix.md"""
-import json, os
+"""gpurun_out/matrix.jsonl (tools/bench_matrix.sh) -> markdown table.  usage: matrix_table.py [round tag] > profiles/r03_bench_matrix.md"""
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lines = open(os.path.join(ROOT, "gpurun_out", "matrix.jsonl")).read().splitlines()
-print("# bench.py matrix - round-2 final, 1x MI355X, device-resident inputs and outputs\n")
+print("# bench.py matrix - %s, 1x MI355X, device-resident inputs and outputs\n" % (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].endswith(".jsonl") else "round-3 final"))
 print("Collected by `tools/bench_matrix.sh` in one gpurun call (`--no-cpu-baseline --no-extras` on every row).  Default frames per call: 512 (640x480 workloads),\n"
       "128 (hd720, hd1080).  Timed steps run the two-half overlap where it applies; the per-kernel figures are bench.py's event-profiled, unsplit pass.\n")
 print("| bench.py arguments | frames/call | frames/s | ms/step | keypoints/frame | extra | path_frac (HBM) | kernel us per step |\n|---|---|---|---|---|---|---|---|")
