@@ -83,6 +83,66 @@ def test_decode_of_the_16_bit_frame_is_only_weakly_pinned():
     assert counts[5:] == [125, 62, 64] and sum(counts) == REFERENCE_TOTAL
 
 
+# ---- the same screenshot also shows WHERE the reference put its keypoints ------------------------------------------------------------------
+# Its "ORB_SLAM3 extract keypoints" window is imshow(drawKeypoints(image, all levels' keypoints scaled to level 0)) at native size: a 512 x 512
+# client area at (577, 315) of the capture, committed as tests/golden/screenshot_room4_window.png.  Every pixel no circle touches still
+# holds the frame's gray value (R = G = B = pixel), every keypoint is an anti-aliased circle of radius 3 around its (sub-pixel) position.
+def _window():
+    win = np.array(__import__("PIL.Image", fromlist=["Image"]).open(__import__("os").path.join(__import__("helpers").GOLDEN, "screenshot_room4_window.png"))).astype(np.int32)
+    gray = load_gray("tum_room4_gray.png").astype(np.int32)
+    untouched = (win[:, :, 0] == gray) & (win[:, :, 1] == gray) & (win[:, :, 2] == gray)
+    return win, gray, untouched
+
+
+def drawn_vs_positions(x, y):
+    """(drawn pixels farther than 5 px from every given position, positions without a drawn ring).  The circle the demo draws at (0, 0) — its
+    output vector starts with default-constructed keypoints (main_orb_extractor.cpp:54-60) — is left out."""
+    from scipy.spatial import cKDTree
+    _, _, untouched = _window()
+    my, mx = np.nonzero(~untouched)
+    keep = ~((mx <= 6) & (my <= 6))
+    drawn = np.stack([mx[keep], my[keep]], 1).astype(float)
+    pts = np.stack([x, y], 1).astype(float)
+    dist, _ = cKDTree(pts).query(drawn)
+    tree = cKDTree(drawn)
+    ringless = 0
+    for p in pts:
+        near = drawn[tree.query_ball_point(p, 4.6)]
+        ringless += int((np.hypot(near[:, 0] - p[0], near[:, 1] - p[1]) >= 1.9).sum() < 12)
+    return int((dist > 5.0).sum()), ringless
+
+
+def test_the_screenshot_shows_this_frame_decoded_to_its_high_byte():
+    """0.910 of the window's pixels equal tests/golden/tum_room4_gray.png EXACTLY (the rest lie under circles).  The other room4 frame gives
+    0.24 and a scaled 16 -> 8 bit conversion of the right frame 0.60 (measured in the build container against the 16-bit original): the picture
+    pins which frame it was and that imread(IMREAD_GRAYSCALE) kept the high byte — the one input-side semantic the keypoint total left open."""
+    _, _, untouched = _window()
+    assert 0.90 < untouched.mean() < 0.93
+
+
+def test_oracle_keypoints_sit_where_the_reference_drew_them():
+    """All 1420 positions: every circle pixel of the reference's picture lies within 5 px of an oracle keypoint (7 stray pixels of 23 400, at
+    the rim of two dense clusters) and every oracle keypoint has its ring.  Positions, unlike the total, also respond to the half-extent
+    rounding of DivideNode and to the order in which equal-sized nodes split (the oracle's DECLARED tie rule — newest first — fits the
+    reference's picture, oldest first does not)."""
+    o = O.Oracle(*REFERENCE_PARAMS)
+    _, k, _ = o.extract(load_gray("tum_room4_gray.png"), (0, 1000))
+    stray, ringless = drawn_vs_positions(k["x"], k["y"])
+    assert stray <= 10 and ringless == 0, (stray, ringless)
+    for mutation, name in ((12, "sort ties oldest first"), (13, "DivideNode floor")):
+        om = O.Oracle(*REFERENCE_PARAMS)
+        om.set_mutation(mutation)
+        _, km, _ = om.extract(load_gray("tum_room4_gray.png"), (0, 1000))
+        assert len(km) == REFERENCE_TOTAL                                  # the total does not see these two ...
+        stray_m, _ = drawn_vs_positions(km["x"], km["y"])
+        assert stray_m >= 3 * max(stray, 1), (name, stray_m)                # ... the positions do
+    # a semantic the total already decides moves the positions far more
+    om = O.Oracle(*REFERENCE_PARAMS)
+    om.set_mutation(1)
+    _, km, _ = om.extract(load_gray("tum_room4_gray.png"), (0, 1000))
+    assert drawn_vs_positions(km["x"], km["y"])[0] > 300
+
+
 @pytest.mark.gpu
 def test_hip_path_reproduces_the_reference_screenshot_count():
     """The HIP path on the reference's frame with the reference's parameters: 1420 keypoints, and bit for bit the oracle's."""
@@ -94,6 +154,8 @@ def test_hip_path_reproduces_the_reference_screenshot_count():
     o = O.Oracle(*REFERENCE_PARAMS)
     wmono, wk, wd = o.extract(img, (0, 1000))
     assert mono == wmono and k.tobytes() == wk.tobytes() and np.array_equal(d, wd)
+    stray, ringless = drawn_vs_positions(k["x"], k["y"])          # ... and they sit where the reference's picture has its circles
+    assert stray <= 10 and ringless == 0
     for l in range(8):
         assert lvl[l].tobytes() == o.level_keypoints(l).tobytes()
         assert ex.debug_candidates(l).tobytes() == o.candidates(l).tobytes()

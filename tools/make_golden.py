@@ -65,6 +65,13 @@ def main():
         g = gray8(src)
         Image.fromarray(g).save(os.path.join(OUT, name), optimize=True)
         print(name, g.shape, "mean %.4f" % g.mean())
+    # the reference's own rendering of its result: the "ORB_SLAM3 extract keypoints" window of img_folder/Screenshot.png (imshow of
+    # drawKeypoints(image, keypoints of all levels scaled to level 0), 512 x 512 at native size), client area at (577, 315) of the screen capture
+    shot = np.array(Image.open(os.path.join(os.path.dirname(REF), "img_folder", "Screenshot.png")).convert("RGB"))
+    win = shot[315:315 + 512, 577:577 + 512]
+    Image.fromarray(win).save(os.path.join(OUT, "screenshot_room4_window.png"), optimize=True)
+    room4 = np.array(Image.open(os.path.join(OUT, "tum_room4_gray.png")))
+    print("screenshot window: %.4f of its pixels equal the room4 frame exactly" % (win == room4[:, :, None]).all(axis=2).mean())
     for case, img, nf, lap in CASES:
         g = np.array(Image.open(os.path.join(OUT, img)))
         o = O.Oracle(nf, 1.2, 8, 20, 7)
