@@ -203,6 +203,16 @@ int main(int argc, char** argv) {
         fclose(ft);
     }
 #endif
+    if (argc > 4) {      // investigation aid: the kernel's global work arrays after the run (per level: capacity, compacted keys, node ids)
+        FILE* fa = fopen(argv[4], "wb");
+        for (int l = 0; l < H.nlevels; l++) {
+            const int cap = g.lv[l].candCap;
+            fwrite(&cap, 4, 1, fa);
+            fwrite(candPos.p + g.lv[l].candOff, 4, (size_t)cap, fa);
+            fwrite(nodeOf.p + g.lv[l].candOff, 2, (size_t)cap, fa);
+        }
+        fclose(fa);
+    }
     FILE* fo = fopen(argv[2], "wb");
     if (!fo) { perror(argv[2]); return 2; }
     for (int l = 0; l < H.nlevels; l++) {
