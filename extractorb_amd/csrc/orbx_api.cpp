@@ -147,6 +147,7 @@ struct orbx_handle {
     // small batches: per-(frame, level, root) leaf counters / best keys filled by k_fast's emit, consumed and cleared by k_octree
     // (orbx_device.hpp: LeafTables); d_leafCode = [2][nlevels][octXT] host-built x / y path codes of the current geometry
     int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 8; 0 = off)
+    int octSmallT = 0;             // ORBX_OCT_SMALL_T: quad-tree workgroup size of the small-batch form (0 = by the largest level quota)
     int* d_leafHist = nullptr;
     unsigned* d_leafBest = nullptr;
     uint8_t* d_leafCode = nullptr;
@@ -464,6 +465,18 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             const long long slots = 1024LL * h->numCUs, wgs = (long long)Bn * g.nlevels;   // threads resident at once at 4 waves per SIMD
             int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : (wgs * 256 <= slots ? 256 : 0));
             if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
+            // ... but with the first sweep done by k_fast (leaf tables) what is left of a level is a chain of barriers over a list of at most
+            // quota + 3 nodes: when 256 threads still give every node of the list its own thread (the short pass forms) the small workgroup
+            // has the cheapest barriers (one frame: 1024 threads 16.7 us, 256 threads 13.6)
+            if (residentT && lt.hist) {
+                int q = 0;
+                for (int l = 0; l < g.nlevels; l++) q = g.lv[l].quota > q ? g.lv[l].quota : q;
+                // (a list longer than 256 keeps the large workgroup: its last pass ranks up to 256 multi-key nodes against each other,
+                // which is arithmetic, not barriers - nfeatures 1200: 1024 threads 18.0 us, 512 threads 19.3)
+                int need = q + 4 <= 256 ? 256 : residentT;
+                if (h->octSmallT) need = h->octSmallT;   // ORBX_OCT_SMALL_T: measurement override
+                if (need < residentT) residentT = need;
+            }
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
             pollute(st);
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
@@ -659,6 +672,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
     h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 8;
     if (h->leafFrames > max_batch) h->leafFrames = max_batch;
+    if (const char* e = getenv("ORBX_OCT_SMALL_T")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) h->octSmallT = t; }
     if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree
     if (h->leafFrames) {
         const size_t n = (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves;
