@@ -299,8 +299,15 @@ __device__ __forceinline__ unsigned resizePixel(const uint8_t* r0, const uint8_t
 __device__ unsigned long long g_chainStamps[32];
 #define CSTAMP(i) do { if (tid == 0 && t == 0) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chainStamps), sizeof(unsigned long long) * 32); }
+// every tile's (start, end, level | XCC_ID << 8 | CU << 16) — tools/chain_spans.py
+__device__ unsigned long long g_chainSpans[3 * 2048];
+extern "C" int orbx_debug_chain_spans(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chainSpans), sizeof(g_chainSpans)); }
+#define CSPAN_BEGIN do { if (tid == 0 && t < 2048) g_chainSpans[3 * t] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSPAN_END(lvl) do { if (tid == 0 && t < 2048) { g_chainSpans[3 * t + 1] = __builtin_amdgcn_s_memrealtime(); g_chainSpans[3 * t + 2] = (unsigned long long)(lvl); } } while (0)
 #else
 #define CSTAMP(i) do {} while (0)
+#define CSPAN_BEGIN do {} while (0)
+#define CSPAN_END(lvl) do {} while (0)
 #endif
 constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
 
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     if (!xcdChunkFrame(nFrames, t, fr)) return;
     const int f = f0 + fr, tid = threadIdx.x;
     CSTAMP(0);
+    CSPAN_BEGIN;
     // (the tile record and the level table stay in memory and are read through wave-uniform loads: a by-value copy indexed by the
     // step number would live in scratch)
     const ChainTile& ct = tiles[t];
@@ -349,6 +357,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
                 *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + bc0) = o;
                 }
             }
+            CSPAN_END(0);
             return;
         }
     }
@@ -563,6 +572,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
         }
     }
     CSTAMP(level);
+    CSPAN_END(level);
 }
 
 void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,

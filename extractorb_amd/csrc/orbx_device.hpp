@@ -107,7 +107,10 @@ constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (p
 #define ORBX_BLUR_SMALL_ROWS 8
 #endif
 constexpr int kBlurBlockRowsSmall = ORBX_BLUR_SMALL_ROWS;   // ... in small batches (latency, not throughput)
-constexpr int kResizeTileRows = 32;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
+#ifndef ORBX_RESIZE_TILE_ROWS
+#define ORBX_RESIZE_TILE_ROWS 32
+#endif
+constexpr int kResizeTileRows = ORBX_RESIZE_TILE_ROWS;   // destination rows per workgroup tile of k_pyr_first / k_resize (256 pixels wide)
 
 // Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
 // A resize tile's staged source rectangle: first column (a multiple of 4; negative = inside the level's border), dwords per row, first
