@@ -297,7 +297,10 @@ __device__ __forceinline__ unsigned resizePixel(const uint8_t* r0, const uint8_t
 
 #ifdef ORBX_CHAIN_STAMPS
 __device__ unsigned long long g_chainStamps[32];
-#define CSTAMP(i) do { if (tid == 0 && t == 0) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef ORBX_CHAIN_STAMP_T
+#define ORBX_CHAIN_STAMP_T 0
+#endif
+#define CSTAMP(i) do { if (tid == 0 && t == ORBX_CHAIN_STAMP_T) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chainStamps), sizeof(unsigned long long) * 32); }
 // every tile's (start, end, level | XCC_ID << 8 | CU << 16) — tools/chain_spans.py
 __device__ unsigned long long g_chainSpans[3 * 2048];
@@ -310,6 +313,93 @@ extern "C" int orbx_debug_chain_spans(unsigned long long* out) { return (int)hip
 #define CSPAN_END(lvl) do {} while (0)
 #endif
 constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
+
+// One step of a chain: the interior rectangle rd of level j (LDS, row stride ds) resized from the rectangle rs of level j - 1 (LDS, row stride
+// ss); cxs / cys = the coefficient records of rd's columns / rows.
+template <bool PACKED, int T = kChainThreads>
+__device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ResizeX* cxs, const ResizeX* cys,
+                                          const int ss, const int ds, const int tid) {
+    if constexpr (PACKED) {
+        // (the host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)  A thread owns four
+        // adjacent columns over a block of consecutive rows, so that — as in resizeTile — the horizontal pass of a source row
+        // (three LDS dwords, two v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it:
+        // ~10 vector instructions per pixel instead of ~35 byte by byte.  The regions narrow from ~50 column quads to ~20 along
+        // the chain, so threads are dealt quad-major (thread = row block * quads + quad): every step keeps most of the 512
+        // threads busy, each with few rows.  The steps of a level-7 tile re-derive ~30 k pixels; they are its critical path.
+        const int nq = (rd.w + 3) >> 2, nb = T / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
+        const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
+        if (blk < nb && yb < ye) {
+            int c0[4], c1[4];
+            u16x2 wt[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const ResizeX cx = cxs[min(x4 + k, rd.w - 1)];
+                c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
+                wt[k] = u16x2{(unsigned short)cx.a0, (unsigned short)cx.a1};
+            }
+            const int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
+            const int base = lo & ~3;
+            const unsigned sh = (unsigned)(lo & 3);
+            unsigned sel[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
+            auto hrow = [&](int srow, unsigned (&h)[4]) {
+                const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
+                const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
+                const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
+            };
+            unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
+            int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
+            for (int y = yb; y < ye; y++) {
+                const ResizeX cy = cys[y];
+                const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
+                if (s0 != have0) {
+                    if (s0 == have1) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) H0[k] = H1[k];
+                    } else hrow(s0, H0);
+                    have0 = s0;
+                }
+                if (s1 != have1) {
+                    if (s1 == have0) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) H1[k] = H0[k];
+                    } else hrow(s1, H1);
+                    have1 = s1;
+                }
+                const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
+                unsigned t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
+                const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
+                *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
+            }
+        }
+    } else {
+    // a thread owns four adjacent columns (their coefficients stay in registers) and walks down every eighth row: sixteen
+    // independent byte reads per step instead of a pixel-by-pixel chain of LDS round trips; one dword store per step
+    const int x4 = 4 * (tid & 63);
+    if (x4 < rd.w) {
+        ResizeX cx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) cx[k] = cxs[min(x4 + k, rd.w - 1)];
+#pragma unroll 2
+        for (int y = tid >> 6; y < rd.h; y += T / 64) {
+            const ResizeX cy = cys[y];
+            const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
+            const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
+            unsigned o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o |= resizePixel(r0, r1, cx[k].sx0, cx[k].sx1, cx[k].a0, cx[k].a1, cy.a0, cy.a1) << (8 * k);
+            *(unsigned*)(D + y * ds + x4) = o;      // (columns past the region's width are padding of the 4-aligned stride)
+        }
+    }
+    }
+}
+
 
 // FROM_IMAGE (k_pyr_all's form): the chains start at the caller's image instead of level 1 — the tile list then holds the tiles of
 // level 1 (one step) and of level 0 (a bordered copy) too, and the WHOLE pyramid is one launch: one frame at 640x480 no longer waits
@@ -467,85 +557,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
         const uint8_t* S = buf[(j - 1) & 1];
         uint8_t* D = buf[j & 1];
         const ResizeX *cxs = coef + off, *cys = cxs + rd.w;
-        if constexpr (PACKED) {
-            // (the host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)  A thread owns four
-            // adjacent columns over a block of consecutive rows, so that — as in resizeTile — the horizontal pass of a source row
-            // (three LDS dwords, two v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it:
-            // ~10 vector instructions per pixel instead of ~35 byte by byte.  The regions narrow from ~50 column quads to ~20 along
-            // the chain, so threads are dealt quad-major (thread = row block * quads + quad): every step keeps most of the 512
-            // threads busy, each with few rows.  The steps of a level-7 tile re-derive ~30 k pixels; they are its critical path.
-            const int nq = (rd.w + 3) >> 2, nb = kChainThreads / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
-            const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
-            if (blk < nb && yb < ye) {
-                int c0[4], c1[4];
-                u16x2 wt[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const ResizeX cx = cxs[min(x4 + k, rd.w - 1)];
-                    c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
-                    wt[k] = u16x2{(unsigned short)cx.a0, (unsigned short)cx.a1};
-                }
-                const int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
-                const int base = lo & ~3;
-                const unsigned sh = (unsigned)(lo & 3);
-                unsigned sel[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
-                auto hrow = [&](int srow, unsigned (&h)[4]) {
-                    const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
-                    const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
-                    const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
-                };
-                unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
-                int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
-                for (int y = yb; y < ye; y++) {
-                    const ResizeX cy = cys[y];
-                    const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
-                    if (s0 != have0) {
-                        if (s0 == have1) {
-#pragma unroll
-                            for (int k = 0; k < 4; k++) H0[k] = H1[k];
-                        } else hrow(s0, H0);
-                        have0 = s0;
-                    }
-                    if (s1 != have1) {
-                        if (s1 == have0) {
-#pragma unroll
-                            for (int k = 0; k < 4; k++) H1[k] = H0[k];
-                        } else hrow(s1, H1);
-                        have1 = s1;
-                    }
-                    const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
-                    unsigned t[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
-                    const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
-                    *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
-                }
-            }
-        } else {
-        // a thread owns four adjacent columns (their coefficients stay in registers) and walks down every eighth row: sixteen
-        // independent byte reads per step instead of a pixel-by-pixel chain of LDS round trips; one dword store per step
-        const int x4 = 4 * (tid & 63);
-        if (x4 < rd.w) {
-            ResizeX cx[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cx[k] = cxs[min(x4 + k, rd.w - 1)];
-#pragma unroll 2
-            for (int y = tid >> 6; y < rd.h; y += kChainThreads / 64) {
-                const ResizeX cy = cys[y];
-                const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
-                const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
-                unsigned o = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) o |= resizePixel(r0, r1, cx[k].sx0, cx[k].sx1, cx[k].a0, cx[k].a1, cy.a0, cy.a1) << (8 * k);
-                *(unsigned*)(D + y * ds + x4) = o;      // (columns past the region's width are padding of the 4-aligned stride)
-            }
-        }
-        }
+        chainStep<PACKED>(S, D, rs, rd, cxs, cys, ss, ds, tid);
         off += rd.w + rd.h;
         rs = rd; rd = rnext;
         __syncthreads();
@@ -573,6 +585,151 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     }
     CSTAMP(level);
     CSPAN_END(level);
+}
+
+// ---- region-major pyramid (orbx_device.hpp: PyrColumn): one workgroup = one region of the image through EVERY level.  The region's rectangle
+//      of the caller's image is loaded once; level j + 1's rectangle is resized from level j's in LDS (chainStep, the reference's chain of
+//      rounded u8 levels, ORBextractor.cc:1164-1219) while the bordered bytes the region owns of level j — interior dwords straight out of the
+//      LDS rectangle, border bytes mirrored (copyMakeBorder REFLECT_101, :1213-1215) — go to HBM.  Nothing is read back from HBM. ----
+#ifndef ORBX_COLS_THREADS
+#define ORBX_COLS_THREADS 512
+#endif
+constexpr int kColsThreads = ORBX_COLS_THREADS;
+template <bool PACKED>
+__global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const PyrColumn* __restrict__ cols, const ColLevels* __restrict__ lvp, int nlevels,
+                                                            const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
+                                                            uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
+    constexpr int T = kColsThreads;
+    extern __shared__ __align__(16) uint8_t lds[];
+    __shared__ ResizeX coef[kChainCoefMax];
+    // what writing a level needs, fetched with the up-front loads: read per level from memory, every level would start with an L2 round trip
+    struct LevelOut { ColOwn own; int w, h, stride, pad; long long off; };
+    __shared__ LevelOut outOf[kMaxLevels];
+    int t, fr;
+    if (!xcdChunkFrame(nFrames, t, fr)) return;
+    const int f = f0 + fr, tid = threadIdx.x;
+    const PyrColumn& pc = cols[t];
+    const ColLevels& lv = *lvp;
+    const int top = nlevels - 1;
+    LevelOut myOut{};
+    if (tid < nlevels) myOut = LevelOut{pc.own[tid], lv.w[tid], lv.h[tid], lv.pyrStride[tid], 0, lv.pyrOff[tid] + (long long)f * lv.pyrFrameBytes[tid]};
+    CSTAMP(0);
+    CSPAN_BEGIN;
+    uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // level j's rectangle lives in buf[j & 1]
+    // the rectangles of the first nine levels are read with STATIC indices: one batch of wave-uniform loads (k_pyr_chain has the reasons)
+    constexpr int kStatic = 8;
+    ChainRegion rj[kStatic + 1];
+#pragma unroll
+    for (int j = 0; j <= kStatic; j++) rj[j] = pc.region[j];
+    {
+        // ---- every load of the workgroup is issued up front: the image rectangle (aligned dwords) and the coefficient records of ALL steps
+        //      (x records of level j's rectangle, then its y records, level after level) ----
+        const ChainRegion r = rj[0];
+        const int nDw = r.w >> 2, total = nDw * r.h;
+        const uint8_t* src = img.p + (long long)f * img.frame + (long long)r.y0 * img.stride + r.x0;
+        unsigned* dst = (unsigned*)buf[0];
+        constexpr int kLoads = (kChainMaxH0 * kChainMaxW / 4 + T - 1) / T;
+        const float inv = __frcp_rn((float)nDw);
+        unsigned w[kLoads];
+#pragma unroll
+        for (int i = 0; i < kLoads; i++) {
+            const int idx = min(tid + i * T, total - 1);          // clamped: every lane loads a valid address
+            const int row = (int)(((float)idx + 0.5f) * inv), c = idx - row * nDw;      // exact: idx < 6144, the quotient is >= 0.5 / nDw away from an integer
+            const uint8_t* q = src + ((unsigned)__mul24(row, img.stride) + 4u * (unsigned)c);
+            const int x = r.x0 + 4 * c;
+            if (img.aligned && x + 3 < img.readableCols) w[i] = *(const unsigned*)q;
+            else {                                                          // a row's last dword, or an unaligned image: no byte past the row is read
+                w[i] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (x + b < img.readableCols) w[i] |= (unsigned)q[b] << (8 * b);
+            }
+        }
+        constexpr int kPerThread = (kChainCoefMax + T - 1) / T;
+        int sel[kPerThread];                                 // element of rxAll (>= 0) or ~element of ryAll (< 0); INT_MIN: no record
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) sel[k] = (int)0x80000000;
+        int off = 0;
+        auto walk = [&](const ChainRegion rr, int xo, int yo) {
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) {
+                const int i = tid + k * T - off;
+                if (i >= 0 && i < rr.w + rr.h) sel[k] = i < rr.w ? xo + rr.x0 + i : ~(yo + rr.y0 + i - rr.w);
+            }
+            off += rr.w + rr.h;
+        };
+#pragma unroll
+        for (int j = 1; j <= kStatic; j++)
+            if (j <= top) walk(rj[j], lv.rxOff[j], lv.ryOff[j]);            // wave-uniform
+        for (int j = kStatic + 1; j <= top; j++) walk(pc.region[j], lv.rxOff[j], lv.ryOff[j]);      // (more than nine levels)
+        ResizeX cv[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            const ResizeX* q = sel[k] >= 0 ? rxAll + sel[k] : ryAll + ~sel[k];
+            cv[k] = sel[k] != (int)0x80000000 ? *q : ResizeX{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++)
+            if (tid + k * T < off) coef[tid + k * T] = cv[k];
+        if (tid < nlevels) outOf[tid] = myOut;
+#pragma unroll
+        for (int i = 0; i < kLoads; i++)
+            if (tid + i * T < total) dst[tid + i * T] = w[i];
+    }
+    __syncthreads();
+    CSTAMP(1);
+    int off = 0;
+    // one level: the next level's rectangle first (the critical path), then this level's owned bytes; both only read S
+    auto doLevel = [&](const int j, const ChainRegion rs, const ChainRegion rd) {
+        const int ss = (rs.w + 3) & ~3;
+        const uint8_t* S = buf[j & 1];
+        if (j < top) {
+            const ResizeX* cxs = coef + off;
+            chainStep<PACKED, T>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + rd.w, ss, (rd.w + 3) & ~3, tid);
+            off += rd.w + rd.h;
+        }
+        const LevelOut lo = outOf[j];
+        const ColOwn own = lo.own;
+        const int w = lo.w, h = lo.h, wB = w + 2 * kEdge;
+        const int ndw = own.dw1 - own.dw0, total = ndw * (own.r1 - own.r0);
+        uint8_t* out = pyr + lo.off;
+        const int stride = lo.stride;
+        const float inv = __frcp_rn((float)(ndw > 0 ? ndw : 1));
+        for (int i = tid; i < total; i += T) {
+            // (exact: the quotient's error, ~i / ndw * 2^-22, stays below the 0.5 / ndw that separates it from an integer while total < 2^21)
+            const int rr = (int)(((float)i + 0.5f) * inv), dw = own.dw0 + (i - rr * ndw), row = own.r0 + rr;
+            const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;      // interior pixel x of that row at srow[x]
+            const int bc0 = 4 * dw, x0 = bc0 - kPadL;          // interior x of the dword's first byte (a multiple of 4, as rs.x0 is)
+            unsigned o;
+            if (x0 >= 0 && x0 + 3 < w) o = *(const unsigned*)(srow + x0);      // no reflection inside this dword
+            else {
+                o = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int bx = bc0 + k - (kPadL - kEdge);
+                    bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);      // bytes of a dword outside the bordered row are padding
+                    o |= (unsigned)srow[reflect101(bx - kEdge, w)] << (8 * k);
+                }
+            }
+            *(unsigned*)(out + (long long)row * stride + bc0) = o;
+        }
+        __syncthreads();
+        CSTAMP(j + 2);
+    };
+#pragma unroll
+    for (int j = 0; j < kStatic; j++)
+        if (j <= top) doLevel(j, rj[j], rj[j + 1]);            // workgroup-uniform
+    for (int j = kStatic; j <= top; j++) doLevel(j, pc.region[j], pc.region[j + 1 < kMaxLevels ? j + 1 : j]);      // (more than eight levels)
+    CSPAN_END(0);
+}
+
+void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const PyrColumn* cols, int nCols,
+                   const ColLevels* lv, int nlevels, const ResizeX* rx, const ResizeX* ry, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
+    SrcView sv;
+    sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
+    sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
+    if (packed) hipLaunchKernelGGL((k_pyr_cols<true>), xcdGrid(nCols, B), dim3(kColsThreads), (size_t)ldsBytes, st, sv, cols, lv, nlevels, rx, ry, pyr, bufEvenBytes, f0, B);
+    else hipLaunchKernelGGL((k_pyr_cols<false>), xcdGrid(nCols, B), dim3(kColsThreads), (size_t)ldsBytes, st, sv, cols, lv, nlevels, rx, ry, pyr, bufEvenBytes, f0, B);
 }
 
 void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,

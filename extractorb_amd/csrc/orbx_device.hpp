@@ -141,6 +141,20 @@ struct ChainTile {
     int rxOff[kMaxLevels], ryOff[kMaxLevels];     // first coefficient record of level j in the handle's x / y tables
 };
 
+// Region-major pyramid (k_pyr_cols): the image is cut into RX x RY regions; ONE workgroup builds its region of EVERY level, level after level
+// in LDS (level l + 1 is resized from the rounded pixels of level l, as the reference's chain does), and writes the bordered bytes it owns of
+// each level as it goes.  region[l] = the rectangle of level l's interior the workgroup holds (what it owns of level l, the pixels its border
+// bytes mirror, and the taps of region[l + 1]; x0 a multiple of 4); own[l] = the dword columns x rows of the BORDERED level l it writes (the
+// own rectangles of the columns partition every level).  Against the tile chains (k_pyr_chain) nothing is derived twice except the regions'
+// overlap: 640x480, 48 regions: 0.7 M pixels derived per frame instead of 6.6 M, and the longest chain of steps handles 14 k pixels, not 31 k.
+struct ColOwn { short dw0, dw1, r0, r1; };
+struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; };
+struct ColLevels {      // what the kernel needs of the level tables, by value (kernel argument: scalar loads)
+    int nlevels, pad;
+    int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];
+    long long pyrOff[kMaxLevels], pyrFrameBytes[kMaxLevels];
+};
+
 #ifdef __HIPCC__
 // The dynamically sized LDS block of a kernel.  (tools/octree_emu compiles k_octree.hip for the HOST to run it under sanitizers; its
 // shim defines this as a pointer to an exactly sized heap block, and ORBX_OCT_EMU_PAD > 0 puts poisoned red zones between the

@@ -122,11 +122,19 @@ struct FrameGeom {
     bool chainAllFits = true, chainAllPacked = true;
     int chainAllLdsBytes = 0, chainAllEvenBytes = 0;
     int chainLdsBytes = 0, chainEvenBytes = 0;   // two ping-pong region buffers able to hold the largest regions (even-level buffer first)
+    // region-major pyramid (k_pyr_cols): the image cut into RX x RY regions (row-major) of about px x px level-0 pixels, for several px:
+    // a launch takes the coarsest cut that still gives the chip enough workgroups (few frames: small regions, short chains of small steps;
+    // more frames: large regions, less overlap)
+    struct ColumnSet { int px = 0, RX = 0, RY = 0; std::vector<PyrColumn> columns; bool fit = false; int ldsBytes = 0, evenBytes = 0; };
+    std::vector<ColumnSet> colSets;          // finest first
+    bool colsPacked = false;
 };
+constexpr int kColPx[] = {40, 56, 80, 112};
 
 // Returns an empty string on success, else the reason the geometry is unsupported.
 // fuseBlur: the resize tiles of levels >= 2 also carry the blur of their source level (wider staged rectangles, blur rectangles set)
-inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, bool fuseBlur = false) {
+// colPx: side (level-0 pixels) of the regions of the region-major pyramid (0: the sizes of kColPx)
+inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, bool fuseBlur = false, int colPx = 0) {
     g = FrameGeom();
     g.rows = rows; g.cols = cols; g.nlevels = t.nlevels;
     for (int l = 0; l < t.nlevels; l++) {
@@ -350,6 +358,88 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         };
         g.chainPacked = packedFrom(2);
         g.chainAllPacked = g.chainPacked && (t.nlevels < 3 || packedFrom(1));
+    }
+    // ---- region-major pyramid (k_pyr_cols, orbx_device.hpp: PyrColumn): RX x RY regions; per region and level the owned part of the bordered
+    //      level (the regions' parts partition its dword columns and rows) and the interior rectangle held in LDS, coarsest level first:
+    //      what the owned bytes show (clamped and reflected exactly as the kernel does) joined with the taps of the next level's rectangle ----
+    if (t.nlevels >= 2) {
+        auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
+        const int top = t.nlevels - 1;
+        auto buildCols = [&](const int px) {
+        FrameGeom::ColumnSet cs;
+        const int RX = std::max(1, (cols + px / 2) / px), RY = std::max(1, (rows + px / 2) / px);
+        cs.px = px; cs.RX = RX; cs.RY = RY;
+        bool fits = true;
+        int maxEven = 0, maxOdd = 0;
+        for (int cy = 0; cy < RY; cy++)
+            for (int cx = 0; cx < RX; cx++) {
+                PyrColumn c{};
+                int x0 = 0, x1 = -1, y0 = 0, y1 = -1;      // region of the level above the one in hand
+                int coefs = 0;
+                for (int l = top; l >= 0; l--) {
+                    const LevelGeom& L = g.lv[l];
+                    const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
+                    // the INTERIOR is cut evenly (x cuts at multiples of 4: dword boundaries of the bordered rows), so that a region's parts of
+                    // successive levels lie above each other; the border frame goes to the outer regions
+                    auto cutX = [&](int i) { return i <= 0 ? 0 : (i >= RX ? nd : (kPadL + (int)(((long long)i * L.w / RX) & ~3LL)) / 4); };
+                    auto cutY = [&](int i) { return i <= 0 ? 0 : (i >= RY ? L.pyrRows : kEdge + (int)((long long)i * L.h / RY)); };
+                    const int dwA = cutX(cx), dwB = cutX(cx + 1), rA = cutY(cy), rB = cutY(cy + 1);
+                    c.own[l] = ColOwn{(short)dwA, (short)dwB, (short)rA, (short)rB};
+                    int nx0 = 1 << 30, nx1 = -1, ny0 = 1 << 30, ny1 = -1;
+                    if (dwB > dwA && rB > rA) {
+                        for (int b = 4 * dwA; b < 4 * dwB; b++) {
+                            int bx = b - (kPadL - kEdge);
+                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                            const int v = refl(bx - kEdge, L.w);
+                            nx0 = std::min(nx0, v); nx1 = std::max(nx1, v);
+                        }
+                        for (int r = rA; r < rB; r++) {
+                            const int v = refl(r - kEdge, L.h);
+                            ny0 = std::min(ny0, v); ny1 = std::max(ny1, v);
+                        }
+                    }
+                    if (l < top && x1 >= x0 && y1 >= y0) {      // taps of the rectangle of level l + 1
+                        const std::vector<ResizeX>& X = g.rx[l + 1];
+                        const std::vector<ResizeX>& Y = g.ry[l + 1];
+                        for (int x = x0; x <= x1; x++) { nx0 = std::min(nx0, (int)std::min(X[x].sx0, X[x].sx1)); nx1 = std::max(nx1, (int)std::max(X[x].sx0, X[x].sx1)); }
+                        for (int y = y0; y <= y1; y++) { ny0 = std::min(ny0, (int)std::min(Y[y].sx0, Y[y].sx1)); ny1 = std::max(ny1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
+                    }
+                    if (nx1 < nx0 || ny1 < ny0) { nx0 = nx1 = 0; ny0 = ny1 = 0; }      // (a region that owns nothing of this level and feeds nothing)
+                    nx0 &= ~3;                                // aligned dwords of the owned bytes are aligned dwords of the LDS rectangle
+                    int w = nx1 - nx0 + 1;
+                    if (l == 0) w = (w + 3) & ~3;             // the loaded rectangle: whole dwords (the kernel never reads past an image row)
+                    const int hh = ny1 - ny0 + 1, bytes = ((w + 3) & ~3) * hh;
+                    c.region[l] = ChainRegion{(short)nx0, (short)ny0, (short)w, (short)hh};
+                    if (w > kChainMaxW || (l == 0 && bytes > kChainMaxW * kChainMaxH0)) fits = false;
+                    if (l & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
+                    if (l >= 1) coefs += w + hh;
+                    x0 = nx0; x1 = std::min(nx0 + w - 1, L.w - 1); y0 = ny0; y1 = ny1;
+                    if (l == 0) x1 = nx1;
+                }
+                if (coefs > kChainCoefMax) fits = false;
+                cs.columns.push_back(c);
+            }
+        cs.evenBytes = (maxEven + 15) & ~15;
+        cs.ldsBytes = cs.evenBytes + ((maxOdd + 15) & ~15) + 32;
+        cs.fit = fits;
+        return cs;
+        };
+        if (colPx > 0) g.colSets.push_back(buildCols(colPx));
+        else for (int px : kColPx) g.colSets.push_back(buildCols(px));
+        bool packed = true;      // the packed horizontal pass: the 8 taps of any four adjacent columns (region columns start anywhere) within 8 source bytes
+        for (int l = 1; l <= top && packed; l++) {
+            const std::vector<ResizeX>& X = g.rx[l];
+            const int w = g.lv[l].w;
+            for (int x = 0; x < w; x++) {
+                int lo = 1 << 30, hi = -1;
+                for (int k = 0; k < 4; k++) {
+                    const ResizeX& cc = X[std::min(x + k, w - 1)];
+                    lo = std::min(lo, (int)std::min(cc.sx0, cc.sx1)); hi = std::max(hi, (int)std::max(cc.sx0, cc.sx1));
+                }
+                if (hi - lo > 7) { packed = false; break; }
+            }
+        }
+        g.colsPacked = packed;
     }
     return std::string();
 }

@@ -21,7 +21,10 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            ({"ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 103), ({"ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            ({"ORBX_OCT_THREADS": "1024", "ORBX_OCT_ROOMY": "1"}, 8, 108),
            # the pyramid of a single frame as two launches (k_pyr_first + chains from level 1) and as one launch per level
-           ({"ORBX_PYR_ALL_WGS": "-1"}, 8, 109), ({"ORBX_PYR_CHAIN": "0"}, 8, 110),
+           ({"ORBX_PYR_COLS": "0", "ORBX_PYR_ALL_WGS": "-1"}, 8, 109), ({"ORBX_PYR_COLS": "0", "ORBX_PYR_CHAIN": "0"}, 8, 110),
+           # ... as one launch tile by tile (the default before the region-major pyramid), and region by region with the coarser cuts
+           ({"ORBX_PYR_COLS": "0"}, 8, 117), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "56"}, 8, 118), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "112"}, 8, 119),
+           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_RESIZE_BYTEWISE": "1", "ORBX_LDS_POLLUTE": "201"}, 8, 120),
            # every device allocation of the handle filled with a byte pattern: nothing may depend on what hipMalloc returns
            ({"ORBX_POISON": "165"}, 8, 111), ({"ORBX_POISON": "255"}, 8, 112),
            # ... nor on what the previous workgroup left in LDS (every CU's LDS filled with a byte in front of every kernel)

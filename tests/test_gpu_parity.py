@@ -264,14 +264,15 @@ def test_device_path_with_padded_rows_and_frames():
         assert d_lc[f].cpu().numpy().tolist() == [len(o.level_keypoints(l)) for l in range(8)]
 
 
-@pytest.mark.parametrize("form", ["default", "ORBX_PYR_ALL_WGS=-1"])
+@pytest.mark.parametrize("form", ["default", "ORBX_PYR_COLS=0", "ORBX_PYR_COLS=0,ORBX_PYR_ALL_WGS=-1", "ORBX_PYR_COLS=1,ORBX_PYR_COL_PX=112"])
 @pytest.mark.parametrize("B,offset,stride", [(1, 1, 643), (2, 3, 641), (3, 2, 650), (1, 0, 640)])
 def test_device_path_with_unaligned_pointer_and_stride(B, offset, stride, form, monkeypatch):
     """cv::Mat ROIs handed over on the device: a base pointer and a row step that are not multiples of 4 (every pyramid form stages
     through aligned dwords when it can and must fall back to byte reads here, never reading past a row of the caller's buffer)."""
     import torch
     if form != "default":
-        monkeypatch.setenv(*form.split("="))
+        for kv in form.split(","):
+            monkeypatch.setenv(*kv.split("="))
     rows, cols = 480, 640
     fstride = stride * rows + 5
     frames = synth.frames("noise", 31, B, rows, cols)
@@ -349,12 +350,14 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
-                                          ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_ALL_WGS", "-1"), ("ORBX_PYR_CHAIN", "0")])
+                                          ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1"),
+                                          ("ORBX_PYR_COLS,ORBX_PYR_ALL_WGS", "0,-1"), ("ORBX_PYR_COLS,ORBX_PYR_CHAIN", "0,0")])
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid of
-    # a small batch is one launch (from the image), two (level 0/1, then chains from level 1) or one per level; the host picks by
-    # batch size / image area / tap geometry, and every choice must give the reference result
-    monkeypatch.setenv(switch, value)
+    # a small batch is one launch region by region (round 3), one launch tile by tile (from the image), two (level 0/1, then chains from
+    # level 1) or one per level; the host picks by batch size / image area / tap geometry, and every choice must give the reference result
+    for sw, v in zip(switch.split(","), value.split(",")):
+        monkeypatch.setenv(sw, v)
     for shape, nf, variant in (((480, 640), 1000, "noise"), ((333, 517), 700, "textured"), ((480, 640), 1200, "natural")):
         img = synth.frames(variant, 21, 1, *shape)[0]
         o, want = oracle_run(img, nf)
@@ -459,3 +462,31 @@ def test_small_batches_around_the_leaf_table_limit(B):
         for f in range(B):
             o, want = oracle_run(src[f], 1000)
             assert_same_result(out[f][:3], want, "B=%d rep %d frame %d" % (B, rep, f))
+
+
+@pytest.mark.parametrize("px", [40, 56, 80, 112])
+def test_region_major_pyramid_every_cut(px, monkeypatch):
+    """k_pyr_cols (one workgroup = one region of the image through every level) with each of the region sizes the host chooses from, forced
+    for every batch size: every bordered level of every frame against the oracle (ORBextractor.cc:1164-1219 incl. copyMakeBorder), then the
+    final arrays.  Shapes: the benchmark's, an odd one (partial dwords at the right edge, regions of unequal size), 1080p; a batch; twelve
+    levels at scale 1.1 (more levels than the kernel's unrolled ones); scale 2.0 (byte-gather steps); two levels."""
+    monkeypatch.setenv("ORBX_PYR_COLS", "1")
+    monkeypatch.setenv("ORBX_PYR_COL_PX", str(px))
+    for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "natural", {}),
+                                   ((480, 640), 900, "natural", dict(nlevels=12, sf=1.1)), ((600, 800), 500, "noise", dict(nlevels=3, sf=2.0)),
+                                   ((241, 322), 300, "textured", dict(nlevels=2, sf=1.2))):
+        nlevels, sf = kw.get("nlevels", 8), kw.get("sf", 1.2)
+        img = synth.frames(variant, 51, 1, *shape)[0]
+        o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
+        ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
+        mono, k, d, lvl = ex(img, None, (0, 0))
+        check_stages(ex, o, lvl, nlevels)
+        assert_same_result((mono, k, d), want, "px %d %s %s" % (px, shape, kw))
+    frames = synth.frames("noise", 52, 5, 480, 640)
+    ex = X.ORBextractor(1000, max_batch=5)
+    out = ex.extract_batch(frames)
+    for f in range(5):
+        o, want = oracle_run(frames[f], 1000)
+        assert_same_result(out[f][:3], want, "px %d batch frame %d" % (px, f))
+        for l in range(8):
+            assert np.array_equal(ex.image_pyramid_level(l, frame=f, bordered=True), o.level(l, bordered=True)), "frame %d level %d" % (f, l)
