@@ -591,15 +591,15 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
 //      of the caller's image is loaded once; level j + 1's rectangle is resized from level j's in LDS (chainStep, the reference's chain of
 //      rounded u8 levels, ORBextractor.cc:1164-1219) while the bordered bytes the region owns of level j — interior dwords straight out of the
 //      LDS rectangle, border bytes mirrored (copyMakeBorder REFLECT_101, :1213-1215) — go to HBM.  Nothing is read back from HBM. ----
-#ifndef ORBX_COLS_THREADS
-#define ORBX_COLS_THREADS 512
-#endif
-constexpr int kColsThreads = ORBX_COLS_THREADS;
-template <bool PACKED>
-__global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const PyrColumn* __restrict__ cols, const ColLevels* __restrict__ lvp, int nlevels,
-                                                            const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
+// A level = two jobs that only READ its rectangle: resizing the next level's rectangle out of it (the chain every later level waits for) and
+// writing the owned bordered bytes to HBM.  The first TD of the T threads do the former, the rest the latter, side by side (one after the
+// other in every thread, a 40-px region's level took 1.0 us, of which 0.36 the write).  TD == T: every thread does both (more frames than
+// the chip has room for at once: no thread should idle).
+template <bool PACKED, int T, int TD>
+__global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __restrict__ cols, const ColLevels* __restrict__ lvp, int nlevels,
+                                                            const ResizeX* __restrict__ colCoef, int coefSlot,
                                                             uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
-    constexpr int T = kColsThreads;
+    static_assert(TD <= T && TD % 64 == 0 && (T - TD) % 64 == 0, "roles are whole waves");
     extern __shared__ __align__(16) uint8_t lds[];
     __shared__ ResizeX coef[kChainCoefMax];
     // what writing a level needs, fetched with the up-front loads: read per level from memory, every level would start with an L2 round trip
@@ -633,44 +633,29 @@ __global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const Py
         unsigned w[kLoads];
 #pragma unroll
         for (int i = 0; i < kLoads; i++) {
+            w[i] = 0;
+            if (i * T < total) {                                  // workgroup-uniform: a small rectangle issues (and computes the addresses of) few loads
             const int idx = min(tid + i * T, total - 1);          // clamped: every lane loads a valid address
             const int row = (int)(((float)idx + 0.5f) * inv), c = idx - row * nDw;      // exact: idx < 6144, the quotient is >= 0.5 / nDw away from an integer
             const uint8_t* q = src + ((unsigned)__mul24(row, img.stride) + 4u * (unsigned)c);
             const int x = r.x0 + 4 * c;
             if (img.aligned && x + 3 < img.readableCols) w[i] = *(const unsigned*)q;
             else {                                                          // a row's last dword, or an unaligned image: no byte past the row is read
-                w[i] = 0;
 #pragma unroll
                 for (int b = 0; b < 4; b++)
                     if (x + b < img.readableCols) w[i] |= (unsigned)q[b] << (8 * b);
             }
+            }
         }
         constexpr int kPerThread = (kChainCoefMax + T - 1) / T;
-        int sel[kPerThread];                                 // element of rxAll (>= 0) or ~element of ryAll (< 0); INT_MIN: no record
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) sel[k] = (int)0x80000000;
-        int off = 0;
-        auto walk = [&](const ChainRegion rr, int xo, int yo) {
-#pragma unroll
-            for (int k = 0; k < kPerThread; k++) {
-                const int i = tid + k * T - off;
-                if (i >= 0 && i < rr.w + rr.h) sel[k] = i < rr.w ? xo + rr.x0 + i : ~(yo + rr.y0 + i - rr.w);
-            }
-            off += rr.w + rr.h;
-        };
-#pragma unroll
-        for (int j = 1; j <= kStatic; j++)
-            if (j <= top) walk(rj[j], lv.rxOff[j], lv.ryOff[j]);            // wave-uniform
-        for (int j = kStatic + 1; j <= top; j++) walk(pc.region[j], lv.rxOff[j], lv.ryOff[j]);      // (more than nine levels)
+        const int nCoef = pc.nCoef;
+        const ResizeX* mine = colCoef + (size_t)t * (size_t)coefSlot;
         ResizeX cv[kPerThread];
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            const ResizeX* q = sel[k] >= 0 ? rxAll + sel[k] : ryAll + ~sel[k];
-            cv[k] = sel[k] != (int)0x80000000 ? *q : ResizeX{0, 0, 0, 0};
-        }
+        for (int k = 0; k < kPerThread; k++) cv[k] = tid + k * T < nCoef ? mine[tid + k * T] : ResizeX{0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < kPerThread; k++)
-            if (tid + k * T < off) coef[tid + k * T] = cv[k];
+            if (tid + k * T < nCoef) coef[tid + k * T] = cv[k];
         if (tid < nlevels) outOf[tid] = myOut;
 #pragma unroll
         for (int i = 0; i < kLoads; i++)
@@ -683,11 +668,16 @@ __global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const Py
     auto doLevel = [&](const int j, const ChainRegion rs, const ChainRegion rd) {
         const int ss = (rs.w + 3) & ~3;
         const uint8_t* S = buf[j & 1];
+        constexpr int TW = TD < T ? T - TD : T;      // threads of the writing role
         if (j < top) {
             const ResizeX* cxs = coef + off;
-            chainStep<PACKED, T>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + rd.w, ss, (rd.w + 3) & ~3, tid);
+            if (tid < TD) chainStep<PACKED, TD>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + rd.w, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
             off += rd.w + rd.h;
         }
+        // (the last level has nothing to derive: every thread writes)
+        const bool everyone = TD == T || j == top;
+        const int wtid = everyone ? tid : tid - TD, wstep = everyone ? T : TW;
+        if (wtid >= 0) {
         const LevelOut lo = outOf[j];
         const ColOwn own = lo.own;
         const int w = lo.w, h = lo.h, wB = w + 2 * kEdge;
@@ -695,7 +685,7 @@ __global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const Py
         uint8_t* out = pyr + lo.off;
         const int stride = lo.stride;
         const float inv = __frcp_rn((float)(ndw > 0 ? ndw : 1));
-        for (int i = tid; i < total; i += T) {
+        for (int i = wtid; i < total; i += wstep) {
             // (exact: the quotient's error, ~i / ndw * 2^-22, stays below the 0.5 / ndw that separates it from an integer while total < 2^21)
             const int rr = (int)(((float)i + 0.5f) * inv), dw = own.dw0 + (i - rr * ndw), row = own.r0 + rr;
             const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;      // interior pixel x of that row at srow[x]
@@ -713,6 +703,7 @@ __global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const Py
             }
             *(unsigned*)(out + (long long)row * stride + bc0) = o;
         }
+        }
         __syncthreads();
         CSTAMP(j + 2);
     };
@@ -723,13 +714,26 @@ __global__ __launch_bounds__(kColsThreads) void k_pyr_cols(SrcView img, const Py
     CSPAN_END(0);
 }
 
+// variant: 0 = 768 threads (512 derive), 1 = 512 (256 derive), 2 = 512 (every thread both jobs), 3 = 256 (both jobs)
 void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const PyrColumn* cols, int nCols,
-                   const ColLevels* lv, int nlevels, const ResizeX* rx, const ResizeX* ry, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
+                   const ColLevels* lv, int nlevels, const ResizeX* colCoef, int coefSlot, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed,
+                   int variant, int f0, int B) {
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
-    if (packed) hipLaunchKernelGGL((k_pyr_cols<true>), xcdGrid(nCols, B), dim3(kColsThreads), (size_t)ldsBytes, st, sv, cols, lv, nlevels, rx, ry, pyr, bufEvenBytes, f0, B);
-    else hipLaunchKernelGGL((k_pyr_cols<false>), xcdGrid(nCols, B), dim3(kColsThreads), (size_t)ldsBytes, st, sv, cols, lv, nlevels, rx, ry, pyr, bufEvenBytes, f0, B);
+#define ORBX_COLS_LAUNCH(P, T, TD) hipLaunchKernelGGL((k_pyr_cols<P, T, TD>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, bufEvenBytes, f0, B)
+    if (packed) {
+        if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
+        else if (variant == 1) ORBX_COLS_LAUNCH(true, 512, 256);
+        else if (variant == 2) ORBX_COLS_LAUNCH(true, 512, 512);
+        else ORBX_COLS_LAUNCH(true, 256, 256);
+    } else {
+        if (variant == 0) ORBX_COLS_LAUNCH(false, 768, 512);
+        else if (variant == 1) ORBX_COLS_LAUNCH(false, 512, 256);
+        else if (variant == 2) ORBX_COLS_LAUNCH(false, 512, 512);
+        else ORBX_COLS_LAUNCH(false, 256, 256);
+    }
+#undef ORBX_COLS_LAUNCH
 }
 
 void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,

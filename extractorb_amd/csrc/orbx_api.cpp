@@ -26,7 +26,7 @@ size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchLdsPollute(hipStream_t, int, int, unsigned*);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
-void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
+void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables);
@@ -130,10 +130,13 @@ struct orbx_handle {
     ChainTile* d_chainAll = nullptr;    // tiles of the one-launch pyramid (smallest batches)
     PyrColumn* d_cols = nullptr;        // regions of the region-major pyramid (k_pyr_cols)
     size_t colsCap = 0, colsOff[8] = {};   // first column of each cut of the geometry in d_cols
+    ResizeX* d_colCoef = nullptr;       // the regions' coefficient lists, cut after cut
+    size_t colCoefCap = 0, colCoefOff[8] = {};
     ColLevels* d_colLevels = nullptr;
     int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
     int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
     long long pyrColsWgs = 0;           // ORBX_PYR_COLS_WGS: largest grid it is preferred for (0: default)
+    int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
     long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
     size_t chainCap = 0;
     bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
@@ -233,7 +236,7 @@ int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_cols, h->d_colLevels, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
                    h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -302,13 +305,16 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
             for (int j = 0; j < kMaxLevels; j++) { c.rxOff[j] = j < g.nlevels ? g.lv[j].rxOff : 0; c.ryOff[j] = j < g.nlevels ? g.lv[j].ryOff : 0; }
         }
     {
-        size_t n = 0;
+        size_t n = 0, nc = 0;
         for (FrameGeom::ColumnSet& cs : g.colSets) {
-            if (n + cs.columns.size() > h->colsCap) cs.fit = false;      // (a region size far below the default ones: the other forms serve)
+            if (n + cs.columns.size() > h->colsCap || nc + cs.coef.size() > h->colCoefCap) cs.fit = false;      // (a region size far below the default ones: the other forms serve)
             if (!cs.fit) continue;
             HIP_TRY(h, hipMemcpy(h->d_cols + n, cs.columns.data(), sizeof(PyrColumn) * cs.columns.size(), hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(h->d_colCoef + nc, cs.coef.data(), sizeof(ResizeX) * cs.coef.size(), hipMemcpyHostToDevice));
             h->colsOff[&cs - g.colSets.data()] = n;
+            h->colCoefOff[&cs - g.colSets.data()] = nc;
             n += cs.columns.size();
+            nc += cs.coef.size();
         }
         ColLevels c{};
         c.nlevels = g.nlevels;
@@ -424,21 +430,23 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
                          (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
         // ... or, with far less arithmetic, region by region: one workgroup takes a region of the image through every level
-        // (the coarsest cut that still gives the chip ~3/4 workgroup per CU, else the finest; while the coarsest cut stays below ~3 per CU:
-        // 640x480: 1 frame 40-px regions 46.0 -> 44.4 us, 2: 56 px 53.5 -> 49.3, 8: 112 px 93 -> 75, 32: 193 -> 176; 64 frames: the per-level launches win)
+        // (the coarsest cut that still gives the chip ~3/4 workgroup per CU, else the finest; while the coarsest cut stays below ~12 per CU.
+        // 640x480, us per call, tile forms -> this: 1 frame (40-px regions) 46.0 -> 40.9, 2 (56 px) 53.5 -> 45.7, 4: 66.2 -> 58.8, 8 (112 px): 93.4 -> 71.2,
+        // 16: 133 -> 113, 32: 193 -> 172, 64: 309 -> 293, 128: 588 -> 582; 256 frames: 1043 -> 1062, the per-level launches win)
         const FrameGeom::ColumnSet* cs = nullptr;
         if (h->pyrCols != 0)
             for (const FrameGeom::ColumnSet& c : g.colSets) {
                 if (!c.fit || c.ldsBytes > 60 * 1024) continue;
                 if (!cs || (long long)c.columns.size() * Bn >= 3LL * h->numCUs / 4) cs = &c;
             }
-        if (cs && h->pyrCols < 0 && (long long)cs->columns.size() * Bn > (h->pyrColsWgs > 0 ? h->pyrColsWgs : 3LL * h->numCUs)) cs = nullptr;
+        if (cs && h->pyrCols < 0 && (long long)cs->columns.size() * Bn > (h->pyrColsWgs > 0 ? h->pyrColsWgs : 12LL * h->numCUs)) cs = nullptr;
         if (cs && h->pyrCols < 0 && h->fuseBlur) cs = nullptr;      // ORBX_FUSE_BLUR=1 asks for the per-level launches (which then carry the blur)
         if (cs) {
             Prof p(h, S_RESIZE, st);
             pollute(st);
             launchPyrCols(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_cols + h->colsOff[cs - g.colSets.data()], (int)cs->columns.size(), h->d_colLevels, g.nlevels,
-                          h->d_rx, h->d_ry, h->d_pyr, cs->ldsBytes, cs->evenBytes, g.colsPacked && !h->resizeBytewise, f0, Bn);
+                          h->d_colCoef + h->colCoefOff[cs - g.colSets.data()], cs->coefSlot, h->d_pyr, cs->ldsBytes, cs->evenBytes, g.colsPacked && !h->resizeBytewise,
+                          h->colsVariant >= 0 ? h->colsVariant : 1, f0, Bn);
         } else if (all) {
             Prof p(h, S_RESIZE, st);
             pollute(st);
@@ -738,9 +746,12 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->pyrCols = getenv("ORBX_PYR_COLS") ? atoi(getenv("ORBX_PYR_COLS")) : -1;
     h->colPx = getenv("ORBX_PYR_COL_PX") ? atoi(getenv("ORBX_PYR_COL_PX")) : 0;
     h->pyrColsWgs = getenv("ORBX_PYR_COLS_WGS") ? atoll(getenv("ORBX_PYR_COLS_WGS")) : 0;
+    h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);
+    h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)
     h->colsCap = roomy(h->colsCap);
+    CREATE_ALLOC(h->d_colCoef, sizeof(ResizeX) * h->colCoefCap);
     CREATE_ALLOC(h->d_cols, sizeof(PyrColumn) * h->colsCap);
     CREATE_ALLOC(h->d_colLevels, sizeof(ColLevels));
     h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);

@@ -148,7 +148,9 @@ struct ChainTile {
 // own rectangles of the columns partition every level).  Against the tile chains (k_pyr_chain) nothing is derived twice except the regions'
 // overlap: 640x480, 48 regions: 0.7 M pixels derived per frame instead of 6.6 M, and the longest chain of steps handles 14 k pixels, not 31 k.
 struct ColOwn { short dw0, dw1, r0, r1; };
-struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; };
+struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; int nCoef, pad; };   // nCoef: coefficient records of all its steps
+// (the records - x records of level 1's rectangle, its y records, level 2's ... - are laid out per region by the host: the kernel copies
+// region t's list from coef[t * slot ..], one coalesced pass, instead of working out per thread which record of which table a slot holds)
 struct ColLevels {      // what the kernel needs of the level tables, by value (kernel argument: scalar loads)
     int nlevels, pad;
     int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];

@@ -125,7 +125,14 @@ struct FrameGeom {
     // region-major pyramid (k_pyr_cols): the image cut into RX x RY regions (row-major) of about px x px level-0 pixels, for several px:
     // a launch takes the coarsest cut that still gives the chip enough workgroups (few frames: small regions, short chains of small steps;
     // more frames: large regions, less overlap)
-    struct ColumnSet { int px = 0, RX = 0, RY = 0; std::vector<PyrColumn> columns; bool fit = false; int ldsBytes = 0, evenBytes = 0; };
+    struct ColumnSet {
+        int px = 0, RX = 0, RY = 0;
+        std::vector<PyrColumn> columns;
+        bool fit = false;
+        int ldsBytes = 0, evenBytes = 0;
+        int coefSlot = 0;                    // records per region in coef (the largest list, rounded up to 8)
+        std::vector<ResizeX> coef;           // columns.size() * coefSlot
+    };
     std::vector<ColumnSet> colSets;          // finest first
     bool colsPacked = false;
 };
@@ -417,8 +424,22 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (l == 0) x1 = nx1;
                 }
                 if (coefs > kChainCoefMax) fits = false;
+                c.nCoef = coefs;
+                if (coefs > cs.coefSlot) cs.coefSlot = coefs;
                 cs.columns.push_back(c);
             }
+        cs.coefSlot = (cs.coefSlot + 7) & ~7;
+        if (fits) {
+            cs.coef.assign(cs.columns.size() * (size_t)cs.coefSlot, ResizeX{0, 0, 0, 0});
+            for (size_t i = 0; i < cs.columns.size(); i++) {
+                ResizeX* q = cs.coef.data() + i * (size_t)cs.coefSlot;
+                for (int l = 1; l <= top; l++) {
+                    const ChainRegion& r = cs.columns[i].region[l];
+                    for (int x = 0; x < r.w; x++) *q++ = g.rx[l][r.x0 + x];
+                    for (int y = 0; y < r.h; y++) *q++ = g.ry[l][r.y0 + y];
+                }
+            }
+        }
         cs.evenBytes = (maxEven + 15) & ~15;
         cs.ldsBytes = cs.evenBytes + ((maxOdd + 15) & ~15) + 32;
         cs.fit = fits;
