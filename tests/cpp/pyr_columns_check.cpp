@@ -1,0 +1,146 @@
+// Host-side check of the region-major pyramid's tables (orbx_geometry.hpp: FrameGeom::colSets, what k_pyr_cols runs from), no GPU:
+//  1. the regions' `own` rectangles partition every bordered level (each dword column x row exactly once);
+//  2. a scalar replay of the kernel's data flow — per region: load region[0] of the image, resize region[l + 1] out of region[l] with the
+//     level's coefficient records taken from the region's own list (cv::resize 8u bilinear arithmetic, ORBextractor.cc:1183-1197), write the
+//     owned bytes of each level with the clamp / REFLECT_101 mapping of copyMakeBorder (:1213-1215) — assembles exactly the pyramid that a
+//     plain level-by-level resize of whole levels with the same tables gives, and never reads outside a rectangle it holds;
+//  3. the limits the kernel relies on (x0 % 4 == 0, widths, coefficient count, LDS bytes).
+// usage: pyr_columns_check <cols> <rows> <nlevels> <scaleFactor>      prints "ok ..." and exits 0, or the first violation and exits 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+#include "orbx_geometry.hpp"
+
+using namespace orbx;
+
+static int refl(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; }
+static unsigned resizePx(int p00, int p01, int p10, int p11, const ResizeX& cx, const ResizeX& cy) {
+    const int h0 = p00 * cx.a0 + p01 * cx.a1, h1 = p10 * cx.a0 + p11 * cx.a1;
+    return (unsigned)((((cy.a0 * (h0 >> 4)) >> 16) + ((cy.a1 * (h1 >> 4)) >> 16) + 2) >> 2);
+}
+#define FAIL(...) do { printf(__VA_ARGS__); printf("\n"); return 1; } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 5) return 2;
+    const int cols = atoi(argv[1]), rows = atoi(argv[2]), nlevels = atoi(argv[3]);
+    const float sf = (float)atof(argv[4]);
+    ScaleTables t = makeScaleTables(1000, sf, nlevels);
+    FrameGeom g;
+    const std::string why = makeFrameGeom(t, rows, cols, g);
+    if (!why.empty()) { printf("rejected: %s\n", why.c_str()); return 0; }
+    layoutArenas(g, 1);
+    // the image and the whole levels, resized level by level
+    std::vector<std::vector<uint8_t>> lvl(nlevels);
+    lvl[0].resize((size_t)cols * rows);
+    unsigned seed = 12345u;
+    for (auto& p : lvl[0]) { seed = seed * 1664525u + 1013904223u; p = (uint8_t)(seed >> 24); }
+    for (int l = 1; l < nlevels; l++) {
+        const int w = g.lv[l].w, h = g.lv[l].h, sw = g.lv[l - 1].w;
+        lvl[l].resize((size_t)w * h);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const ResizeX cx = g.rx[l][x], cy = g.ry[l][y];
+                const uint8_t* s = lvl[l - 1].data();
+                lvl[l][(size_t)y * w + x] = (uint8_t)resizePx(s[(size_t)cy.sx0 * sw + cx.sx0], s[(size_t)cy.sx0 * sw + cx.sx1], s[(size_t)cy.sx1 * sw + cx.sx0], s[(size_t)cy.sx1 * sw + cx.sx1], cx, cy);
+            }
+    }
+    int checked = 0;
+    for (const FrameGeom::ColumnSet& cs : g.colSets) {
+        if (!cs.fit) continue;
+        if ((int)cs.columns.size() != cs.RX * cs.RY) FAIL("px %d: %zu regions for a %d x %d cut", cs.px, cs.columns.size(), cs.RX, cs.RY);
+        if (cs.ldsBytes > 64 * 1024) FAIL("px %d: %d bytes of LDS", cs.px, cs.ldsBytes);
+        std::vector<std::vector<int>> written(nlevels);      // per level: how often each (row, dword) was written
+        std::vector<std::vector<uint8_t>> out(nlevels);
+        std::vector<int> nd(nlevels);
+        for (int l = 0; l < nlevels; l++) {
+            nd[l] = (kPadL - kEdge + g.lv[l].w + 2 * kEdge + 3) / 4;
+            written[l].assign((size_t)nd[l] * g.lv[l].pyrRows, 0);
+            out[l].assign((size_t)nd[l] * 4 * g.lv[l].pyrRows, 0);
+        }
+        for (size_t ci = 0; ci < cs.columns.size(); ci++) {
+            const PyrColumn& c = cs.columns[ci];
+            const ResizeX* coef = cs.coef.data() + ci * (size_t)cs.coefSlot;
+            int off = 0, total = 0;
+            for (int l = 1; l < nlevels; l++) total += c.region[l].w + c.region[l].h;
+            if (total != c.nCoef || total > kChainCoefMax || total > cs.coefSlot) FAIL("px %d region %zu: %d coefficient records, nCoef %d, slot %d", cs.px, ci, total, c.nCoef, cs.coefSlot);
+            std::vector<uint8_t> cur, nxt;
+            for (int l = 0; l < nlevels; l++) {
+                const ChainRegion r = c.region[l];
+                const int w = g.lv[l].w, h = g.lv[l].h;
+                if (r.x0 & 3) FAIL("px %d region %zu level %d: x0 %d not a multiple of 4", cs.px, ci, l, r.x0);
+                if (r.w < 1 || r.h < 1 || r.w > kChainMaxW || r.x0 < 0 || r.y0 < 0 || r.y0 + r.h > h) FAIL("px %d region %zu level %d: rectangle %d,%d %dx%d outside the %dx%d level", cs.px, ci, l, r.x0, r.y0, r.w, r.h, w, h);
+                const int stride = (r.w + 3) & ~3;
+                if ((l & 1 ? cs.ldsBytes - cs.evenBytes - 32 : cs.evenBytes) < stride * r.h) FAIL("px %d region %zu level %d: %d bytes do not fit its LDS buffer", cs.px, ci, l, stride * r.h);
+                if (l == 0) {
+                    if (r.w & 3) FAIL("px %d region %zu: loaded width %d not whole dwords", cs.px, ci, r.w);
+                    if (stride * r.h > kChainMaxW * kChainMaxH0) FAIL("px %d region %zu: %d loaded bytes", cs.px, ci, stride * r.h);
+                    cur.assign((size_t)stride * r.h, 0xEE);
+                    for (int y = 0; y < r.h; y++)
+                        for (int x = 0; x < r.w; x++)
+                            if (r.x0 + x < w) cur[(size_t)y * stride + x] = lvl[0][(size_t)(r.y0 + y) * w + r.x0 + x];      // (the kernel never reads past an image row)
+                }
+                // the owned bytes of this level out of `cur`
+                const ColOwn o = c.own[l];
+                if (o.dw0 < 0 || o.dw1 > nd[l] || o.r0 < 0 || o.r1 > g.lv[l].pyrRows || o.dw1 < o.dw0 || o.r1 < o.r0) FAIL("px %d region %zu level %d: own rectangle", cs.px, ci, l);
+                const int wB = w + 2 * kEdge;
+                for (int row = o.r0; row < o.r1; row++)
+                    for (int dw = o.dw0; dw < o.dw1; dw++) {
+                        written[l][(size_t)row * nd[l] + dw]++;
+                        const int iy = refl(row - kEdge, h);
+                        for (int k = 0; k < 4; k++) {
+                            int bx = 4 * dw + k - (kPadL - kEdge);
+                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                            const int ix = refl(bx - kEdge, w);
+                            if (ix < r.x0 || ix >= r.x0 + r.w || iy < r.y0 || iy >= r.y0 + r.h) FAIL("px %d region %zu level %d: owned byte (%d, %d) shows pixel (%d, %d) outside the held rectangle", cs.px, ci, l, row, 4 * dw + k, ix, iy);
+                            out[l][((size_t)row * nd[l] + dw) * 4 + k] = cur[(size_t)(iy - r.y0) * stride + (ix - r.x0)];
+                        }
+                    }
+                // the next level's rectangle out of `cur`, with the region's own coefficient list
+                if (l + 1 < nlevels) {
+                    const ChainRegion d = c.region[l + 1];
+                    const int ds = (d.w + 3) & ~3;
+                    nxt.assign((size_t)ds * d.h, 0xEE);
+                    const ResizeX *cxs = coef + off, *cys = cxs + d.w;
+                    for (int y = 0; y < d.h; y++)
+                        for (int x = 0; x < d.w; x++) {
+                            const ResizeX cx = cxs[x], cy = cys[y];
+                            const ResizeX gx = g.rx[l + 1][d.x0 + x], gy = g.ry[l + 1][d.y0 + y];
+                            if (cx.sx0 != gx.sx0 || cx.sx1 != gx.sx1 || cx.a0 != gx.a0 || cx.a1 != gx.a1 || cy.sx0 != gy.sx0 || cy.sx1 != gy.sx1 || cy.a0 != gy.a0 || cy.a1 != gy.a1)
+                                FAIL("px %d region %zu level %d: coefficient list differs from the level tables at (%d, %d)", cs.px, ci, l + 1, x, y);
+                            if (d.x0 + x >= g.lv[l + 1].w) continue;      // (padding columns of an aligned start are never shown)
+                            const int xs[2] = {cx.sx0, cx.sx1}, ys[2] = {cy.sx0, cy.sx1};
+                            int p[2][2];
+                            for (int a = 0; a < 2; a++)
+                                for (int b = 0; b < 2; b++) {
+                                    if (xs[b] < r.x0 || xs[b] >= r.x0 + r.w || ys[a] < r.y0 || ys[a] >= r.y0 + r.h || xs[b] >= w)
+                                        FAIL("px %d region %zu level %d: tap (%d, %d) of pixel (%d, %d) outside the held rectangle", cs.px, ci, l + 1, xs[b], ys[a], d.x0 + x, d.y0 + y);
+                                    p[a][b] = cur[(size_t)(ys[a] - r.y0) * stride + (xs[b] - r.x0)];
+                                }
+                            nxt[(size_t)y * ds + x] = (uint8_t)resizePx(p[0][0], p[0][1], p[1][0], p[1][1], cx, cy);
+                        }
+                    off += d.w + d.h;
+                    cur.swap(nxt);
+                }
+            }
+        }
+        for (int l = 0; l < nlevels; l++) {
+            const int w = g.lv[l].w, h = g.lv[l].h, wB = w + 2 * kEdge;
+            for (int row = 0; row < g.lv[l].pyrRows; row++)
+                for (int dw = 0; dw < nd[l]; dw++) {
+                    if (written[l][(size_t)row * nd[l] + dw] != 1) FAIL("px %d level %d: dword (%d, %d) written %d times", cs.px, l, row, dw, written[l][(size_t)row * nd[l] + dw]);
+                    for (int k = 0; k < 4; k++) {
+                        int bx = 4 * dw + k - (kPadL - kEdge);
+                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                        const uint8_t want = lvl[l][(size_t)refl(row - kEdge, h) * w + refl(bx - kEdge, w)];
+                        if (out[l][((size_t)row * nd[l] + dw) * 4 + k] != want) FAIL("px %d level %d: byte (%d, %d) is %d, the level-by-level pyramid has %d", cs.px, l, row, 4 * dw + k, out[l][((size_t)row * nd[l] + dw) * 4 + k], want);
+                    }
+                }
+        }
+        checked++;
+    }
+    printf("ok %dx%d %d levels scale %.2f: %d cuts\n", cols, rows, nlevels, sf, checked);
+    return 0;
+}

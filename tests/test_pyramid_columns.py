@@ -1,0 +1,45 @@
+"""Host logic of the region-major pyramid (k_pyr_cols), no GPU: tests/cpp/pyr_columns_check.cpp replays the kernel's data flow with scalar code
+from the tables orbx_geometry.hpp builds — per region the image rectangle, every level's rectangle resized out of the previous one with the
+region's own coefficient list, the owned bordered bytes — and compares the assembled pyramid with a level-by-level resize of whole levels; it
+also checks that the owned rectangles partition every bordered level, that no tap or mirrored pixel lies outside the rectangle a region holds,
+and the limits the kernel relies on.  (The GPU kernel itself against the oracle: tests/test_gpu_parity.py::test_region_major_pyramid_every_cut.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("pcc") / "pyr_columns_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "extractorb_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "pyr_columns_check.cpp"), "-o", exe])
+    return exe
+
+
+def run(exe, cols, rows, nlevels, sf):
+    r = subprocess.run([exe, str(cols), str(rows), str(nlevels), str(sf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, "%dx%d levels %d scale %s: %s" % (cols, rows, nlevels, sf, r.stdout.strip())
+    return r.stdout.strip()
+
+
+@pytest.mark.parametrize("cols,rows,nlevels,sf", [(640, 480, 8, 1.2), (752, 480, 8, 1.2), (517, 333, 8, 1.2), (1241, 376, 8, 1.2), (1920, 1080, 8, 1.2),
+                                                  (752, 480, 12, 1.1), (800, 600, 3, 2.0), (322, 241, 2, 1.2), (512, 512, 4, 1.5), (1280, 720, 8, 1.2)])
+def test_the_cuts_rebuild_the_level_by_level_pyramid(checker, cols, rows, nlevels, sf):
+    out = run(checker, cols, rows, nlevels, sf)
+    assert out.startswith("ok") and not out.endswith(": 0 cuts"), out
+
+
+def test_random_geometries(checker):
+    rng = np.random.default_rng(7)
+    ok = 0
+    for _ in range(24):
+        cols, rows = int(rng.integers(200, 1500)), int(rng.integers(200, 1000))
+        nlevels = int(rng.integers(2, 10))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
+        out = run(checker, cols, rows, nlevels, sf)
+        ok += out.startswith("ok")
+    assert ok >= 12      # (the rest are geometries orbx_create rejects: a level narrower than a FAST cell)
