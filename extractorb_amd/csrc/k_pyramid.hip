@@ -714,7 +714,8 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
     CSPAN_END(0);
 }
 
-// variant: 0 = 768 threads (512 derive), 1 = 512 (256 derive), 2 = 512 (every thread both jobs), 3 = 256 (both jobs)
+// variant: 0 = 768 threads (512 derive), 1 = 512 (256 derive), 2 = 512 (every thread both jobs), 3 = 256 (both jobs), 4 = 768 (256 derive),
+// 5 = 1024 (256 derive), 6 = 1024 (512 derive)
 void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const PyrColumn* cols, int nCols,
                    const ColLevels* lv, int nlevels, const ResizeX* colCoef, int coefSlot, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed,
                    int variant, int f0, int B) {
@@ -726,11 +727,17 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
         if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
         else if (variant == 1) ORBX_COLS_LAUNCH(true, 512, 256);
         else if (variant == 2) ORBX_COLS_LAUNCH(true, 512, 512);
+        else if (variant == 4) ORBX_COLS_LAUNCH(true, 768, 256);
+        else if (variant == 5) ORBX_COLS_LAUNCH(true, 1024, 256);
+        else if (variant == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
         else ORBX_COLS_LAUNCH(true, 256, 256);
     } else {
         if (variant == 0) ORBX_COLS_LAUNCH(false, 768, 512);
         else if (variant == 1) ORBX_COLS_LAUNCH(false, 512, 256);
         else if (variant == 2) ORBX_COLS_LAUNCH(false, 512, 512);
+        else if (variant == 4) ORBX_COLS_LAUNCH(false, 768, 256);
+        else if (variant == 5) ORBX_COLS_LAUNCH(false, 1024, 256);
+        else if (variant == 6) ORBX_COLS_LAUNCH(false, 1024, 512);
         else ORBX_COLS_LAUNCH(false, 256, 256);
     }
 #undef ORBX_COLS_LAUNCH

@@ -351,7 +351,8 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
                                           ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1"),
-                                          ("ORBX_PYR_COLS,ORBX_PYR_ALL_WGS", "0,-1"), ("ORBX_PYR_COLS,ORBX_PYR_CHAIN", "0,0")])
+                                          ("ORBX_PYR_COLS,ORBX_PYR_ALL_WGS", "0,-1"), ("ORBX_PYR_COLS,ORBX_PYR_CHAIN", "0,0")] +
+                                         [("ORBX_PYR_COLS_VARIANT", str(v)) for v in range(7)])      # every workgroup shape of k_pyr_cols
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid of
     # a small batch is one launch region by region (round 3), one launch tile by tile (from the image), two (level 0/1, then chains from
