@@ -31,7 +31,11 @@ namespace orbx {
 
 #ifdef ORBX_OCT_STAMPS
 __device__ unsigned long long g_octStamps[128];
-#define STAMP(id) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && nst < 126) { stampId[nst] = (id); stampT[nst++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long g_octSpans[2 * 16];      // (start, end) of frame 0's workgroup of every level
+#ifndef ORBX_OCT_STAMP_LEVEL
+#define ORBX_OCT_STAMP_LEVEL 0
+#endif
+#define STAMP(id) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == ORBX_OCT_STAMP_LEVEL && nst < 126) { stampId[nst] = (id); stampT[nst++] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(id) do {} while (0)
 #endif
@@ -106,6 +110,9 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 // Queued variants (large batches): 1024 and 512 threads are compiled for 8 waves per SIMD (64 VGPRs: two 1024-thread or four
 // 512-thread workgroups per CU), 256 threads for 6 (80 VGPRs, fewer values in scratch; LDS allows six such workgroups per CU
 // anyway): 179 -> 169 us per 512 frames at 640x480; the same budget on the 1024-thread variant halves its residency (1080p: 282 -> 310 us).
+#ifndef OCT_WAVE_PHASE2
+#define OCT_WAVE_PHASE2 1      // a sorted pass over at most 64 nodes runs on one wave (k_octree_body.inc)
+#endif
 #ifndef OCT_SHORT_PHASE2
 #define OCT_SHORT_PHASE2 (OCT_W <= 4)
 #endif
@@ -157,6 +164,7 @@ __device__ __forceinline__ void maxPerNode(unsigned long long* best, bool active
 extern "C" int orbx_debug_oct_stamps(unsigned long long* out128) {
     return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_octStamps), sizeof(unsigned long long) * 128);
 }
+extern "C" int orbx_debug_oct_spans(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_octSpans), sizeof(unsigned long long) * 32); }
 #endif
 
 // bytes of the node arrays of one workgroup (LDS, or a slice of the HBM arena of the _1024g variant); layout: k_octree_body.inc

@@ -170,6 +170,12 @@ struct ColLevels {      // what the kernel needs of the level tables, by value (
 #endif
 constexpr size_t kOctPad = ORBX_OCT_EMU_PAD;
 
+// LDS operations of one wave execute in issue order, so the lanes of a wave only need the COMPILER to keep the order of the stores before and
+// the loads after this point (no s_barrier).  (The host emulation of k_octree runs lanes as threads: its shim defines this as a wave barrier.)
+#ifndef ORBX_WAVE_LDS_SYNC
+#define ORBX_WAVE_LDS_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+
 // Inclusive prefix sum over the 64 lanes of a wave, every lane active: row_shr 1/2/4/8 inside the rows of 16, then lane 15 of
 // rows 0 and 2 broadcast into rows 1 and 3, lane 31 into rows 2 and 3 (DPP: six vector adds, no LDS round trip — a __shfl_up
 // ladder is six dependent ds_bpermute).  A lane with no source takes 0 (`old` of v_mov_dpp with bound_ctrl off).

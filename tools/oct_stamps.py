@@ -23,3 +23,9 @@ for i in range(n):
     if prev is not None:
         print("%-48s %8.2f us" % (names[sid], (t - prev) / 100.0))   # s_memrealtime ticks at 100 MHz
     prev = t
+sp = np.zeros(32, np.uint64)
+if hasattr(L, "orbx_debug_oct_spans") and L.orbx_debug_oct_spans(sp.ctypes.data_as(C.c_void_p)) == 0:
+    s = sp.astype(np.int64).reshape(-1, 2)
+    s = s[s[:, 0] > 0]
+    t0 = s[:, 0].min()
+    print("frame 0's workgroups, (start, end) us after the first start: " + "  ".join("L%d %.2f-%.2f" % (i, (a - t0) / 100.0, (b - t0) / 100.0) for i, (a, b) in enumerate(s)))

@@ -81,6 +81,8 @@ inline unsigned long long __ballot(int pred) {
     for (int l = 0; l < 64; l++) m |= emu::peek(s, l) << l;
     return m;
 }
+// lanes are threads here: "LDS operations of a wave execute in issue order" becomes a barrier of the wave's threads (every lane calls it)
+#define ORBX_WAVE_LDS_SYNC() do { __atomic_thread_fence(__ATOMIC_SEQ_CST); (void)emu::exchange(0); __atomic_thread_fence(__ATOMIC_SEQ_CST); } while (0)
 inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 inline int __shfl(int v, int srcLane) { return (int)(unsigned)emu::peek(emu::exchange((unsigned)v), srcLane & 63); }
