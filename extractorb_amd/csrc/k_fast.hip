@@ -160,6 +160,14 @@ extern "C" int orbx_debug_fast_clock(unsigned long long* out, int reset) {
     if (reset) return (int)hipMemset((void*)nullptr, 0, 0) + (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fastClock), out, sizeof(unsigned long long) * 2 * kFastClockSlots);
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastClock), sizeof(unsigned long long) * 2 * kFastClockSlots);
 }
+// ... and the span of every wave of frame 0 (tools/fast_spans.py): [2 * (chunk * 4 + wave)] = start, end in s_memrealtime ticks
+__device__ unsigned long long g_fastSpans[2 * 4096], g_fastMid[4 * 4096];      // (mid: staged, scored, counted, ... of a FAST wave)
+extern "C" int orbx_debug_fast_spans(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastSpans), sizeof(g_fastSpans)); }
+extern "C" int orbx_debug_fast_mid(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastMid), sizeof(g_fastMid)); }
+#define FAST_MID(which) do { const int fsI = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.z == 0 && fsI < 4096) g_fastMid[4 * fsI + (which)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FAST_SPAN(which) do { const int fsI = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.z == 0 && fsI < 4096) g_fastSpans[2 * fsI + (which)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define FAST_CLOCK_BEGIN const unsigned long long fcR0 = __builtin_amdgcn_s_memrealtime(), fcT0 = __builtin_amdgcn_s_memtime();
 #define FAST_CLOCK_END do { const unsigned long long fcT1 = __builtin_amdgcn_s_memtime(), fcR1 = __builtin_amdgcn_s_memrealtime(); \
         const unsigned fcW = (unsigned)(f * nCells + ci); \
@@ -167,6 +175,8 @@ extern "C" int orbx_debug_fast_clock(unsigned long long* out, int reset) {
 #else
 #define FAST_CLOCK_BEGIN
 #define FAST_CLOCK_END do {} while (0)
+#define FAST_SPAN(which) do {} while (0)
+#define FAST_MID(which) do {} while (0)
 #endif
 constexpr int kFastWaves = 4;
 #ifndef ORBX_FAST_WAVES
@@ -211,9 +221,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
     int chunk, fr;
     if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all cells of a frame on one XCD: the 6-px ROI overlap of neighbouring cells hits its L2
+    FAST_SPAN(0);
     if constexpr (FUSE_BLUR) {
         if (chunk >= tail.fastChunks) {                // workgroup-uniform
             blurLanes<kBlurBlockRowsSmall>(tail.items, tail.laneItem, tail.nLanes, lv, pyr, tail.blur, chunk - tail.fastChunks, f0 + fr);
+            FAST_SPAN(1);
             return;
         }
     }
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     for (int i = 0; i < (kScoreBytes + 255) / 256; i++)
         if (lane * 4 + i * 256 < kScoreBytes) *(unsigned*)(score + lane * 4 + i * 256) = 0u;
     waveLdsSync();
+    FAST_MID(0);
 
     const int npix = cw * ch;
     const int qx = 64 % cw, qy = 64 / cw;               // how (x, y) advance when the pixel index advances by 64
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     waveLdsSync();
     if (ORBX_FAST_SKIP & 2) { if (lane == 0) cellCount[(long long)f * nCells + ci] = 0u; return; }
 
+    FAST_MID(1);
     // ---- pass 2: strict local maxima, four pixels per lane (the score rows keep the tile's dword grid): nine dword
     //      reads, the 3 x 5 neighbour pairs by v_perm, packed 3-input maxima with minThFAST folded in, so
     //      "keep" is simply S > max.  Survivors are appended in raster order (lane order, then pixel order inside the
@@ -401,6 +415,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     // segments in cell order, which is the reference's vToDistributeKeys order (cell row, cell column, y, x)
     if (lane == 0) cellCount[(long long)f * nCells + ci] = (unsigned)total;
     FAST_CLOCK_END;
+    FAST_SPAN(1);
+    FAST_MID(2);
     if (total == 0) return;
     unsigned base = 0;
     unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
             }
         }
     }
+    FAST_SPAN(1);      // (diagnostic builds: the wave's end including the emit; the stamp above stays as the end of a cell without keys)
 }
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,

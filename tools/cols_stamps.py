@@ -28,3 +28,7 @@ s = s[s[:, 0] > 0]
 t0 = s[:, 0].min()
 d = (s[:, 1] - s[:, 0]) / 100.0
 print("%d workgroups: starts 0..%.2f us, duration mean %.2f max %.2f, last end %.2f us" % (len(s), (s[:, 0].max() - t0) / 100.0, d.mean(), d.max(), (s[:, 1].max() - t0) / 100.0))
+if len(s) == 192:      # 640x480 at 40-px regions: durations as the 16 x 12 grid of regions (us)
+    sp3 = sp.astype(np.int64).reshape(-1, 3)[:192]
+    dd = ((sp3[:, 1] - sp3[:, 0]) / 100.0).reshape(12, 16)
+    print("durations of the 16 x 12 regions (us):"); print(np.array2string(dd, precision=1, floatmode="fixed", max_line_width=200))
