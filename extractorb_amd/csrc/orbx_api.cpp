@@ -29,7 +29,7 @@ void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const 
 void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables);
+                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
 bool fastCanCarryBlur(int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
@@ -136,6 +136,8 @@ struct orbx_handle {
     int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
     int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
     long long pyrColsWgs = 0;           // ORBX_PYR_COLS_WGS: largest grid it is preferred for (0: default)
+    int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
+    long long fastWideWgs = 0;          // ORBX_FAST_WIDE_WGS: most cells per call it is used for (0: 4 per CU)
     int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
     long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
     size_t chainCap = 0;
@@ -506,7 +508,8 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
-                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt);
+                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
+                       h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= (h->fastWideWgs > 0 ? h->fastWideWgs : 4LL * h->numCUs)));
         }
         {
             Prof p(h, S_OCTREE, st);
@@ -750,6 +753,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->pyrCols = getenv("ORBX_PYR_COLS") ? atoi(getenv("ORBX_PYR_COLS")) : -1;
     h->colPx = getenv("ORBX_PYR_COL_PX") ? atoi(getenv("ORBX_PYR_COL_PX")) : 0;
     h->pyrColsWgs = getenv("ORBX_PYR_COLS_WGS") ? atoll(getenv("ORBX_PYR_COLS_WGS")) : 0;
+    h->fastWide = getenv("ORBX_FAST_WIDE") ? atoi(getenv("ORBX_FAST_WIDE")) : -1;
+    h->fastWideWgs = getenv("ORBX_FAST_WIDE_WGS") ? atoll(getenv("ORBX_FAST_WIDE_WGS")) : 0;
     h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);

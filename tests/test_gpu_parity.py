@@ -352,7 +352,8 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
                                           ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1"),
                                           ("ORBX_PYR_COLS,ORBX_PYR_ALL_WGS", "0,-1"), ("ORBX_PYR_COLS,ORBX_PYR_CHAIN", "0,0")] +
-                                         [("ORBX_PYR_COLS_VARIANT", str(v)) for v in range(7)])      # every workgroup shape of k_pyr_cols
+                                         [("ORBX_PYR_COLS_VARIANT", str(v)) for v in range(7)] +     # every workgroup shape of k_pyr_cols
+                                         [("ORBX_FAST_WIDE", "0"), ("ORBX_FAST_WIDE,ORBX_FAST_PREFILTER", "1,0")])      # FAST: a wave / a workgroup per cell
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid of
     # a small batch is one launch region by region (round 3), one launch tile by tile (from the image), two (level 0/1, then chains from
@@ -491,3 +492,20 @@ def test_region_major_pyramid_every_cut(px, monkeypatch):
         assert_same_result(out[f][:3], want, "px %d batch frame %d" % (px, f))
         for l in range(8):
             assert np.array_equal(ex.image_pyramid_level(l, frame=f, bordered=True), o.level(l, bordered=True)), "frame %d level %d" % (f, l)
+
+
+def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):
+    """k_fast_wide (four waves per FAST cell; default only while a call holds few cells) forced for a batch: candidates IN ORDER, every stage and the
+    final arrays of every frame against the oracle — dense, sparse (cells that fall back to minThFAST, empty cells) and natural content, with
+    and without the leaf tables (nine frames are past ORBX_LEAF_FRAMES)."""
+    monkeypatch.setenv("ORBX_FAST_WIDE", "1")
+    monkeypatch.setenv("ORBX_FAST_PREFILTER", "0")
+    for B in (3, 9):
+        frames = np.concatenate([synth.frames("noise", 7, B // 3, 480, 640), synth.frames("sparse", 8, B // 3, 480, 640), synth.frames("natural", 9, B - 2 * (B // 3), 480, 640)])
+        ex = X.ORBextractor(1000, max_batch=B)
+        out = ex.extract_batch(frames)
+        for f in range(B):
+            o, want = oracle_run(frames[f], 1000)
+            assert_same_result(out[f][:3], want, "B=%d frame %d" % (B, f))
+            for l in range(8):
+                assert np.array_equal(ex.debug_candidates(l, f), o.candidates(l)), "candidates of level %d, frame %d" % (l, f)

@@ -37,7 +37,8 @@ if len(sys.argv) > 2:
 mid = np.zeros(4 * 4096, np.uint64)
 if hasattr(L, "orbx_debug_fast_mid") and L.orbx_debug_fast_mid(mid.ctypes.data_as(C.c_void_p)) == 0:
     m = mid.astype(np.int64).reshape(-1, 4)
-    for name, sel in (("level-0 cells (waves 0..299)", range(0, 300)), ("deepest cells (waves 780..814)", range(780, 815))):
+    wide = os.environ.get("ORBX_FAST_WIDE") == "1"
+    for name, sel in ((("level-0 cells (waves 0..1199)", range(0, 1200)), ("deepest cells (waves 3120..3259)", range(3120, 3260))) if wide else (("level-0 cells (waves 0..299)", range(0, 300)), ("deepest cells (waves 780..814)", range(780, 815)))):
         rows = [(m[i, 0] - buf.astype(np.int64).reshape(-1, 2)[i, 0], m[i, 1] - m[i, 0], m[i, 2] - m[i, 1], buf.astype(np.int64).reshape(-1, 2)[i, 1] - m[i, 2]) for i in sel if m[i, 0] > 0 and m[i, 2] > 0]
         a = np.array(rows) / 100.0
         print("%s: start -> staged %.2f, score pass %.2f, NMS + count %.2f, emit %.2f us (means of %d waves)" % (name, a[:, 0].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(), len(a)))
