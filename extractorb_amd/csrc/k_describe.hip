@@ -89,6 +89,15 @@ constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 
 //   * IC_Angle: lane = patch row; the row's 31 pixels are byte-aligned with v_alignbyte and reduced with
 //     v_dot4_u32_u8 against per-row weight words (u+16 inside the disc, 0 outside) — sum(u*I) = dot(I, u+16) - 16*dot(I, 1);
 //   * rBRIEF: lane = 8 of the 256 test pairs; a ballot per group of 32 pairs packs 4 descriptor bytes of each keypoint.
+#ifdef ORBX_DESC_STAMPS
+// diagnostic build (tools/desc_spans.py): stage stamps of every wave of frame 0, s_memrealtime ticks
+__device__ unsigned long long g_descStamps[6 * 1024];
+extern "C" int orbx_debug_desc_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_descStamps), sizeof(g_descStamps)); }
+#define DSTAMP(i) do { const int dsW = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.z == 0 && dsW < 1024) g_descStamps[6 * dsW + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels,
                                                    const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                    const uint2* __restrict__ sel, int selPerFrame,
@@ -102,6 +111,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     int chunk, fr;
     if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all keypoints of a frame on one XCD: overlapping patches share its L2
     const int f = f0 + fr;
+    DSTAMP(0);
     {   // weight words of row |v| = a, bytes k = 0..31 <-> u = k - 15
         const int which = tid >> 7, a = (tid >> 3) & 15, j = tid & 7;
         unsigned w = 0;
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const int i = slot - selOff;
     const bool active = slot < selPerFrame && i < levelCount[f * nlevels + level];
     if (__ballot(active) == 0) return;
+    DSTAMP(1);
     const int gw = lv[level].w, gh = lv[level].h, pyrStride = lv[level].pyrStride, blurStride = lv[level].blurStride;
     const uint8_t* pyrL = pyr + lv[level].pyrOff + (long long)f * lv[level].pyrFrameBytes;      // wave-uniform bases:
     const uint8_t* blurL = blur + lv[level].blurOff + (long long)f * lv[level].blurFrameBytes;   // lanes add 32-bit offsets
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     kx = min(max(kx, kEdge), gw - kEdge - 1);
     ky = min(max(ky, kEdge), gh - kEdge - 1);
 
+    DSTAMP(2);
     // ---- stage both patches: raw level rows/cols +-15 (IC_Angle), blurred level rows/cols +-18 (rBRIEF) ----
     uint8_t* rawT = smem + (wave * 2 + half) * kPatchLds;
     uint8_t* blurT = rawT + kRawRows * kRawStride;
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
+    DSTAMP(3);
     // ---- IC_Angle (:75-102): integer moments over the radius-15 disc of the unblurred level ----
     int m10 = 0, m01 = 0;
     if (hl < kRawRows) {
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         const unsigned mine = half ? (unsigned)(m >> 32) : (unsigned)m;
         myWord = hl == j ? mine : myWord;
     }
+    DSTAMP(4);
     if (!active) return;
 
     // ---- placement (:1137-1158): non-lapping keys fill from the front, lapping keys from the back ----
