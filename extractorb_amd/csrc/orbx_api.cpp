@@ -158,7 +158,7 @@ struct orbx_handle {
     int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
     // small batches: per-(frame, level, root) leaf counters / best keys filled by k_fast's emit, consumed and cleared by k_octree
     // (orbx_device.hpp: LeafTables); d_leafCode = [2][nlevels][octXT] host-built x / y path codes of the current geometry
-    int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 8; 0 = off)
+    int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 128; 0 = off)
     int octSmallT = 0;             // ORBX_OCT_SMALL_T: quad-tree workgroup size of the small-batch form (0 = by the largest level quota)
     int* d_leafHist = nullptr;
     unsigned* d_leafBest = nullptr;
@@ -725,7 +725,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_sink, 64);
     CREATE_ALLOC(h->d_sel, h->selEntries * sizeof(uint2));
     if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
-    h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 8;
+    // (k_fast pays ~6 % for the tables, k_octree loses its first sweep: 640x480, us per call without -> with: 12 frames 110 -> 101, 32: 169 -> 163,
+    // 64: 306 -> 296, 128: 562 -> 556, 256: 1040 -> 1046, 512: 2040 -> 2053; 1920x1080: 16 frames 519 -> 431, 32: 904 -> 827, 128: 3108 -> 3092)
+    h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 128;
     if (h->leafFrames > max_batch) h->leafFrames = max_batch;
     if (const char* e = getenv("ORBX_OCT_SMALL_T")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) h->octSmallT = t; }
     if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree

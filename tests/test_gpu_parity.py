@@ -452,10 +452,11 @@ def test_scale_factor_two_uses_the_byte_gather_resize():
 
 
 @pytest.mark.parametrize("B", [1, 2, 7, 8, 9, 12])
-def test_small_batches_around_the_leaf_table_limit(B):
-    """Up to ORBX_LEAF_FRAMES (8) frames per call k_fast's emit builds the quad-tree's leaf tables and k_octree starts from them; one frame more
-    and the kernel sweeps the segments itself.  Both sides of the limit, twice in a row on one handle (the tables must be clean again), every
-    frame against the oracle."""
+def test_small_batches_around_the_leaf_table_limit(B, monkeypatch):
+    """Up to ORBX_LEAF_FRAMES frames per call (default 128; 8 here) k_fast's emit builds the quad-tree's leaf tables and k_octree starts from them;
+    one frame more and the kernel sweeps the segments itself.  Both sides of the limit, twice in a row on one handle (the tables must be clean
+    again), every frame against the oracle."""
+    monkeypatch.setenv("ORBX_LEAF_FRAMES", "8")
     frames = np.concatenate([synth.frames("noise", 3, (B + 1) // 2, 480, 640), synth.frames("sparse", 5, B // 2 + 1, 480, 640)])[:B]
     ex = X.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=12)
     for rep in range(2):
@@ -497,7 +498,8 @@ def test_region_major_pyramid_every_cut(px, monkeypatch):
 def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):
     """k_fast_wide (four waves per FAST cell; default only while a call holds few cells) forced for a batch: candidates IN ORDER, every stage and the
     final arrays of every frame against the oracle — dense, sparse (cells that fall back to minThFAST, empty cells) and natural content, with
-    and without the leaf tables (nine frames are past ORBX_LEAF_FRAMES)."""
+    and without the leaf tables (nine frames are past ORBX_LEAF_FRAMES = 8)."""
+    monkeypatch.setenv("ORBX_LEAF_FRAMES", "8")
     monkeypatch.setenv("ORBX_FAST_WIDE", "1")
     monkeypatch.setenv("ORBX_FAST_PREFILTER", "0")
     for B in (3, 9):
@@ -509,3 +511,18 @@ def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):
             assert_same_result(out[f][:3], want, "B=%d frame %d" % (B, f))
             for l in range(8):
                 assert np.array_equal(ex.debug_candidates(l, f), o.candidates(l)), "candidates of level %d, frame %d" % (l, f)
+
+
+@pytest.mark.parametrize("B", [128, 130])
+def test_the_default_leaf_table_limit(B):
+    """The default limit (128 frames per call): a call at the limit builds the leaf tables for every frame, a larger one for none; twice on one handle;
+    frames spread over the batch against the oracle, all frames of both calls against each other."""
+    frames = np.concatenate([synth.frames("noise", 11, B // 2, 240, 320), synth.frames("natural", 12, B - B // 2, 240, 320)])
+    ex = X.ORBextractor(500, max_width=320, max_height=240, max_batch=B)
+    a = ex.extract_batch(frames)
+    b = ex.extract_batch(frames)
+    for f in range(B):
+        assert a[f][0] == b[f][0] and np.array_equal(a[f][1], b[f][1]) and np.array_equal(a[f][2], b[f][2]), "frame %d differs between two calls" % f
+    for f in (0, 1, B // 2 - 1, B // 2, B - 2, B - 1):
+        o, want = oracle_run(frames[f], 500)
+        assert_same_result(a[f][:3], want, "B=%d frame %d" % (B, f))
