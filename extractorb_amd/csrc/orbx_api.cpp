@@ -526,9 +526,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             if (residentT && lt.hist) {
                 int q = 0;
                 for (int l = 0; l < g.nlevels; l++) q = g.lv[l].quota > q ? g.lv[l].quota : q;
-                // (a list longer than 256 keeps the large workgroup: its last pass ranks up to 256 multi-key nodes against each other,
-                // which is arithmetic, not barriers - nfeatures 1200: 1024 threads 18.0 us, 512 threads 19.3)
-                int need = q + 4 <= 256 ? 256 : residentT;
+                // (nfeatures 1200, level-0 quota 261: 512 threads 14.1 us, 1024 threads 15.1 - its last pass ranks up to 256 multi-key nodes
+                // against each other, one packed key per node; before the packed key the larger workgroup won, 18.0 vs 19.3)
+                int need = q + 4 <= 256 ? 256 : (q + 4 <= 512 ? 512 : residentT);
                 if (h->octSmallT) need = h->octSmallT;   // ORBX_OCT_SMALL_T: measurement override
                 if (need < residentT) residentT = need;
             }
