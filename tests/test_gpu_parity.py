@@ -526,3 +526,15 @@ def test_the_default_leaf_table_limit(B):
     for f in (0, 1, B // 2 - 1, B // 2, B - 2, B - 1):
         o, want = oracle_run(frames[f], 500)
         assert_same_result(a[f][:3], want, "B=%d frame %d" % (B, f))
+
+
+@pytest.mark.parametrize("shape,nf", [((1944, 2592), 3000), ((3000, 4000), 5000), ((480, 4000), 1500)])
+def test_large_and_very_wide_images(shape, nf):
+    """5- and 12-megapixel frames and a 4000-px-wide strip (several quad-tree roots, hundreds of pyramid regions, thousands of FAST cells): every
+    stage and the final arrays of one frame against the oracle."""
+    img = synth.frames("natural", 77, 1, *shape)[0]
+    o, want = oracle_run(img, nf)
+    ex = X.ORBextractor(nf, max_width=shape[1], max_height=shape[0])
+    mono, k, d, lvl = ex(img)
+    check_stages(ex, o, lvl)
+    assert_same_result((mono, k, d), want, str(shape))
