@@ -53,3 +53,11 @@ def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
         json.dump(_totals, open(os.path.join(out, "r03_fuzz_parity.json"), "w"), indent=1)
     except OSError:
         pass
+
+
+def test_seeded_batch_shape_sweep():
+    """tools/fuzz_batches.py: random frames per call (1 .. 160) x image size x feature count x content, i.e. the host's launch policies crossed at
+    their thresholds; three frames of every batch against the oracle, two calls on one handle against each other."""
+    import fuzz_batches
+    done, skipped, checked = fuzz_batches.run(24, 31)
+    assert done + skipped == 24 and done >= 20 and checked >= 2 * done
