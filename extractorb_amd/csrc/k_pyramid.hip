@@ -316,9 +316,11 @@ constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shor
 
 // One step of a chain: the interior rectangle rd of level j (LDS, row stride ds) resized from the rectangle rs of level j - 1 (LDS, row stride
 // ss); cxs / cys = the coefficient records of rd's columns / rows.
-template <bool PACKED, int T = kChainThreads>
+// QUAD (k_pyr_cols): cxs holds one host-made QuadRec per column quad instead of one ResizeX per column.
+template <bool PACKED, int T = kChainThreads, bool QUAD = false>
 __device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ResizeX* cxs, const ResizeX* cys,
                                           const int ss, const int ds, const int tid) {
+    static_assert(PACKED || !QUAD, "quad records exist for the packed step only");
     if constexpr (PACKED) {
         // (the host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)  A thread owns four
         // adjacent columns over a block of consecutive rows, so that — as in resizeTile — the horizontal pass of a source row
@@ -329,8 +331,19 @@ __device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const Ch
         const int nq = (rd.w + 3) >> 2, nb = T / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
         const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
         if (blk < nb && yb < ye) {
-            int c0[4], c1[4];
             u16x2 wt[4];
+            unsigned sel[4];
+            int base;
+            unsigned sh;
+            if constexpr (QUAD) {
+                const uint4* qr = (const uint4*)((const QuadRec*)cxs + (x4 >> 2));      // three 16-byte LDS reads
+                const uint4 q0 = qr[0], q1 = qr[1];
+                const unsigned bs = ((const unsigned*)qr)[8];
+                sel[0] = q0.x; sel[1] = q0.y; sel[2] = q0.z; sel[3] = q0.w;
+                wt[0] = __builtin_bit_cast(u16x2, q1.x); wt[1] = __builtin_bit_cast(u16x2, q1.y); wt[2] = __builtin_bit_cast(u16x2, q1.z); wt[3] = __builtin_bit_cast(u16x2, q1.w);
+                base = (int)(bs & 0xffffu); sh = bs >> 16;
+            } else {
+            int c0[4], c1[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const ResizeX cx = cxs[min(x4 + k, rd.w - 1)];
@@ -338,11 +351,11 @@ __device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const Ch
                 wt[k] = u16x2{(unsigned short)cx.a0, (unsigned short)cx.a1};
             }
             const int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
-            const int base = lo & ~3;
-            const unsigned sh = (unsigned)(lo & 3);
-            unsigned sel[4];
+            base = lo & ~3;
+            sh = (unsigned)(lo & 3);
 #pragma unroll
             for (int k = 0; k < 4; k++) sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
+            }
             auto hrow = [&](int srow, unsigned (&h)[4]) {
                 const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
                 const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
                                                             uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
     static_assert(TD <= T && TD % 64 == 0 && (T - TD) % 64 == 0, "roles are whole waves");
     extern __shared__ __align__(16) uint8_t lds[];
-    __shared__ ResizeX coef[kChainCoefMax];
+    __shared__ __align__(16) ResizeX coef[kChainCoefMax];
     // what writing a level needs, fetched with the up-front loads: read per level from memory, every level would start with an L2 round trip
     struct LevelOut { ColOwn own; int w, h, stride, pad; long long off; };
     __shared__ LevelOut outOf[kMaxLevels];
@@ -670,9 +683,10 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         const uint8_t* S = buf[j & 1];
         constexpr int TW = TD < T ? T - TD : T;      // threads of the writing role
         if (j < top) {
-            const ResizeX* cxs = coef + off;
-            if (tid < TD) chainStep<PACKED, TD>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + rd.w, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
-            off += rd.w + rd.h;
+            const ResizeX* cxs = coef + off;                        // the level's quad records, then its y records (PyrColumn's layout)
+            const int nqUnits = 6 * ((rd.w + 3) >> 2);
+            if (tid < TD) chainStep<true, TD, true>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
+            off += nqUnits + ((rd.h + 1) & ~1);
         }
         // (the last level has nothing to derive: every thread writes)
         const bool everyone = TD == T || j == top;
@@ -723,23 +737,14 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
 #define ORBX_COLS_LAUNCH(P, T, TD) hipLaunchKernelGGL((k_pyr_cols<P, T, TD>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, bufEvenBytes, f0, B)
-    if (packed) {
-        if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
-        else if (variant == 1) ORBX_COLS_LAUNCH(true, 512, 256);
-        else if (variant == 2) ORBX_COLS_LAUNCH(true, 512, 512);
-        else if (variant == 4) ORBX_COLS_LAUNCH(true, 768, 256);
-        else if (variant == 5) ORBX_COLS_LAUNCH(true, 1024, 256);
-        else if (variant == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
-        else ORBX_COLS_LAUNCH(true, 256, 256);
-    } else {
-        if (variant == 0) ORBX_COLS_LAUNCH(false, 768, 512);
-        else if (variant == 1) ORBX_COLS_LAUNCH(false, 512, 256);
-        else if (variant == 2) ORBX_COLS_LAUNCH(false, 512, 512);
-        else if (variant == 4) ORBX_COLS_LAUNCH(false, 768, 256);
-        else if (variant == 5) ORBX_COLS_LAUNCH(false, 1024, 256);
-        else if (variant == 6) ORBX_COLS_LAUNCH(false, 1024, 512);
-        else ORBX_COLS_LAUNCH(false, 256, 256);
-    }
+    (void)packed;      // (the host only takes this form when the taps of every column quad fit the packed step's 8-byte window)
+    if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
+    else if (variant == 1) ORBX_COLS_LAUNCH(true, 512, 256);
+    else if (variant == 2) ORBX_COLS_LAUNCH(true, 512, 512);
+    else if (variant == 4) ORBX_COLS_LAUNCH(true, 768, 256);
+    else if (variant == 5) ORBX_COLS_LAUNCH(true, 1024, 256);
+    else if (variant == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
+    else ORBX_COLS_LAUNCH(true, 256, 256);
 #undef ORBX_COLS_LAUNCH
 }
 

@@ -436,7 +436,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // 640x480, us per call, tile forms -> this: 1 frame (40-px regions) 46.0 -> 40.9, 2 (56 px) 53.5 -> 45.7, 4: 66.2 -> 58.8, 8 (112 px): 93.4 -> 71.2,
         // 16: 133 -> 113, 32: 193 -> 172, 64: 309 -> 293, 128: 588 -> 582; 256 frames: 1043 -> 1062, the per-level launches win)
         const FrameGeom::ColumnSet* cs = nullptr;
-        if (h->pyrCols != 0)
+        if (h->pyrCols != 0 && g.colsPacked && !h->resizeBytewise)      // (its steps are the packed ones: the regions carry quad records)
             for (const FrameGeom::ColumnSet& c : g.colSets) {
                 if (!c.fit || c.ldsBytes > 60 * 1024) continue;
                 if (!cs || (long long)c.columns.size() * Bn >= 3LL * h->numCUs / 4) cs = &c;

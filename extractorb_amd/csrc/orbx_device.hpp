@@ -147,10 +147,14 @@ struct ChainTile {
 // bytes mirror, and the taps of region[l + 1]; x0 a multiple of 4); own[l] = the dword columns x rows of the BORDERED level l it writes (the
 // own rectangles of the columns partition every level).  Against the tile chains (k_pyr_chain) nothing is derived twice except the regions'
 // overlap: 640x480, 48 regions: 0.7 M pixels derived per frame instead of 6.6 M, and the longest chain of steps handles 14 k pixels, not 31 k.
+// What a thread of the packed resize step needs of its four adjacent columns, worked out by the host per region and level (k_pyr_cols): the
+// aligned start and the byte shift of the 8-byte tap window inside the region's row, the v_perm selectors that cut each column's two taps out of
+// it, the weight pairs.  (Derived in the kernel from four ResizeX records it was ~45 of the ~100 vector instructions of a one-row step.)
+struct QuadRec { unsigned sel[4]; unsigned wt[4]; int baseSh; int pad[3]; };      // baseSh = base | shift << 16;  48 bytes = six 8-byte units
 struct ColOwn { short dw0, dw1, r0, r1; };
 struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; int nCoef, pad; };   // nCoef: coefficient records of all its steps
-// (the records - x records of level 1's rectangle, its y records, level 2's ... - are laid out per region by the host: the kernel copies
-// region t's list from coef[t * slot ..], one coalesced pass, instead of working out per thread which record of which table a slot holds)
+// (the records - per level the quad records of its rectangle's column quads (QuadRec), then its y records (ResizeX, an even number of
+// slots) - are laid out per region by the host in 8-byte units: the kernel copies region t's list from coef[t * slot ..], one coalesced pass)
 struct ColLevels {      // what the kernel needs of the level tables, by value (kernel argument: scalar loads)
     int nlevels, pad;
     int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];

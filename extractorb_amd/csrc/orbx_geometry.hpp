@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -419,7 +420,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     c.region[l] = ChainRegion{(short)nx0, (short)ny0, (short)w, (short)hh};
                     if (w > kChainMaxW || (l == 0 && bytes > kChainMaxW * kChainMaxH0)) fits = false;
                     if (l & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
-                    if (l >= 1) coefs += w + hh;
+                    if (l >= 1) coefs += 6 * ((w + 3) >> 2) + ((hh + 1) & ~1);      // 8-byte units: quad records, y records (even: the next level's quads stay 16-byte aligned)
                     x0 = nx0; x1 = std::min(nx0 + w - 1, L.w - 1); y0 = ny0; y1 = ny1;
                     if (l == 0) x1 = nx1;
                 }
@@ -435,8 +436,23 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                 ResizeX* q = cs.coef.data() + i * (size_t)cs.coefSlot;
                 for (int l = 1; l <= top; l++) {
                     const ChainRegion& r = cs.columns[i].region[l];
-                    for (int x = 0; x < r.w; x++) *q++ = g.rx[l][r.x0 + x];
+                    const ChainRegion& rs = cs.columns[i].region[l - 1];
+                    for (int x4 = 0; x4 < r.w; x4 += 4) {      // (chainStep's arithmetic, once per region and level instead of once per thread and step)
+                        QuadRec qr{};
+                        int c0[4], c1[4], lo = 1 << 30;
+                        for (int k = 0; k < 4; k++) {
+                            const ResizeX& cx = g.rx[l][r.x0 + std::min(x4 + k, r.w - 1)];
+                            c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
+                            qr.wt[k] = (unsigned)(unsigned short)cx.a0 | ((unsigned)(unsigned short)cx.a1 << 16);
+                            lo = std::min(lo, std::min(c0[k], c1[k]));
+                        }
+                        for (int k = 0; k < 4; k++) qr.sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
+                        qr.baseSh = (lo & ~3) | ((lo & 3) << 16);
+                        std::memcpy(q, &qr, sizeof(qr));
+                        q += sizeof(qr) / sizeof(ResizeX);
+                    }
                     for (int y = 0; y < r.h; y++) *q++ = g.ry[l][r.y0 + y];
+                    if (r.h & 1) *q++ = ResizeX{0, 0, 0, 0};
                 }
             }
         }

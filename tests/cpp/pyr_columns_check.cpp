@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     }
     int checked = 0;
     for (const FrameGeom::ColumnSet& cs : g.colSets) {
-        if (!cs.fit) continue;
+        if (!cs.fit || !g.colsPacked) continue;      // (the kernel's steps are the packed ones: without packed taps the host never takes this form)
         if ((int)cs.columns.size() != cs.RX * cs.RY) FAIL("px %d: %zu regions for a %d x %d cut", cs.px, cs.columns.size(), cs.RX, cs.RY);
         if (cs.ldsBytes > 64 * 1024) FAIL("px %d: %d bytes of LDS", cs.px, cs.ldsBytes);
         std::vector<std::vector<int>> written(nlevels);      // per level: how often each (row, dword) was written
@@ -63,8 +63,8 @@ int main(int argc, char** argv) {
         for (size_t ci = 0; ci < cs.columns.size(); ci++) {
             const PyrColumn& c = cs.columns[ci];
             const ResizeX* coef = cs.coef.data() + ci * (size_t)cs.coefSlot;
-            int off = 0, total = 0;
-            for (int l = 1; l < nlevels; l++) total += c.region[l].w + c.region[l].h;
+            int off = 0, total = 0;      // 8-byte units: per level the quad records (six units each), then the y records (an even number of slots)
+            for (int l = 1; l < nlevels; l++) total += 6 * ((c.region[l].w + 3) / 4) + ((c.region[l].h + 1) & ~1);
             if (total != c.nCoef || total > kChainCoefMax || total > cs.coefSlot) FAIL("px %d region %zu: %d coefficient records, nCoef %d, slot %d", cs.px, ci, total, c.nCoef, cs.coefSlot);
             std::vector<uint8_t> cur, nxt;
             for (int l = 0; l < nlevels; l++) {
@@ -103,10 +103,21 @@ int main(int argc, char** argv) {
                     const ChainRegion d = c.region[l + 1];
                     const int ds = (d.w + 3) & ~3;
                     nxt.assign((size_t)ds * d.h, 0xEE);
-                    const ResizeX *cxs = coef + off, *cys = cxs + d.w;
+                    const int nq = (d.w + 3) / 4;
+                    const QuadRec* qrs = (const QuadRec*)(coef + off);
+                    const ResizeX* cys = coef + off + 6 * nq;
                     for (int y = 0; y < d.h; y++)
                         for (int x = 0; x < d.w; x++) {
-                            const ResizeX cx = cxs[x], cy = cys[y];
+                            // the column's taps and weights as the kernel reads them out of its quad record: tap = row start + base + shift + selector byte
+                            const QuadRec& qr = qrs[x / 4];
+                            const int k = x & 3, base = qr.baseSh & 0xffff, sh = qr.baseSh >> 16;
+                            if ((base & 3) || sh > 3 || (qr.sel[k] & 0xff00ff00u) != 0x0C000C00u) FAIL("px %d region %zu level %d: malformed quad record %d", cs.px, ci, l + 1, x / 4);
+                            const int t0 = (int)(qr.sel[k] & 0xff), t1 = (int)((qr.sel[k] >> 16) & 0xff);
+                            if (t0 > 7 || t1 > 7) FAIL("px %d region %zu level %d: a tap of column %d lies outside the 8-byte window", cs.px, ci, l + 1, x);
+                            ResizeX cx;
+                            cx.sx0 = (short)(r.x0 + base + sh + t0); cx.sx1 = (short)(r.x0 + base + sh + t1);
+                            cx.a0 = (short)(qr.wt[k] & 0xffff); cx.a1 = (short)(qr.wt[k] >> 16);
+                            const ResizeX cy = cys[y];
                             const ResizeX gx = g.rx[l + 1][d.x0 + x], gy = g.ry[l + 1][d.y0 + y];
                             if (cx.sx0 != gx.sx0 || cx.sx1 != gx.sx1 || cx.a0 != gx.a0 || cx.a1 != gx.a1 || cy.sx0 != gy.sx0 || cy.sx1 != gy.sx1 || cy.a0 != gy.a0 || cy.a1 != gy.a1)
                                 FAIL("px %d region %zu level %d: coefficient list differs from the level tables at (%d, %d)", cs.px, ci, l + 1, x, y);
@@ -121,7 +132,7 @@ int main(int argc, char** argv) {
                                 }
                             nxt[(size_t)y * ds + x] = (uint8_t)resizePx(p[0][0], p[0][1], p[1][0], p[1][1], cx, cy);
                         }
-                    off += d.w + d.h;
+                    off += 6 * nq + ((d.h + 1) & ~1);
                     cur.swap(nxt);
                 }
             }
