@@ -1,15 +1,14 @@
-# One 640x480 frame per call: the launch timeline (round 3, commit ca730f7)
+import subprocess
+h=subprocess.check_output(['git','log','--oneline','-1'],cwd='/root/repo').decode()[:7]
+t=open('/root/repo/gpurun_out/trace_b1.txt').read().strip()
+open('/root/repo/profiles/r03_single_frame_timeline.md','w').write('''# One 640x480 frame per call: the launch timeline (round 3, commit %s)
 
 `tools/trace_b1.sh` on the GPU box (1x MI355X): `rocprofv3 --kernel-trace` of `python3 bench.py --steps 50 --warmup 5 --batch 1 --no-cpu-baseline
 --no-extras` (ORBX_SPLIT=0), one call out of the middle of the timed region, times relative to its first kernel.  Round 2's timeline for the same
 call: `k_pyr_chain` 19 + `k_fast` 11 + `k_octree` 33 + `k_describe` 6 = 65 us.
 
 ```
-k_pyr_cols       start    0.00 us  dur  11.36 us  gap   0.00 us  grid 1024x192x1 wg 1024
-k_fast_wide      start   11.36 us  dur   9.36 us  gap   0.00 us  grid 256x933x1 wg 256
-k_octree_256r    start   20.72 us  dur  10.16 us  gap   0.00 us  grid 256x8x1 wg 256
-k_describe       start   30.88 us  dur   7.12 us  gap   0.00 us  grid 256x130x1 wg 256
-k_pyr_cols       start   38.00 us  dur  10.96 us  gap   0.00 us  grid 1024x192x1 wg 1024
+%s
 ```
 
 Inside `k_pyr_cols` (a `-DORBX_CHAIN_STAMPS` build, `tools/cols_stamps.py`, region 21 of the 192 of the 40-px cut; `s_memrealtime`, 10-ns ticks):
@@ -35,3 +34,4 @@ Inside `k_fast_wide` (`-DORBX_FAST_CLOCK` build, `tools/fast_spans.py`): a level
 
 Inside `k_octree_256r`, the level-0 workgroup (`-DORBX_OCT_STAMPS` build, `tools/oct_stamps.py`): leaf tables + roots 1.44, count pyramid 1.00 + 0.32, fast-forward
 1.76, the one sorted pass (64 -> 217 nodes, on one wave) 2.24, best keys + output 1.68: 8.4 us; the coarsest level needs two sorted passes and ends last, at 9.7 us.
+''' % (h, t))
