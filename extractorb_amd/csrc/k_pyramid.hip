@@ -695,27 +695,40 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         const LevelOut lo = outOf[j];
         const ColOwn own = lo.own;
         const int w = lo.w, h = lo.h, wB = w + 2 * kEdge;
-        const int ndw = own.dw1 - own.dw0, total = ndw * (own.r1 - own.r0);
         uint8_t* out = pyr + lo.off;
-        const int stride = lo.stride;
-        const float inv = __frcp_rn((float)(ndw > 0 ? ndw : 1));
-        for (int i = wtid; i < total; i += wstep) {
-            // (exact: the quotient's error, ~i / ndw * 2^-22, stays below the 0.5 / ndw that separates it from an integer while total < 2^21)
-            const int rr = (int)(((float)i + 0.5f) * inv), dw = own.dw0 + (i - rr * ndw), row = own.r0 + rr;
-            const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;      // interior pixel x of that row at srow[x]
-            const int bc0 = 4 * dw, x0 = bc0 - kPadL;          // interior x of the dword's first byte (a multiple of 4, as rs.x0 is)
-            unsigned o;
-            if (x0 >= 0 && x0 + 3 < w) o = *(const unsigned*)(srow + x0);      // no reflection inside this dword
-            else {
-                o = 0;
+        const int stride = lo.stride, nrows = own.r1 - own.r0;
+        // the owned dword columns in two passes, so that no wave runs both bodies: first the columns that lie inside the level's rows (aligned
+        // dwords of the LDS rectangle: nearly everything; an inner region owns nothing else), then the frame's columns of an outer region
+        // (mirrored / clamped byte by byte).  In one pass an outer region's waves ran the byte-by-byte body for every trip of the loop — three
+        // trips for a corner's level 0, which made the corners the launch's last workgroups.
+        const int fa = max((int)own.dw0, kPadL / 4), fb = max(fa, min((int)own.dw1, kPadL / 4 + (w >> 2)));      // [fa, fb): x0 >= 0 and x0 + 3 < w
+        {
+            const int ndw = fb - fa, total = ndw * nrows;
+            const float inv = __frcp_rn((float)(ndw > 0 ? ndw : 1));
+            for (int i = wtid; i < total; i += wstep) {
+                // (exact: the quotient's error, ~i / ndw * 2^-22, stays below the 0.5 / ndw that separates it from an integer while total < 2^21)
+                const int rr = (int)(((float)i + 0.5f) * inv), dw = fa + (i - rr * ndw), row = own.r0 + rr;
+                const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;      // interior pixel x of that row at srow[x]
+                *(unsigned*)(out + (long long)row * stride + 4 * dw) = *(const unsigned*)(srow + (4 * dw - kPadL));      // (a multiple of 4, as rs.x0 is)
+            }
+        }
+        const int nL = fa - own.dw0, nO = nL + (own.dw1 - fb);      // frame columns left / in all
+        if (nO > 0) {                                                // workgroup-uniform
+            const int total = nO * nrows;
+            const float inv = __frcp_rn((float)nO);
+            for (int i = wtid; i < total; i += wstep) {
+                const int rr = (int)(((float)i + 0.5f) * inv), jj = i - rr * nO, dw = jj < nL ? own.dw0 + jj : fb + (jj - nL), row = own.r0 + rr;
+                const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;
+                const int bc0 = 4 * dw;
+                unsigned o = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int bx = bc0 + k - (kPadL - kEdge);
                     bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);      // bytes of a dword outside the bordered row are padding
                     o |= (unsigned)srow[reflect101(bx - kEdge, w)] << (8 * k);
                 }
+                *(unsigned*)(out + (long long)row * stride + bc0) = o;
             }
-            *(unsigned*)(out + (long long)row * stride + bc0) = o;
         }
         }
         __syncthreads();
