@@ -7,7 +7,7 @@ conversions, f64) in ~4.  SQ_INSTS_VALU x 4 cycles therefore over-states a kerne
 tool compiles a kernel source to ISA (same flags as the Makefile) and reports that share per kernel, whole body, every instruction
 counted once (the hot loops of these kernels are straight-line bodies that dominate the static count as they dominate the dynamic one).
 
-usage: valu_census.py [--json]      -> table (or JSON {kernel: {valu, full_rate, share}}) for the six kernels of the hot path"""
+usage: valu_census.py [--json]      -> table (or JSON {kernel: {valu, full_rate, share}}) for the kernels of the hot path"""
 import json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "extractorb_amd", "csrc")
@@ -15,6 +15,7 @@ FULL = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_and_
 # kernel (as bench.py / rocprof name it) -> (source file, mangled-name fragment of the variant the default workload runs)
 KERNELS = {"k_fast": ("k_fast.hip", "k_fastILi48ELi45ELb0E"), "k_blur": ("k_blur.hip", "k_blur"), "k_describe": ("k_describe.hip", "k_describe"),
            "k_pyr_first": ("k_pyramid.hip", "k_pyr_firstILb1E"), "k_resize": ("k_pyramid.hip", "k_resizeILb1E"),
+           "k_pyr_cols": ("k_pyramid.hip", "k_pyr_colsILb1ELi512ELi256E"),
            "k_octree_256": ("k_octree.hip", "k_octree_256E")}
 
 
