@@ -380,11 +380,14 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     assert_same_result((mono, k, d), want, "%s=%s clustered" % (switch, value))
 
 
-@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True)])
+@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True)])
 def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
     # a large batch runs as two halves on two streams (odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small
     # frames count as large, ORBX_SPLIT=0 turns the overlap off
+    if B < 0:      # (negative: the pyramid as one launch per level, the form of large batches of large frames, instead of the region-major one)
+        monkeypatch.setenv("ORBX_PYR_COLS", "0")
+        B = -B
     if split:
         monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
     else:
