@@ -702,15 +702,34 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         // (mirrored / clamped byte by byte).  In one pass an outer region's waves ran the byte-by-byte body for every trip of the loop — three
         // trips for a corner's level 0, which made the corners the launch's last workgroups.
         const int fa = max((int)own.dw0, kPadL / 4), fb = max(fa, min((int)own.dw1, kPadL / 4 + (w >> 2)));      // [fa, fb): x0 >= 0 and x0 + 3 < w
-        {
+        if (fb > fa && (fb - fa) * nrows <= 2 * wstep) {             // workgroup-uniform: a small part (a fine cut's region; the deep levels)
+            // ... is dealt dword by dword: at most two per thread, no chain of dependent rows
             const int ndw = fb - fa, total = ndw * nrows;
-            const float inv = __frcp_rn((float)(ndw > 0 ? ndw : 1));
+            const float inv = __frcp_rn((float)ndw);
             for (int i = wtid; i < total; i += wstep) {
                 // (exact: the quotient's error, ~i / ndw * 2^-22, stays below the 0.5 / ndw that separates it from an integer while total < 2^21)
                 const int rr = (int)(((float)i + 0.5f) * inv), dw = fa + (i - rr * ndw), row = own.r0 + rr;
                 const uint8_t* srow = S + __mul24(reflect101(row - kEdge, h) - rs.y0, ss) - rs.x0;      // interior pixel x of that row at srow[x]
                 *(unsigned*)(out + (long long)row * stride + 4 * dw) = *(const unsigned*)(srow + (4 * dw - kPadL));      // (a multiple of 4, as rs.x0 is)
             }
+        } else if (fb > fa) {
+            // a thread takes ONE dword column and walks down a block of rows (a row of the rectangle = one coalesced run of stores across
+            // the lanes): per dword a row reflection, an LDS read and a store — no index arithmetic (dealt dword by dword through a division it
+            // was ~22 instructions per dword, a fifth of the kernel's at 512 frames)
+            // (quotients of small integers through the reciprocal: exact while the dividend stays below 2^12 — an integer division is ~40 instructions)
+            const int ndw = fb - fa;
+            const float rdw = __frcp_rn((float)ndw);
+            const int ngrp = max((int)(((float)wstep + 0.5f) * rdw), 1);
+            const int per = (int)(((float)(nrows + ngrp - 1) + 0.5f) * __frcp_rn((float)ngrp));
+            const int grp = (int)(((float)wtid + 0.5f) * rdw), c = wtid - grp * ndw;
+            if (wtid >= 0 && grp < ngrp) {
+                const int rA = own.r0 + grp * per, rB = min(rA + per, (int)own.r1);
+                const uint8_t* scol = S + (4 * (fa + c) - kPadL - rs.x0);      // the column's first byte in rectangle row 0 (a multiple of 4, as rs.x0 is)
+                uint8_t* ocol = out + 4 * (fa + c);
+                for (int row = rA; row < rB; row++)
+                    *(unsigned*)(ocol + (long long)row * stride) = *(const unsigned*)(scol + __mul24(reflect101(row - kEdge, h) - rs.y0, ss));
+            }
+            // (columns beyond ngrp * ndw threads: a rectangle wider than the role has threads — the regions are at most 64 dwords wide)
         }
         const int nL = fa - own.dw0, nO = nL + (own.dw1 - fb);      // frame columns left / in all
         if (nO > 0) {                                                // workgroup-uniform
