@@ -141,7 +141,14 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even at N = 1 (what --gpus N > 1 does "
                     "by itself when no launcher set RANK)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed slab")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --stub-extractor)")
+    ap.add_argument("--stub-extractor", action="store_true", help="REHEARSAL, not a measurement: CPU tensors, the result slabs written by the "
+                    "oracle instead of the HIP path, so that the N > 1 control flow of this file (double-buffered slabs, the asynchronous gather, "
+                    "the waits before a slab is overwritten, configs[4], the max-over-ranks clock, the per-rank check of what arrived) runs at "
+                    "world size 2 in the CPU test suite (tests/test_bench_world2.py).  The line it prints carries value = null")
     args = ap.parse_args()
+    if args.stub_extractor != (args.backend == "gloo"):
+        raise SystemExit("--backend gloo and --stub-extractor go together (the HIP path runs under nccl = RCCL only)")
     if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
         return spawn_ranks(sys.argv[1:], args.gpus)      # BEFORE torch / HIP are imported: the parent never touches the GPU
 
@@ -161,45 +168,87 @@ def main():
     if world != N:
         raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (N, world))
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # launched by torch.distributed.run (any world size)
-    if not torch.cuda.is_available():
+    stub = args.stub_extractor
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
-    torch.cuda.set_device(local_rank)
+    dev = "cpu" if stub else "cuda"
+    dsync = (lambda: None) if stub else torch.cuda.synchronize
+    if not stub:
+        torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- inputs: this rank's B frames of the stream, generated on the host, parked in HBM ----
-    if variant == "stereo":      # L/R pairs cut from one wider textured frame: a true disparity for the matcher to find
-        pairs = []
-        for p in range(B // 2):
-            big = synth.textured_frame(rank * B + p, rows, cols + 80)
-            disp = 6 + (p * 7) % 35
-            pairs += [big[:, 40:40 + cols], big[:, 40 + disp:40 + disp + cols]]
-        frames = np.ascontiguousarray(np.stack(pairs))
-    elif variant == "pan":     # one textured scene per rank seen by a camera panning 1 px per frame: consecutive frames match
-        big = synth.textured_frame(rank, rows, cols + B)
-        frames = np.ascontiguousarray(np.stack([big[:, i:i + cols] for i in range(B)]))
-    else:
-        frames = synth.frames(variant, rank * B, B, rows, cols)
-    d_img = torch.from_numpy(frames).cuda()
+    def stream_frames(r, first=0, count=None):
+        """frames [first, first + count) of rank r's B frames: every rank's input is a pure function of (rank, index), so rank 0 can
+        rebuild what any other rank extracted when it checks the gathered slabs"""
+        count = B - first if count is None else count
+        if variant == "stereo":      # L/R pairs cut from one wider textured frame: a true disparity for the matcher to find
+            out = []
+            for i in range(first, first + count):
+                pp = i // 2
+                big = synth.textured_frame(r * B + pp, rows, cols + 80)
+                disp = 6 + (pp * 7) % 35
+                out.append(big[:, 40:40 + cols] if i % 2 == 0 else big[:, 40 + disp:40 + disp + cols])
+            return np.ascontiguousarray(np.stack(out))
+        if variant == "pan":     # one textured scene per rank seen by a camera panning 1 px per frame: consecutive frames match
+            big = synth.textured_frame(r, rows, cols + B)
+            return np.ascontiguousarray(np.stack([big[:, i:i + cols] for i in range(first, first + count)]))
+        return synth.frames(variant, r * B + first, count, rows, cols)
+
+    frames = stream_frames(rank)
+    d_img = torch.from_numpy(frames).to(dev)
     color = int(wl.get("color", 0))
     if color:      # channel c of frame f = gray frame (f + c) of the stream: three different planes, interleaved
         d_color = torch.stack([torch.roll(d_img, -c, 0) for c in range(color)], dim=-1).contiguous()
     nH = max(1, args.handles)
     if nH > 1 and any(wl.get(k) for k in ("match", "init_match", "track", "bow", "refkf")):
         raise SystemExit("--handles > 1 is for the plain extraction workloads: the next-row scratch arrays of %s are one set per process" % args.workload)
-    exs = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank) for _ in range(nH)]
-    ex = exs[0]
-    stream = torch.cuda.current_stream()
-    streams = [stream] + [torch.cuda.Stream() for _ in range(nH - 1)]
-    for e, st_ in zip(exs, streams):
-        e.set_stream(st_.cuda_stream)
+    if stub:
+        if any(wl.get(k) for k in ("match", "init_match", "track", "bow", "refkf", "color")) or nH > 1:
+            raise SystemExit("--stub-extractor rehearses the plain extraction workloads with one handle")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O_stub      # the oracle stands in for the extractor in the REHEARSAL mode only (value = null)
+        import contextlib
+        import ctypes
+
+        class StubExtractor:
+            capacity = nf + 3 * 8
+
+            def __init__(self):
+                self.o = O_stub.Oracle(nf, 1.2, 8, 20, 7)
+
+            def extract_batch_device(self, d_imgs, nB, rows_, cols_, pk, pd, pn, pm, cap_, lapping=(0, 1000)):
+                imgs = d_imgs.numpy()
+                for f in range(nB):
+                    mono, k, d = self.o.extract(imgs[f], lapping)
+                    ctypes.memmove(pk + f * cap_ * 28, k.ctypes.data, len(k) * 28)
+                    ctypes.memmove(pd + f * cap_ * 32, np.ascontiguousarray(d).ctypes.data, len(k) * 32)
+                    ctypes.c_int32.from_address(pn + 4 * f).value = len(k)
+                    ctypes.c_int32.from_address(pm + 4 * f).value = mono
+
+        exs = [StubExtractor()]
+        ex = exs[0]
+        stream, streams = None, [None]
+        on_stream = lambda st_: contextlib.nullcontext()
+    else:
+        exs = [X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B, device=local_rank) for _ in range(nH)]
+        ex = exs[0]
+        stream = torch.cuda.current_stream()
+        streams = [stream] + [torch.cuda.Stream() for _ in range(nH - 1)]
+        for e, st_ in zip(exs, streams):
+            e.set_stream(st_.cuda_stream)
+        on_stream = torch.cuda.stream
     cap = min(ex.capacity, nf + 3 * 8)      # the reference's bound: every level keeps at most quota + 3 keypoints (SURVEY.md §8a-7)
     # one contiguous result slab per rank: [keypoints | descriptors | n | mono] — the unit the gather moves
     lay = sharding.slab_layout(B, cap)
     off_k, off_d, off_n, off_m = lay["keypoints"], lay["descriptors"], lay["n"], lay["mono"]
     # two slabs: while step k's results travel to rank 0, step k+1 already computes into the other one
-    slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda") for _ in range(max(2, nH))]
+    slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device=dev) for _ in range(max(2, nH))]
     slab = slabs[0]
     match = bool(wl.get("match"))
     if match:
@@ -277,6 +326,7 @@ def main():
         gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(len(slabs))]
     pending = [None] * len(slabs)      # the gather that last read slab k (and last wrote gathered[k])
     counter = [0]
+    corrupt_rank = int(os.environ.get("ORBX_BENCH_TEST_CORRUPT_RANK", "-1"))      # tests/test_bench_world2.py: a wrong slab must fail the run
 
     def step():
         k = counter[0] % len(slabs)
@@ -287,7 +337,7 @@ def main():
         if pending[k] is not None:
             # slab k is about to be overwritten by handle j on ITS stream: that stream, not torch's current one, has to wait
             # for the gather that is still reading the slab
-            with torch.cuda.stream(streams[j]):
+            with on_stream(streams[j]):
                 pending[k].wait()
             pending[k] = None
         if color:
@@ -301,6 +351,8 @@ def main():
             finish_and_track(e_, b)
         if bow:
             compute_bow(e_, b)
+        if corrupt_rank == rank and counter[0] == 1 + args.warmup + args.steps:
+            slabs[k][off_d + (B - 1) * cap * 32] ^= 0xFF      # (test switch: one descriptor byte of the last timed step's last frame)
         if gather:
             if j != 0:
                 stream.wait_stream(streams[j])   # the collective is ordered after torch's CURRENT stream
@@ -312,10 +364,10 @@ def main():
             if w is not None:
                 w.wait()
                 pending[i] = None
-        torch.cuda.synchronize()
+        dsync()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        dsync()
 
     # one untimed priming step outside the warmup count: the first call installs the geometry tables, and the first gather
     # builds RCCL's point-to-point channels (seconds at N = 8); --warmup 0 must not put either into the timed region
@@ -336,7 +388,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     base = slabs[0].data_ptr()
@@ -348,10 +400,13 @@ def main():
     cfg5 = None
     if distributed and (N > 1 or os.environ.get("ORBX_BENCH_CONFIGS4_AT_ANY_N")) and args.workload == "mono640" and not args.no_extras:      # (the env switch: the test reaches this code on a one-GPU box)
         B5 = min(64, B)
-        e5 = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B5, device=local_rank)
-        e5.set_stream(stream.cuda_stream)
+        if stub:
+            e5 = ex
+        else:
+            e5 = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=cols, max_height=rows, max_batch=B5, device=local_rank)
+            e5.set_stream(stream.cuda_stream)
         l5 = sharding.slab_layout(B5, cap)
-        s5 = [torch.zeros(l5["bytes"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+        s5 = [torch.zeros(l5["bytes"], dtype=torch.uint8, device=dev) for _ in range(2)]
         g5 = [[torch.empty_like(s5[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
         p5 = [None, None]
 
@@ -371,17 +426,17 @@ def main():
                 if p5[i5] is not None:
                     p5[i5].wait()
                     p5[i5] = None
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            dsync(); dist.barrier(); dsync()
 
-        for i in range(4):
+        for i in range(2 if stub else 4):
             step5(i)
         fence5()
-        K5 = max(args.steps, 20)
+        K5 = args.steps if stub else max(args.steps, 20)
         t5 = time.perf_counter()
         for i in range(K5):
             step5(i)
         fence5()
-        dt5 = torch.tensor([time.perf_counter() - t5], dtype=torch.float64, device="cuda")
+        dt5 = torch.tensor([time.perf_counter() - t5], dtype=torch.float64, device=dev)
         dist.all_reduce(dt5, op=dist.ReduceOp.MAX)
         dt5 = float(dt5.item())
         cfg5 = dict(frames_per_gpu_per_step=B5, global_frames_per_step=N * B5, steps=K5, fps=round(N * B5 * K5 / dt5, 1),
@@ -389,33 +444,64 @@ def main():
                     % (N * B5, "" if gather else " (gather disabled)"))
         del e5
 
-    # ---- what was timed is what is checked: frames of the LAST timed step's slab against the oracle, after the timed region ----
+    # ---- what was timed is what is checked: frames of the LAST timed step's slab against the oracle, after the timed region.  Under the
+    #      gather rank 0 checks what ARRIVED: frames of every rank's gathered slab (it rebuilds that rank's inputs: stream_frames) ----
     verified = None
+    bad = []
     if rank == 0 and not args.no_verify and args.steps > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O      # the checker; never the product path
-        last = slabs[(counter[0] - 1) % len(slabs)]
-        picks = sorted({0, max(B // 2 - 1, 0), min(B // 2, B - 1), B - 1})       # first / last frame of each half-batch
-        h_n = last[off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
-        h_m = last[off_m:off_m + 4 * B].cpu().numpy().view(np.int32)
+        kl = (counter[0] - 1) % len(slabs)
         orc = O.Oracle(nf, 1.2, 8, 20, 7)
-        bad = []
-        for f in picks:
-            img = d_img[f].cpu().numpy()        # the gray frame the timed step read (for *_bgr: what k_gray wrote)
-            wm, wk, wd = orc.extract(img, wl["lapping"])
-            n = int(h_n[f])
-            gk = last[off_k + f * cap * 28: off_k + f * cap * 28 + n * 28].cpu().numpy().tobytes()
-            gd = last[off_d + f * cap * 32: off_d + f * cap * 32 + n * 32].cpu().numpy().tobytes()
-            if not (n == len(wk) and int(h_m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
-                bad.append(f)
-        verified = dict(frames=picks, of_step="last timed step (slab %d)" % ((counter[0] - 1) % len(slabs)), against="oracle (CPU restatement)",
-                        compared="n, mono index, keypoints (28 B each), descriptors (32 B each)", keypoints=int(sum(int(h_n[f]) for f in picks)),
-                        bit_exact=not bad, mismatching_frames=bad)
+
+        def check(slab_t, r, picks_):
+            h_n = slab_t[off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
+            h_m = slab_t[off_m:off_m + 4 * B].cpu().numpy().view(np.int32)
+            kp = 0
+            for f in picks_:
+                # the gray frame the timed step read: this rank's own (for *_bgr: what k_gray wrote), or rank r's, rebuilt
+                img = d_img[f].cpu().numpy() if r == rank else stream_frames(r, f, 1)[0]
+                wm, wk, wd = orc.extract(img, wl["lapping"])
+                n = int(h_n[f])
+                gk = slab_t[off_k + f * cap * 28: off_k + f * cap * 28 + n * 28].cpu().numpy().tobytes() if 0 <= n <= cap else b""
+                gd = slab_t[off_d + f * cap * 32: off_d + f * cap * 32 + n * 32].cpu().numpy().tobytes() if 0 <= n <= cap else b""
+                if not (n == len(wk) and int(h_m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
+                    bad.append((r, f))
+                kp += max(n, 0)
+            return kp
+
+        picks = sorted({0, max(B // 2 - 1, 0), min(B // 2, B - 1), B - 1})       # first / last frame of each half-batch
+        kps_checked = check(slabs[kl], rank, picks)
+        ranks_checked = [0]
+        per_rank = {}
+        if gather and world > 1:
+            # rank 0's own arrived copy must be the slab it sent; of every other rank: two frames of what arrived
+            if not torch.equal(gathered[kl][0], slabs[kl]):
+                bad.append((0, -1))
+            for r in range(1, world):
+                pr = sorted({(7 * r) % B, B - 1})
+                kps_checked += check(gathered[kl][r], r, pr)
+                per_rank[str(r)] = pr
+                ranks_checked.append(r)
+        verified = dict(frames=picks, of_step="last timed step (slab %d)" % kl, against="oracle (CPU restatement)",
+                        compared="n, mono index, keypoints (28 B each), descriptors (32 B each)", keypoints=int(kps_checked),
+                        ranks_checked=ranks_checked, frames_of_other_ranks=per_rank or None,
+                        what="rank 0's slab" + ("; for ranks >= 1 the slab that ARRIVED through the gather, against the oracle on that rank's frames (rebuilt on rank 0)"
+                                                if per_rank else ""),
+                        bit_exact=not bad, mismatching_frames=[list(x) for x in bad])
         if bad:
-            print("bench.py: TIMED RESULTS DIFFER FROM THE ORACLE on frames %s" % bad, file=sys.stderr, flush=True)
+            print("bench.py: TIMED RESULTS DIFFER FROM THE ORACLE on (rank, frame) %s" % bad, file=sys.stderr, flush=True)
 
     result = None
-    if rank == 0:
+    if rank == 0 and stub:
+        result = {"metric": "REHEARSAL of bench.py's control flow (--stub-extractor): not a measurement", "value": None, "unit": "frames/s", "n_gpus": N,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                  "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "stub": True, "backend": args.backend,
+                  "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "variant": variant, "frames_per_gpu_per_step": B,
+                             "global_frames_per_step": N * B, "extractor": "oracle (CPU restatement) writing the slabs"},
+                  "verified": verified, "roofline": None, "cpu_baseline": None, "secondary": ({"configs4_64_per_gpu": cfg5} if cfg5 else None)}
+        print(json.dumps(result), flush=True)
+    if rank == 0 and not stub:
         # ---- per-kernel durations, HIP events on the handle's stream (separate, untimed pass) ----
         def profiled_step():
             ex.extract_batch_device(d_img, B, rows, cols, base + off_k, base + off_d, base + off_n, base + off_m, cap,
@@ -649,7 +735,7 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 3 if bad else 0      # a line whose timed results differ from the oracle is not a valid figure: the process says so
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 // ORBX_ERR_NO_DEVICE, and nothing here includes, links or calls anything under oracle/.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -163,19 +164,31 @@ struct orbx_handle {
     int* d_leafHist = nullptr;
     unsigned* d_leafBest = nullptr;
     uint8_t* d_leafCode = nullptr;
-    // outputs of the host path
+    // outputs of the host path: ONE result slab [n | mono | level counts | keypoints | descriptors | per-level keypoints], section-major for the
+    // frames of the call (outLayout), on the device (d_out) and in pinned host memory (h_out).  A batch comes back with ONE D2H copy of the part the
+    // caller asked for; ONE frame per call (the reference's call shape, Frame.cc:419-427) has no copy at all: the kernels write the slab in
+    // pinned host memory themselves (tools/host_zero_copy.py: +3.8 us on the kernels against 4-6 copy commands of ~10 us each)
     int outCap = 0;
-    Keypoint *d_outK = nullptr, *d_outLevelK = nullptr;
-    uint8_t* d_outD = nullptr;
-    int *d_nOut = nullptr, *d_monoOut = nullptr, *d_outLevelCounts = nullptr;
+    uint8_t *d_out = nullptr, *h_out = nullptr;
+    size_t outBytes = 0;
+    bool zeroCopy = true;              // ORBX_ZERO_COPY=0: a single frame also goes through d_out and the D2H copy
     // pinned staging
     int* h_lap = nullptr;
     std::vector<int> lapCached;
-    Keypoint *h_outK = nullptr, *h_outLevelK = nullptr;
-    uint8_t* h_outD = nullptr;
-    int *h_nOut = nullptr, *h_monoOut = nullptr, *h_outLevelCounts = nullptr;
+    uint8_t* h_in = nullptr;           // pageable input of a few frames is gathered here (tight rows), then ONE asynchronous H2D copy
+    size_t hInBytes = 0;
+    uint8_t* h_pyr = nullptr;          // orbx_fetch_pyramid: one frame's bordered levels (allocated on first use)
+    size_t hPyrBytes = 0;
+    // where the results of the last host-buffer batch are: as the kernels see them (dev: d_out, or h_out when written zero-copy) and on the host
+    struct OutView { Keypoint* k = nullptr; uint8_t* d = nullptr; int* n = nullptr; int* mono = nullptr; Keypoint* lk = nullptr; int* lc = nullptr; };
+    OutView dev, host;
+    bool pyramidOnly = false;          // the last call was orbx_compute_pyramid: the handle holds a pyramid (and blurred levels) but no results
+    bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
+    bool testFailAfterFast = false;    // ORBX_TEST_FAIL_AFTER_FAST (test aid)
+    bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
+    int lastPyrForm = -1, lastPyrCut = 0, lastBlurForm = -1;      // orbx_debug_last_forms
     int lastB = 0;
-    int lastHostB = 0;           // frames whose results the handle itself holds (d_outK / h_nOut ...): set by the host-buffer path only
+    int lastHostB = 0;           // frames whose results the handle itself holds (the result slab: h->dev / h->host): set by the host-buffer path only
     int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
     bool pendingLevels = false;
     // FAST kernel choice.  Both variants give identical results; the one that first rejects pixels with a cheap exact
@@ -236,17 +249,40 @@ int fail(orbx_handle* h, int code, const std::string& msg) {
 
 int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Byte offsets of the sections of the result slab for a call of B frames (capacity cap per frame).  What every caller wants comes first, so
+// that the D2H copy of a batch is one contiguous range: [0, noLevels) without the per-level arrays, [0, all) with them.
+struct OutLayout { size_t n, mono, counts, kps, desc, levelK, noLevels, all; };
+OutLayout outLayout(int B, int cap, int nlevels) {
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    OutLayout o;
+    o.n = 0;
+    o.mono = up(sizeof(int) * (size_t)B);
+    o.counts = o.mono + up(sizeof(int) * (size_t)B);
+    o.kps = o.counts + up(sizeof(int) * (size_t)B * nlevels);
+    o.desc = o.kps + up(sizeof(Keypoint) * (size_t)cap * B);
+    o.noLevels = o.desc + up((size_t)32 * cap * B);
+    o.levelK = o.noLevels;
+    o.all = o.levelK + up(sizeof(Keypoint) * (size_t)cap * B);
+    return o;
+}
+orbx_handle::OutView outView(uint8_t* base, const OutLayout& o) {
+    orbx_handle::OutView v;
+    v.n = (int*)(base + o.n); v.mono = (int*)(base + o.mono); v.lc = (int*)(base + o.counts);
+    v.k = (Keypoint*)(base + o.kps); v.d = base + o.desc; v.lk = (Keypoint*)(base + o.levelK);
+    return v;
+}
+
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_outK,
-                   h->d_outLevelK, h->d_outD, h->d_nOut, h->d_monoOut, h->d_outLevelCounts, h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
+                   h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->statEvent) (void)hipEventDestroy(h->statEvent);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->aux) (void)hipStreamDestroy(h->aux);
-    void* host[] = {h->h_candStat, h->h_lap, h->h_outK, h->h_outLevelK, h->h_outD, h->h_nOut, h->h_monoOut, h->h_outLevelCounts};
+    void* host[] = {h->h_candStat, h->h_lap, h->h_out, h->h_in, h->h_pyr};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -387,9 +423,10 @@ int checkFrameArgs(orbx_handle* h, int n_frames, int rows, int cols) {
 }
 
 // The launch sequence of one batch.  Everything is enqueued on h->stream; nothing synchronises.
+enum { kStageFront = 1, kStageBack = 2 };      // front: pyramid (+ blur) = ComputePyramid; back: FAST, quad-tree, orientation, descriptors
 int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int cols, long long stride,
                  long long frameStride, const int* lap, Keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_nOut,
-                 int* d_monoOut, Keypoint* d_levelK, int* d_levelCounts) {
+                 int* d_monoOut, Keypoint* d_levelK, int* d_levelCounts, int stages = kStageFront | kStageBack) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (rows != h->geom.rows || cols != h->geom.cols) {
         int rc = installGeometry(h, rows, cols);
@@ -397,6 +434,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     }
     const FrameGeom& g = h->geom;
     hipStream_t st = h->stream;
+    if (h->leafDirty) {      // an earlier call returned between k_fast and k_octree: the leaf tables still hold its counts
+        const size_t n = (size_t)h->leafFrames * h->nlevels * h->octR * kOctLeaves;
+        HIP_TRY(h, hipMemsetAsync(h->d_leafHist, 0, n * sizeof(int), st));
+        HIP_TRY(h, hipMemsetAsync(h->d_leafBest, 0, n * sizeof(unsigned), st));
+        h->leafDirty = false;
+    }
     Prof total(h, S_TOTAL);
     // lapping areas: upload only when they change (they are per-camera constants in the reference)
     {
@@ -448,6 +491,8 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         if (cs && h->pyrCols < 0 && (h->pyrColsWgs > 0 || !smallFrame) &&
             (long long)cs->columns.size() * Bn > (h->pyrColsWgs > 0 ? h->pyrColsWgs : 12LL * h->numCUs)) cs = nullptr;
         if (cs && h->pyrCols < 0 && h->fuseBlur) cs = nullptr;      // ORBX_FUSE_BLUR=1 asks for the per-level launches (which then carry the blur)
+        h->lastPyrCut = cs ? cs->px : 0;
+        h->lastPyrForm = cs ? 0 : (all ? 1 : 2);
         if (cs) {
             // workgroup shape (launchPyrCols): while every workgroup has a CU to itself, more threads shorten its levels - 1024 (512 derive, 512
             // write) for the fine cuts, 768 (256 + 512) for the coarse ones, whose levels write more than they derive; else 512 (256 + 256).
@@ -475,6 +520,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // cannot fill the chip anyway - ONE launch in which every tile re-derives what it needs of the levels in between (k_pyr_rest)
         const bool chain = h->pyrChain && g.nlevels > 2 && !g.chain.empty() && g.chainFits && g.chainLdsBytes <= 60 * 1024 &&
                            (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 16LL * h->numCUs);
+        if (!chain) h->lastPyrForm = 3;
         if (chain) {
             Prof p(h, S_RESIZE, st);
             pollute(st);
@@ -494,6 +540,8 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
+        h->lastBlurForm = blurRidesWithFast(Bn) ? 1 : (fused ? 2 : 0);
+        h->blurOwed = blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
         if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
             const int v = fused ? 2 : blurVariant(Bn);
@@ -502,6 +550,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
         }
     };
+    bool injected = false;
     auto back = [&](hipStream_t st, int f0, int Bn) {
         // small batches: k_fast's emit does the quad-tree's first sweep (leaf counters and best keys in L2); k_octree loads and clears them
         LeafTables lt{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
@@ -509,13 +558,20 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             lt = LeafTables{h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_leafCode + (size_t)g.nlevels * h->octXT, h->octR, h->octXT, g.nlevels, h->leafFrames};
         {
             Prof p(h, S_FAST, st);
-            const bool carry = blurRidesWithFast(Bn);
+            const bool carry = h->blurOwed && blurRidesWithFast(Bn);
+            if (h->blurOwed && !carry) {      // (a front part that counted on this launch, and a back part that cannot carry the blur: event profiling switched on in between)
+                launchBlur(st, h->d_tiles + h->blurItemOff[1], h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], kBlurBlockRowsSmall, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+            }
+            h->blurOwed = false;
             pollute(st);
+            if (lt.hist) h->leafDirty = true;
+            if (h->testFailAfterFast && lt.hist) { injected = true; h->testFailAfterFast = false; }      // (test aid: a call that dies between k_fast and k_octree)
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
                        h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
                        h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= (h->fastWideWgs > 0 ? h->fastWideWgs : 4LL * h->numCUs)));
         }
+        if (injected) return;
         {
             Prof p(h, S_OCTREE, st);
             // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
@@ -542,6 +598,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
+            h->leafDirty = false;
         }
         {
             Prof p(h, S_DESCRIBE, st);
@@ -558,9 +615,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // (front of one under FAST of the other, events between the streams at every stage) and four parts were both slower.
     // ORBX_SPLIT=0 turns it off; event profiling always runs unsplit so that one launch is one batch.
     const bool split = h->splitMode > 0 && !h->profiling && B >= 2 && (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
-    if (!split) {
-        front(st, 0, B);
-        back(st, 0, B);
+    const bool doFront = (stages & kStageFront) != 0, doBack = (stages & kStageBack) != 0;
+    if (!split || !doFront || !doBack) {
+        if (doFront) front(st, 0, B);
+        if (doBack) back(st, 0, B);
     } else {
         struct Join {      // the internal stream is always joined back into the caller's, also on an early error return
             orbx_handle* h; hipStream_t st; bool armed = false;
@@ -577,18 +635,50 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     }
     // statistics for the next batches' kernel choice; nobody waits for this copy.  Once a density is known the stream is sampled every 32nd
     // call only: the copy is a 4-us blit kernel on the stream, 7 % of a single-frame call
-    if (h->fastMode < 0 && !h->statPending && (h->candDensity < 0.f || (h->statCalls++ & 31) == 0)) {
+    if (doBack && !injected && h->fastMode < 0 && !h->statPending && (h->candDensity < 0.f || (h->statCalls++ & 31) == 0)) {
         HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipEventRecord(h->statEvent, st));
         h->statPending = true;
         h->statB = B;
     }
+    if (injected) return fail(h, ORBX_ERR_HIP, "ORBX_TEST_FAIL_AFTER_FAST: returned between k_fast and k_octree");
     HIP_TRY(h, hipGetLastError());
     h->lastB = B;
     h->lastHostB = 0;            // the caller's buffers hold this batch; orbx_extract_batch_begin sets it again for its own
+    h->pyramidOnly = !doBack;
     return ORBX_OK;
 }
 
+
+// The frames of a host-buffer call into the tight cols x rows x B device slab d_input, enqueued on the handle's stream.  Pinned input
+// (orbx_host_alloc) is copied asynchronously as it lies; a few frames of pageable input are first gathered row by row in the handle's pinned
+// staging (a hipMemcpyAsync from pageable memory stages inside the runtime and waits: 640x480 ~40 us against ~3 + ~15 here), which also turns a
+// strided cv::Mat into one copy; larger pageable batches are left to the runtime.
+int uploadFrames(orbx_handle* h, int B, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride, ptrdiff_t frame_stride) {
+    hipStream_t st = h->stream;
+    const size_t tight = (size_t)rows * cols, total = tight * B;
+    bool pinned = false;
+    {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, imgs) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();      // (older runtimes report unregistered memory as an error)
+    }
+    if (!pinned && total <= h->hInBytes) {
+        for (int f = 0; f < B; f++) {
+            const uint8_t* src = imgs + f * frame_stride;
+            uint8_t* dst = h->h_in + f * tight;
+            if (stride == cols) std::memcpy(dst, src, tight);
+            else for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * cols, src + (ptrdiff_t)y * stride, (size_t)cols);
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_input, h->h_in, total, hipMemcpyHostToDevice, st));
+    } else if (stride == cols && frame_stride == (ptrdiff_t)tight) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_input, imgs, total, hipMemcpyHostToDevice, st));
+    } else {
+        for (int f = 0; f < B; f++)
+            HIP_TRY(h, hipMemcpy2DAsync(h->d_input + (size_t)f * tight, cols, imgs + f * frame_stride, stride, cols, rows, hipMemcpyHostToDevice, st));
+    }
+    return ORBX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -774,13 +864,10 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 16 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_ALLOC(h->d_foot, sizeof(TileFoot) * h->footCap);
-    const size_t oc = (size_t)h->outCap * max_batch;
-    CREATE_ALLOC(h->d_outK, oc * sizeof(Keypoint));
-    CREATE_ALLOC(h->d_outLevelK, oc * sizeof(Keypoint));
-    CREATE_ALLOC(h->d_outD, oc * 32);
-    CREATE_ALLOC(h->d_nOut, sizeof(int) * max_batch);
-    CREATE_ALLOC(h->d_monoOut, sizeof(int) * max_batch);
-    CREATE_ALLOC(h->d_outLevelCounts, sizeof(int) * max_batch * nlevels);
+    h->outBytes = outLayout(max_batch, h->outCap, nlevels).all;
+    CREATE_ALLOC(h->d_out, h->outBytes);
+    h->testFailAfterFast = getenv("ORBX_TEST_FAIL_AFTER_FAST") && atoi(getenv("ORBX_TEST_FAIL_AFTER_FAST")) != 0;
+    h->zeroCopy = !(getenv("ORBX_ZERO_COPY") && atoi(getenv("ORBX_ZERO_COPY")) == 0);
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
@@ -800,12 +887,11 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;
     }   // diagnostic: the byte-gather form of k_resize
-    CREATE_TRY(hipHostMalloc(&h->h_outK, oc * sizeof(Keypoint)));
-    CREATE_TRY(hipHostMalloc(&h->h_outLevelK, oc * sizeof(Keypoint)));
-    CREATE_TRY(hipHostMalloc(&h->h_outD, oc * 32));
-    CREATE_TRY(hipHostMalloc(&h->h_nOut, sizeof(int) * max_batch));
-    CREATE_TRY(hipHostMalloc(&h->h_monoOut, sizeof(int) * max_batch));
-    CREATE_TRY(hipHostMalloc(&h->h_outLevelCounts, sizeof(int) * max_batch * nlevels));
+    CREATE_TRY(hipHostMalloc(&h->h_out, h->outBytes));
+    std::memset(h->h_out, 0, h->outBytes);
+    // pageable input up to this size is gathered in pinned memory first (a hipMemcpyAsync from pageable memory stages and waits inside the call)
+    h->hInBytes = std::min((size_t)max_width * max_height * max_batch, (size_t)8 << 20);
+    CREATE_TRY(hipHostMalloc(&h->h_in, h->hInBytes));
     // the border of the pyramid arena is only ever written by the kernels, but the padding bytes between
     // rows are never written: clear once so introspection copies are deterministic
     CREATE_TRY(hipMemset(h->d_pyr, 0, h->pyrBytes));
@@ -882,27 +968,18 @@ int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, 
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const int B = n_frames;
-    // H2D into a tight cols x rows x B slab (truly asynchronous when `imgs` is pinned: orbx_host_alloc)
-    if (stride == cols && frame_stride == (ptrdiff_t)rows * cols) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_input, imgs, (size_t)rows * cols * B, hipMemcpyHostToDevice, st));
-    } else {
-        for (int f = 0; f < B; f++)
-            HIP_TRY(h, hipMemcpy2DAsync(h->d_input + (size_t)f * rows * cols, cols, imgs + f * frame_stride, stride, cols,
-                                        rows, hipMemcpyHostToDevice, st));
-    }
-    const int cap = h->outCap;
-    rc = enqueueBatch(h, B, h->d_input, rows, cols, cols, (long long)rows * cols, lap, h->d_outK, h->d_outD, cap,
-                      h->d_nOut, h->d_monoOut, h->d_outLevelK, h->d_outLevelCounts);
+    rc = uploadFrames(h, B, imgs, rows, cols, stride, frame_stride);
     if (rc != ORBX_OK) return rc;
-    const size_t oc = (size_t)cap * B;
-    HIP_TRY(h, hipMemcpyAsync(h->h_nOut, h->d_nOut, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(h->h_monoOut, h->d_monoOut, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(h->h_outK, h->d_outK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(h->h_outD, h->d_outD, oc * 32, hipMemcpyDeviceToHost, st));
-    if (want_levels) {
-        HIP_TRY(h, hipMemcpyAsync(h->h_outLevelK, h->d_outLevelK, oc * sizeof(Keypoint), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipMemcpyAsync(h->h_outLevelCounts, h->d_outLevelCounts, sizeof(int) * B * h->nlevels, hipMemcpyDeviceToHost, st));
-    }
+    const int cap = h->outCap;
+    const OutLayout lo = outLayout(B, cap, h->nlevels);
+    // one frame per call: the kernels write the results into the pinned slab themselves (no copy command at all)
+    const bool zc = B == 1 && h->zeroCopy;
+    h->dev = outView(zc ? h->h_out : h->d_out, lo);
+    h->host = outView(h->h_out, lo);
+    rc = enqueueBatch(h, B, h->d_input, rows, cols, cols, (long long)rows * cols, lap, h->dev.k, h->dev.d, cap, h->dev.n, h->dev.mono,
+                      want_levels ? h->dev.lk : nullptr, want_levels ? h->dev.lc : nullptr);
+    if (rc != ORBX_OK) return rc;
+    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, want_levels ? lo.all : lo.noLevels, hipMemcpyDeviceToHost, st));
     h->pendingB = B;
     h->lastHostB = B;
     h->pendingLevels = want_levels != 0;
@@ -920,19 +997,20 @@ int orbx_extract_batch_end(orbx_handle* h, orbx_keypoint* kps, uint8_t* desc, in
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "per-level outputs requested but the batch was begun with want_levels = 0");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const orbx_handle::OutView& r = h->host;
     int status = ORBX_OK;
     for (int f = 0; f < B; f++) {
-        const int n = h->h_nOut[f];
+        const int n = r.n[f];
         n_out[f] = n;
-        mono_out[f] = h->h_monoOut[f];
+        mono_out[f] = r.mono[f];
         if (n > capacity || n > cap) {
             status = fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the caller's capacity");
             continue;
         }
-        std::memcpy(kps + (size_t)f * capacity, h->h_outK + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
-        std::memcpy(desc + (size_t)f * capacity * 32, h->h_outD + (size_t)f * cap * 32, (size_t)n * 32);
-        if (level_kps) std::memcpy(level_kps + (size_t)f * capacity, h->h_outLevelK + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
-        if (level_counts) std::memcpy(level_counts + (size_t)f * h->nlevels, h->h_outLevelCounts + (size_t)f * h->nlevels, sizeof(int) * h->nlevels);
+        std::memcpy(kps + (size_t)f * capacity, r.k + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
+        std::memcpy(desc + (size_t)f * capacity * 32, r.d + (size_t)f * cap * 32, (size_t)n * 32);
+        if (level_kps) std::memcpy(level_kps + (size_t)f * capacity, r.lk + (size_t)f * cap, (size_t)n * sizeof(Keypoint));
+        if (level_counts) std::memcpy(level_counts + (size_t)f * h->nlevels, r.lc + (size_t)f * h->nlevels, sizeof(int) * h->nlevels);
     }
     return status;
 }
@@ -945,8 +1023,8 @@ int orbx_extract_batch_end_view(orbx_handle* h, const orbx_keypoint** kps, const
     if (!kps || !desc || !capacity || !n_out || !mono_out) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *kps = (const orbx_keypoint*)h->h_outK; *desc = h->h_outD; *capacity = h->outCap;
-    *n_out = h->h_nOut; *mono_out = h->h_monoOut;
+    *kps = (const orbx_keypoint*)h->host.k; *desc = h->host.d; *capacity = h->outCap;
+    *n_out = h->host.n; *mono_out = h->host.mono;
     return ORBX_OK;
 }
 
@@ -974,6 +1052,112 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff
     const int lap[2] = {lap0, lap1};
     return orbx_extract_batch(h, 1, img, rows, cols, stride, (ptrdiff_t)rows * stride, lap, kps, desc, capacity, n_out,
                               mono_out, level_kps, level_counts);
+}
+
+int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1, int want_levels,
+                      const orbx_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_out, const orbx_keypoint** level_kps,
+                      const int** level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!img || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
+    if (!kps || !desc || !n_out || !mono_out || stride < cols || (want_levels && (!level_kps || !level_counts)))
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer or stride < cols");
+    const int lap[2] = {lap0, lap1};
+    int rc = orbx_extract_batch_begin(h, 1, img, rows, cols, stride, (ptrdiff_t)rows * stride, lap, want_levels);
+    if (rc != ORBX_OK) return rc;
+    h->pendingB = 0;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int n = h->host.n[0];
+    if (n < 0 || n > h->outCap) return fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the handle's capacity (internal bound violated)");
+    *kps = (const orbx_keypoint*)h->host.k; *desc = h->host.d; *n_out = n; *mono_out = h->host.mono[0];
+    if (want_levels) { *level_kps = (const orbx_keypoint*)h->host.lk; *level_counts = h->host.lc; }
+    return ORBX_OK;
+}
+
+int orbx_compute_pyramid(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "a batch is already in flight on this handle: call orbx_extract_batch_end first");
+    if (!img || rows <= 0 || cols <= 0) return fail(h, ORBX_ERR_EMPTY_IMAGE, "empty image");
+    if (stride < cols) return fail(h, ORBX_ERR_BAD_ARGUMENT, "stride < cols");
+    int rc = checkFrameArgs(h, 1, rows, cols);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = uploadFrames(h, 1, img, rows, cols, stride, (ptrdiff_t)rows * stride);
+    if (rc != ORBX_OK) return rc;
+    rc = enqueueBatch(h, 1, h->d_input, rows, cols, cols, (long long)rows * cols, nullptr, nullptr, nullptr, h->outCap, nullptr, nullptr, nullptr,
+                      nullptr, kStageFront);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // ComputePyramid returns with mvImagePyramid filled (ORBextractor.cc:1164-1219)
+    return ORBX_OK;
+}
+
+int orbx_compute_keypoints_octree(orbx_handle* h, orbx_keypoint* level_kps, int capacity, int* level_counts) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (!level_kps || !level_counts || capacity < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer or capacity < 1");
+    if (h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "a batch is already in flight on this handle: call orbx_extract_batch_end first");
+    if (h->geom.nlevels == 0 || h->lastB < 1)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_compute_keypoints_octree: the handle holds no pyramid (call orbx_compute_pyramid or an extract call first)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int cap = h->outCap;
+    const OutLayout lo = outLayout(1, cap, h->nlevels);
+    h->dev = outView(h->zeroCopy ? h->h_out : h->d_out, lo);
+    h->host = outView(h->h_out, lo);
+    // the stages after the pyramid on frame 0 of what the handle holds; the final arrays (level-0 coordinates, descriptors) are a by-product
+    int rc = enqueueBatch(h, 1, h->d_input, h->geom.rows, h->geom.cols, h->geom.cols, (long long)h->geom.rows * h->geom.cols, nullptr, h->dev.k,
+                          h->dev.d, cap, h->dev.n, h->dev.mono, h->dev.lk, h->dev.lc, kStageBack);
+    if (rc != ORBX_OK) return rc;
+    if (!h->zeroCopy) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.all, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->lastHostB = 1;
+    const int n = h->host.n[0];
+    if (n < 0 || n > cap) return fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the handle's capacity (internal bound violated)");
+    if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the caller's capacity");
+    std::memcpy(level_kps, h->host.lk, (size_t)n * sizeof(Keypoint));
+    std::memcpy(level_counts, h->host.lc, sizeof(int) * h->nlevels);
+    return ORBX_OK;
+}
+
+int orbx_fetch_pyramid(orbx_handle* h, int frame, const uint8_t** base, size_t* level_offset, int* level_stride, int* widths, int* heights) {
+    if (!h || !base || !level_offset || !level_stride || !widths || !heights) return ORBX_ERR_BAD_ARGUMENT;
+    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB)
+        return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_fetch_pyramid: no such frame in the last batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const FrameGeom& g = h->geom;
+    size_t total = 0;
+    for (int l = 0; l < g.nlevels; l++) total += (size_t)g.lv[l].pyrFrameBytes;
+    if (total > h->hPyrBytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->h_pyr) (void)hipHostFree(h->h_pyr);
+        h->h_pyr = nullptr; h->hPyrBytes = 0;
+        size_t want = 0;      // room for the largest geometry of the handle, so that this happens once
+        for (int l = 0; l < h->maxGeom.nlevels; l++) want += (size_t)h->maxGeom.lv[l].pyrStride * h->maxGeom.lv[l].pyrRows;
+        want = std::max(want + want / 8 + 4096, total);
+        HIP_TRY(h, hipHostMalloc(&h->h_pyr, want));
+        h->hPyrBytes = want;
+    }
+    // a handle made for one frame per call holds the levels of its frame back to back (level-major arena): ONE copy
+    bool contiguous = true;
+    for (int l = 1; l < g.nlevels; l++) contiguous = contiguous && g.lv[l].pyrOff + (long long)frame * g.lv[l].pyrFrameBytes ==
+                                                                     g.lv[l - 1].pyrOff + (long long)(frame + 1) * g.lv[l - 1].pyrFrameBytes;
+    size_t at = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        if (!contiguous) HIP_TRY(h, hipMemcpyAsync(h->h_pyr + at, h->d_pyr + L.pyrOff + (long long)frame * L.pyrFrameBytes, (size_t)L.pyrFrameBytes, hipMemcpyDeviceToHost, h->stream));
+        level_offset[l] = at + (size_t)kEdge * L.pyrStride + kPadL;      // interior pixel (0, 0); the REFLECT_101 frame of :1193-1215 lies around it
+        level_stride[l] = L.pyrStride; widths[l] = L.w; heights[l] = L.h;
+        at += (size_t)L.pyrFrameBytes;
+    }
+    if (contiguous) HIP_TRY(h, hipMemcpyAsync(h->h_pyr, h->d_pyr + g.lv[0].pyrOff + (long long)frame * g.lv[0].pyrFrameBytes, total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *base = h->h_pyr;
+    return ORBX_OK;
+}
+
+int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form) {
+    if (!h) return ORBX_ERR_BAD_ARGUMENT;
+    if (pyramid_form) *pyramid_form = h->lastPyrForm;
+    if (pyramid_cut_px) *pyramid_cut_px = h->lastPyrCut;
+    if (blur_form) *blur_form = h->lastBlurForm;
+    return ORBX_OK;
 }
 
 int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride, int* width,
@@ -1117,13 +1301,13 @@ int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float
                                               "(after orbx_extract_batch_device use orbx_stereo_match_device)");
     const int cap = h->outCap;
     for (int p = 0; p < n_pairs; p++) {     // counts of the left eyes, copied to the host by that call
-        const int n = h->h_nOut[2 * p];
+        const int n = h->host.n[2 * p];
         if (n < 0 || n > cap) return fail(h, ORBX_ERR_HIP, "corrupt keypoint count in the handle's staging (internal)");
         if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity smaller than the left keypoint count");
     }
     int rc = stereoEnsure(h, n_pairs, cap, h->geom.rows > 0 ? h->geom.rows : 1);
     if (rc != ORBX_OK) return rc;
-    rc = stereoEnqueue(h, n_pairs, h->d_outK, h->d_outD, h->d_nOut, cap, bf, b, h->d_uRight, h->d_depth, h->d_nMatched);
+    rc = stereoEnqueue(h, n_pairs, h->dev.k, h->dev.d, h->dev.n, cap, bf, b, h->d_uRight, h->d_depth, h->d_nMatched);
     if (rc != ORBX_OK) return rc;
     std::vector<float> hu((size_t)n_pairs * cap), hd((size_t)n_pairs * cap);
     HIP_TRY(h, hipMemcpyAsync(hu.data(), h->d_uRight, hu.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1131,7 +1315,7 @@ int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float
     HIP_TRY(h, hipMemcpyAsync(n_matched, h->d_nMatched, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int p = 0; p < n_pairs; p++) {
-        const int n = h->h_nOut[2 * p];
+        const int n = h->host.n[2 * p];
         std::memcpy(u_right + (size_t)p * capacity, hu.data() + (size_t)p * cap, sizeof(float) * n);
         std::memcpy(depth + (size_t)p * capacity, hd.data() + (size_t)p * cap, sizeof(float) * n);
     }

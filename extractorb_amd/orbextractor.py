@@ -126,6 +126,12 @@ def load_library():
     L.orbx_compute_level_sizes.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.orbx_compute_cell_grid.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + [ip] * 7
     L.orbx_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp, C.c_int, ip, ip, vp, vp]
+    L.orbx_extract_view.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), ip, ip,
+                                    C.POINTER(vp), C.POINTER(vp)]
+    L.orbx_compute_pyramid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t]
+    L.orbx_compute_keypoints_octree.argtypes = [vp, vp, C.c_int, vp]
+    L.orbx_fetch_pyramid.argtypes = [vp, C.c_int, C.POINTER(vp), vp, vp, vp, vp]
+    L.orbx_debug_last_forms.argtypes = [vp, ip, ip, ip]
     L.orbx_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, C.c_int,
                                      vp, vp, vp, vp]
     L.orbx_extract_batch_begin.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int]
@@ -513,9 +519,48 @@ class ORBextractor:
             return buf[:h.value + 38, :w.value + 38].copy()
         return buf[:h.value, :w.value].copy()
 
+    def fetch_pyramid(self, frame=0, bordered=False):
+        """All levels of one frame in ONE device-to-host copy (orbx_fetch_pyramid): a list of arrays, each a copy of the w x h level (or of
+        the (w + 38) x (h + 38) buffer with the BORDER_REFLECT_101 frame the reference's views sit in, ORBextractor.cc:1173-1177)."""
+        base = C.c_void_p()
+        off = np.zeros(self.nlevels, np.uint64); st = np.zeros(self.nlevels, np.int32)
+        w = np.zeros(self.nlevels, np.int32); h = np.zeros(self.nlevels, np.int32)
+        self._check(self._L.orbx_fetch_pyramid(self._h, frame, C.byref(base), _ptr(off), _ptr(st), _ptr(w), _ptr(h)))
+        out = []
+        for l in range(self.nlevels):
+            e = 19 if bordered else 0
+            rows, cols, stride = int(h[l]) + 2 * e, int(w[l]) + 2 * e, int(st[l])
+            start = base.value + int(off[l]) - e * stride - e
+            buf = (C.c_uint8 * (stride * rows)).from_address(start)
+            out.append(np.frombuffer(buf, np.uint8).reshape(rows, stride)[:, :cols].copy())
+        return out
+
     @property
     def mvImagePyramid(self):
-        return [self.image_pyramid_level(l) for l in range(self.nlevels)]
+        return self.fetch_pyramid()
+
+    # ---- the two public stage methods (inc/ORBextractor.h:87-90; src/orb_extractor/main_orb_extractor.cpp:43-46 calls them) ----
+    def ComputePyramid(self, image):
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1 or image.size == 0:
+            raise ValueError("image must be a non-empty 2-D uint8 array with contiguous rows (CV_8UC1)")
+        self._check(self._L.orbx_compute_pyramid(self._h, _ptr(image), image.shape[0], image.shape[1], image.strides[0]))
+
+    def ComputeKeyPointsOctTree(self):
+        """allKeypoints: one array per level, level coordinates, angles set (ORBextractor.cc:773-888)."""
+        cap = self.capacity
+        lvl = np.zeros(cap, KEYPOINT_DTYPE); counts = np.zeros(self.nlevels, np.int32)
+        self._check(self._L.orbx_compute_keypoints_octree(self._h, _ptr(lvl), cap, _ptr(counts)))
+        per_level, o = [], 0
+        for c in counts.tolist():
+            per_level.append(lvl[o:o + c].copy()); o += c
+        return per_level
+
+    def last_forms(self):
+        """(pyramid form, region side of k_pyr_cols, blur form) of the last call: include/orbx.h, orbx_debug_last_forms."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.orbx_debug_last_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     # ---- introspection for tests/bench ----
     def debug_candidates(self, level, frame=0):

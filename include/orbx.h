@@ -102,6 +102,26 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff
                  int lap1, orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out,
                  orbx_keypoint* level_kps, int* level_counts);
 
+/* The same call without the last copy: the results stay in the handle's pinned result slab and the caller gets pointers into it, valid
+ * until the next call on this handle (the C++ shim copies them straight into the caller's std::vector / cv::Mat: one copy instead of
+ * two).  want_levels != 0 also produces allLevelsKeypoints (level_kps flattened level by level, level_counts[nlevels]).  One frame per
+ * call has NO copy command on the stream: the image goes through pinned staging in one H2D copy and the kernels write the slab in host
+ * memory themselves. */
+int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1, int want_levels,
+                      const orbx_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_out, const orbx_keypoint** level_kps,
+                      const int** level_counts);
+
+/* Replaces the two public stage methods of the reference class (inc/ORBextractor.h:87-90: `protected:` is commented out so that callers
+ * can use them; src/orb_extractor/main_orb_extractor.cpp:43-46 and main_whole_orb_extractor.cpp:44-46 do):
+ *   void ORBextractor::ComputePyramid(cv::Mat image)                                        ORBextractor.cc:1164-1219
+ *   void ORBextractor::ComputeKeyPointsOctTree(vector<vector<KeyPoint>>& allKeypoints)      ORBextractor.cc:773-888
+ * orbx_compute_pyramid uploads one CV_8UC1 host image and builds the pyramid (mvImagePyramid: orbx_fetch_pyramid / orbx_get_level);
+ * orbx_compute_keypoints_octree runs cell-grid FAST, DistributeOctTree, the (16,16) shift / octave / size fix-up and the orientation on
+ * the pyramid the handle holds (from orbx_compute_pyramid or from any extract call: frame 0 of it) and returns allKeypoints flattened
+ * level by level in LEVEL coordinates with angles set, exactly what operator() hands out as allLevelsKeypoints (:1094).  Both synchronous. */
+int orbx_compute_pyramid(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride);
+int orbx_compute_keypoints_octree(orbx_handle* h, orbx_keypoint* level_kps, int capacity, int* level_counts);
+
 /* Batched form for a video stream or a stereo pair (the two std::threads of Frame.cc:109-112 become one
  * launch sequence).  All frames share rows/cols/stride; frame f starts at imgs + f*frame_stride.
  * Outputs are frame-major with a fixed per-frame capacity: kps[f*capacity + i], desc[(f*capacity+i)*32],
@@ -143,6 +163,13 @@ int orbx_extract_batch_device(orbx_handle* h, int n_frames, const uint8_t* d_img
  * (width+38) x (height+38) buffer with the BORDER_REFLECT_101 frame of ORBextractor.cc:1193-1215. */
 int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride,
                    int* width, int* height);
+
+/* All levels of frame `frame` of the last batch (or of orbx_compute_pyramid) in ONE device-to-host copy, for readers of mvImagePyramid
+ * (Frame.cc:820,910,924,929): *base points into pinned staging owned by the handle (valid until the next orbx_fetch_pyramid on it);
+ * level l is heights[l] rows of widths[l] pixels, pixel (0,0) at base[level_offset[l]], rows level_stride[l] bytes apart, and — as in the
+ * reference, where mvImagePyramid[l] is a view into a bordered buffer (ORBextractor.cc:1173-1177) — the 19-px BORDER_REFLECT_101 frame
+ * lies around it in the same buffer.  Arrays hold nlevels entries. */
+int orbx_fetch_pyramid(orbx_handle* h, int frame, const uint8_t** base, size_t* level_offset, int* level_stride, int* widths, int* heights);
 
 /* ---- next row beyond the extractor ------------------------------------------------------
  * Replaces Frame::ComputeStereoMatches() (reference src/Frame.cc:813-991) for stereo pairs extracted by ONE
@@ -338,6 +365,12 @@ int orbx_synchronize(orbx_handle* h);
 /* ---- introspection used by tests and bench.py (not part of the reference surface) ------------- */
 /* rounds the fixed-point projection search of the last launch needed for pair 0, and 100-MHz ticks of its staging / first scan / rounds */
 int orbx_debug_search_rounds(int* out4);
+
+/* Which launch forms the last call took (results never depend on them; the parity tests assert the form they mean to cover and the
+ * published timings name theirs): pyramid_form 0 = k_pyr_cols (region-major, *pyramid_cut_px = side of its regions), 1 = k_pyr_chain from
+ * the image (one launch), 2 = k_pyr_first + k_pyr_chain, 3 = k_pyr_first + one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the
+ * FAST launch, 2 = inside the k_resize launches, 3 = inside k_pyr_cols. */
+int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
 
 /* Stage outputs of frame `frame` of the last batch, copied to host.  Candidates are the reference's
  * vToDistributeKeys of one level (ORBextractor.cc:786-864) in rectangle coordinates; their order is

@@ -32,7 +32,9 @@ namespace orbx {
 //   static void            createU8(Mat&, int rows, int cols)   // like _descriptors.create(n, 32, CV_8U)
 //   static void            release(Mat&)
 //   static uint8_t*        mutableData(Mat&)
-//   static Mat             wrapCopy(const uint8_t* src, int rows, int cols, ptrdiff_t step)  // owning copy
+//   static Mat             wrapBordered(const uint8_t* src, int rows, int cols, ptrdiff_t step, int border)
+//                          // owning copy of the (rows + 2*border) x (cols + 2*border) buffer around src (= pixel (0,0)), returned as the
+//                          // rows x cols view into it: what mvImagePyramid[level] is in the reference (ORBextractor.cc:1173-1177)
 template <class Traits>
 class BasicORBextractor {
 public:
@@ -69,36 +71,58 @@ public:
         orbx_destroy(h_);
         h_ = nh; maxW_ = w; maxH_ = hgt;
         capacity_ = orbx_max_keypoints(h_);
-        kbuf_.resize(capacity_); lbuf_.resize(capacity_); dbuf_.resize((size_t)capacity_ * 32);
-        pyramidStale_ = true; lastRows_ = lastCols_ = 0;
+        mvImagePyramid.resize(nlevels);
     }
     BasicORBextractor(const BasicORBextractor&) = delete;
     BasicORBextractor& operator=(const BasicORBextractor&) = delete;
 
     // inc/ORBextractor.h:58-61 / ORBextractor.cc:1078-1162.  `mask` is ignored, as in the reference.
+    // One copy per output: the results come out of the handle's pinned slab straight into the caller's containers; no allocation in here
+    // beyond what the caller's own vectors / Mat need to grow.
     int operator()(const Mat& image, const Mat& /*mask*/, std::vector<KeyPoint>& keypoints, Mat& descriptors,
                    std::vector<int>& vLappingArea, std::vector<std::vector<KeyPoint>>& allLevelsKeypoints) {
         if (Traits::empty(image)) return -1;                                     // :1083-1084
         if (!Traits::isU8C1(image)) throw std::invalid_argument("ORBextractor: image.type() != CV_8UC1");   // assert :1087
         Reserve(Traits::cols(image), Traits::rows(image));                       // the reference has no size limit
         int n = 0, mono = 0;
-        std::vector<int> counts(nlevels);
-        int rc = orbx_extract(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image),
-                              vLappingArea.at(0), vLappingArea.at(1), reinterpret_cast<orbx_keypoint*>(kbuf_.data()),
-                              dbuf_.data(), capacity_, &n, &mono, reinterpret_cast<orbx_keypoint*>(lbuf_.data()), counts.data());
+        const orbx_keypoint *k = nullptr, *lk = nullptr;
+        const uint8_t* d = nullptr;
+        const int* counts = nullptr;
+        int rc = orbx_extract_view(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image),
+                                   vLappingArea.at(0), vLappingArea.at(1), 1, &k, &d, &n, &mono, &lk, &counts);
         if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
-        keypoints.assign(kbuf_.begin(), kbuf_.begin() + n);                      // _keypoints = vector<KeyPoint>(nkeypoints) :1112
+        const KeyPoint* kp = reinterpret_cast<const KeyPoint*>(k);
+        keypoints.assign(kp, kp + n);                                            // _keypoints = vector<KeyPoint>(nkeypoints) :1112
         if (n == 0) Traits::release(descriptors);                                // :1102-1103
         else {
             Traits::createU8(descriptors, n, 32);                                // :1106
-            std::memcpy(Traits::mutableData(descriptors), dbuf_.data(), (size_t)n * 32);
+            std::memcpy(Traits::mutableData(descriptors), d, (size_t)n * 32);
         }
-        allLevelsKeypoints.assign(nlevels, std::vector<KeyPoint>());             // :1094
-        for (int l = 0, o = 0; l < nlevels; o += counts[l], l++)
-            allLevelsKeypoints[l].assign(lbuf_.begin() + o, lbuf_.begin() + o + counts[l]);
-        pyramidStale_ = true;
-        lastRows_ = Traits::rows(image); lastCols_ = Traits::cols(image);
+        const KeyPoint* lp = reinterpret_cast<const KeyPoint*>(lk);
+        allLevelsKeypoints.resize(nlevels);                                      // :1094
+        for (int l = 0, o = 0; l < nlevels; o += counts[l], l++) allLevelsKeypoints[l].assign(lp + o, lp + o + counts[l]);
+        mvImagePyramid.invalidate();
         return mono;                                                             // :1161
+    }
+
+    // inc/ORBextractor.h:87-90: the reference comments `protected:` out so that its demos can call the two stages themselves
+    // (src/orb_extractor/main_orb_extractor.cpp:43-46).  ComputePyramid fills mvImagePyramid (here: the pyramid in HBM, fetched on first
+    // access); ComputeKeyPointsOctTree works on the pyramid the extractor holds and hands out level coordinates with angles (:773-888).
+    void ComputePyramid(Mat image) {
+        if (Traits::empty(image)) throw std::invalid_argument("ORBextractor::ComputePyramid: empty image");
+        if (!Traits::isU8C1(image)) throw std::invalid_argument("ORBextractor: image.type() != CV_8UC1");
+        Reserve(Traits::cols(image), Traits::rows(image));
+        int rc = orbx_compute_pyramid(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image));
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_compute_pyramid: ") + orbx_last_error(h_));
+        mvImagePyramid.invalidate();
+    }
+    void ComputeKeyPointsOctTree(std::vector<std::vector<KeyPoint>>& allKeypoints) {
+        lbuf_.resize(capacity_);
+        counts_.resize(nlevels);
+        int rc = orbx_compute_keypoints_octree(h_, reinterpret_cast<orbx_keypoint*>(lbuf_.data()), capacity_, counts_.data());
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_compute_keypoints_octree: ") + orbx_last_error(h_));
+        allKeypoints.resize(nlevels);                                            // :775
+        for (int l = 0, o = 0; l < nlevels; o += counts_[l], l++) allKeypoints[l].assign(lbuf_.begin() + o, lbuf_.begin() + o + counts_[l]);
     }
 
     int GetLevels() { return nlevels; }                                          // inc/ORBextractor.h:63-83
@@ -108,24 +132,36 @@ public:
     std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // mvImagePyramid is a public member of the reference (inc/ORBextractor.h:85) that
-    // Frame::ComputeStereoMatches reads after the call (src/Frame.cc:820,910,929).  The pyramid lives in HBM;
-    // call FetchImagePyramid() before touching the member (one D2H copy per level, only for callers that need it).
-    std::vector<Mat> mvImagePyramid;
-    void FetchImagePyramid() {
-        if (!pyramidStale_ || lastRows_ == 0) return;
-        std::vector<int> ws(nlevels), hs(nlevels);
-        orbx_compute_level_sizes((float)scaleFactor, nlevels, lastRows_, lastCols_, ws.data(), hs.data());
-        std::vector<uint8_t> tmp;
-        for (int l = 0; l < nlevels; l++) {
-            int w = 0, hgt = 0;
-            tmp.resize((size_t)ws[l] * hs[l]);
-            int rc = orbx_get_level(h_, 0, l, 0, tmp.data(), ws[l], &w, &hgt);
-            if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_get_level: ") + orbx_last_error(h_));
-            mvImagePyramid[l] = Traits::wrapCopy(tmp.data(), hgt, w, ws[l]);
-        }
-        pyramidStale_ = false;
-    }
+    // mvImagePyramid is a public member of the reference (inc/ORBextractor.h:85) that Frame::ComputeStereoMatches indexes right after the
+    // call (src/Frame.cc:820,910,924,929).  Here the pyramid lives in HBM, so the member is a view that behaves like the reference's
+    // std::vector<cv::Mat> for its readers — operator[], at, size, begin / end, conversion to const std::vector<Mat>& — and brings the levels
+    // to the host on the FIRST access after a call (one device-to-host copy of the whole bordered pyramid, orbx_fetch_pyramid; nothing is
+    // copied for callers that never look).  Each level is, as in the reference (ORBextractor.cc:1173-1177), a w x h view into its own
+    // (w + 38) x (h + 38) buffer with the BORDER_REFLECT_101 frame around it, and owns that buffer (a Mat taken from it stays valid).
+    class ImagePyramid {
+    public:
+        explicit ImagePyramid(BasicORBextractor* owner) : owner_(owner) {}
+        Mat& operator[](size_t l) { fetch(); return levels_[l]; }
+        const Mat& operator[](size_t l) const { fetch(); return levels_[l]; }
+        Mat& at(size_t l) { fetch(); return levels_.at(l); }
+        const Mat& at(size_t l) const { fetch(); return levels_.at(l); }
+        size_t size() const { return levels_.size(); }
+        bool empty() const { return levels_.empty(); }
+        typename std::vector<Mat>::iterator begin() { fetch(); return levels_.begin(); }
+        typename std::vector<Mat>::iterator end() { fetch(); return levels_.end(); }
+        typename std::vector<Mat>::const_iterator begin() const { fetch(); return levels_.begin(); }
+        typename std::vector<Mat>::const_iterator end() const { fetch(); return levels_.end(); }
+        operator const std::vector<Mat>&() const { fetch(); return levels_; }
+        void resize(size_t n) { levels_.resize(n); }                             // ORBextractor.cc:437
+        void invalidate() { stale_ = true; }
+    private:
+        void fetch() const { if (stale_) owner_->fetchLevels(levels_); stale_ = false; }
+        BasicORBextractor* owner_;
+        mutable std::vector<Mat> levels_;
+        mutable bool stale_ = false;
+    };
+    ImagePyramid mvImagePyramid{this};
+    void FetchImagePyramid() { (void)mvImagePyramid[0]; }                        // the explicit form (kept from the first version of this header)
 
     // the remaining public data members of the reference class (inc/ORBextractor.h:95-110)
     int nfeatures;
@@ -143,13 +179,20 @@ public:
     orbx_handle* handle() { return h_; }
 
 private:
+    void fetchLevels(std::vector<Mat>& levels) {
+        const uint8_t* base = nullptr;
+        size_t off[ORBX_MAX_LEVELS];
+        int stride[ORBX_MAX_LEVELS], w[ORBX_MAX_LEVELS], hgt[ORBX_MAX_LEVELS];
+        int rc = orbx_fetch_pyramid(h_, 0, &base, off, stride, w, hgt);
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error(h_));
+        levels.resize(nlevels);
+        for (int l = 0; l < nlevels; l++) levels[l] = Traits::wrapBordered(base + off[l], hgt[l], w[l], stride[l], ORBX_EDGE_THRESHOLD);
+    }
     orbx_handle* h_ = nullptr;
     int device_ = -1, maxW_ = 0, maxH_ = 0;
-    int lastRows_ = 0, lastCols_ = 0;
     int capacity_ = 0;
-    bool pyramidStale_ = true;
-    std::vector<KeyPoint> kbuf_, lbuf_;
-    std::vector<uint8_t> dbuf_;
+    std::vector<KeyPoint> lbuf_;
+    std::vector<int> counts_;
 };
 
 }  // namespace orbx
@@ -170,7 +213,10 @@ struct CvTraits {
     static void createU8(Mat& m, int r, int c) { m.create(r, c, CV_8U); }
     static void release(Mat& m) { m.release(); }
     static uint8_t* mutableData(Mat& m) { return m.data; }
-    static Mat wrapCopy(const uint8_t* s, int r, int c, ptrdiff_t step) { return Mat(r, c, CV_8UC1, (void*)s, (size_t)step).clone(); }
+    static Mat wrapBordered(const uint8_t* s, int r, int c, ptrdiff_t step, int b) {
+        Mat whole = Mat(r + 2 * b, c + 2 * b, CV_8UC1, (void*)(s - (ptrdiff_t)b * step - b), (size_t)step).clone();      // Mat temp(wholeSize, image.type()), :1174
+        return whole(cv::Rect(b, b, c, r));                                                                              // temp(Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, sz.width, sz.height)), :1175
+    }
 };
 }  // namespace orbx
 namespace ORB_SLAM3 {

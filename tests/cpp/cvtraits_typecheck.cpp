@@ -37,8 +37,9 @@ int main(int argc, char** argv) {
         try { cv::Mat bgr(rows, cols, CV_8UC3); std::vector<cv::KeyPoint> k; cv::Mat d; vector<vector<cv::KeyPoint>> a; (*mpORBextractorLeft)(bgr, cv::Mat(), k, d, vLapping, a); }
         catch (const std::invalid_argument&) { refused = true; }
         if (!refused) return 5;
-        mpORBextractorLeft->FetchImagePyramid();        // Frame::ComputeStereoMatches reads mvImagePyramid (Frame.cc:820)
-        if (mpORBextractorLeft->mvImagePyramid.size() != 8 || mpORBextractorLeft->mvImagePyramid[0].cols != cols) return 6;
+        // Frame::ComputeStereoMatches reads mvImagePyramid right after the call (Frame.cc:820): no call in between
+        const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
+        if (mpORBextractorLeft->mvImagePyramid.size() != 8 || mpORBextractorLeft->mvImagePyramid[0].cols != cols || nRows != rows) return 6;
         FILE* o = fopen(argv[5], "wb");
         int n = (int)mvKeys.size();
         fwrite(&monoLeft, 4, 1, o); fwrite(&n, 4, 1, o);

@@ -32,6 +32,7 @@ struct MatStep {           // Mat::step converts to size_t
     size_t v = 0;
     operator size_t() const { return v; }
 };
+struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {} };
 class Mat {
 public:
     Mat() {}
@@ -52,6 +53,12 @@ public:
         for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step.v, data + (size_t)y * step.v, m.step.v);
         return m;
     }
+    // views that share the buffer (and keep it alive), as Mat::operator()(Rect) / rowRange / colRange do
+    Mat operator()(const Rect& r) const { Mat m(*this); m.data = data + (size_t)r.y * step.v + r.x; m.rows = r.height; m.cols = r.width; return m; }
+    Mat rowRange(int a, int b) const { return (*this)(Rect(0, a, cols, b - a)); }
+    Mat colRange(int a, int b) const { return (*this)(Rect(a, 0, b - a, rows)); }
+    template <class T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step.v + x * sizeof(T)); }
+    template <class T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step.v + x * sizeof(T)); }
     int rows = 0, cols = 0;
     uchar* data = nullptr;
     MatStep step;

@@ -18,7 +18,7 @@
 namespace mini {
 struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
 struct Mat {
-    int rows = 0, cols = 0; ptrdiff_t step = 0; std::vector<uint8_t> buf;
+    int rows = 0, cols = 0; ptrdiff_t step = 0; std::vector<uint8_t> buf, border;
     bool empty() const { return rows == 0 || cols == 0; }
 };
 struct Traits {
@@ -33,9 +33,12 @@ struct Traits {
     static void createU8(Mat& m, int r, int c) { m.rows = r; m.cols = c; m.step = c; m.buf.assign((size_t)r * c, 0); }
     static void release(Mat& m) { m = Mat(); }
     static uint8_t* mutableData(Mat& m) { return m.buf.data(); }
-    static Mat wrapCopy(const uint8_t* s, int r, int c, ptrdiff_t step) {
+    // mini::Mat has no views: the level's pixels are copied out of the bordered buffer, the border itself into `frame` (rows above, ..)
+    static Mat wrapBordered(const uint8_t* s, int r, int c, ptrdiff_t step, int b) {
         Mat m; createU8(m, r, c);
-        for (int y = 0; y < r; y++) std::memcpy(m.buf.data() + (size_t)y * c, s + (size_t)y * step, c);
+        for (int y = 0; y < r; y++) std::memcpy(m.buf.data() + (size_t)y * c, s + (ptrdiff_t)y * step, c);
+        m.border.assign((size_t)(r + 2 * b) * (c + 2 * b), 0);
+        for (int y = -b; y < r + b; y++) std::memcpy(m.border.data() + (size_t)(y + b) * (c + 2 * b), s + (ptrdiff_t)y * step - b, c + 2 * b);
         return m;
     }
 };

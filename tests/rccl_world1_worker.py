@@ -28,16 +28,19 @@ def main():
     slabs = [torch.zeros(lay["bytes"], dtype=torch.uint8, device="cuda") for _ in range(2)]
     gathered = [[torch.empty_like(slabs[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
     pending = [None, None]
-    inputs = []
+
+    def frames_of(step, r):
+        """rank r's frames of a step: a pure function of (step, rank), so that rank 0 can rebuild what every other rank extracted"""
+        lo, hi = sharding.shard_range(world * B, r, world)
+        return synth.frames(["textured", "noise"][step & 1], 1000 * step + lo, hi - lo, rows, cols)
+
     for s in range(steps):
-        lo, hi = sharding.shard_range(world * B, rank, world)
-        fr = synth.frames(["textured", "noise"][s & 1], 1000 * s + lo, hi - lo, rows, cols)
-        inputs.append(fr)
+        fr = frames_of(s, rank)
         k = s & 1
         if pending[k] is not None:
             pending[k].wait()
             if rank == 0:       # the slab of step s - 2 has arrived: check it before its buffers are reused
-                check(gathered[k], inputs[s - 2], B, cap, nf, world)
+                check(gathered[k], lambda r: frames_of(s - 2, r), B, cap, nf, world)
         b = slabs[k].data_ptr()
         ex.extract_batch_device(torch.from_numpy(fr).cuda(), B, rows, cols, b + lay["keypoints"], b + lay["descriptors"], b + lay["n"],
                                 b + lay["mono"], cap)
@@ -46,18 +49,20 @@ def main():
         pending[s & 1].wait()
         torch.cuda.synchronize()
         if rank == 0:
-            check(gathered[s & 1], inputs[s], B, cap, nf, world)
+            check(gathered[s & 1], lambda r, s=s: frames_of(s, r), B, cap, nf, world)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         print("RCCL_WORLD1_OK steps=%d frames_per_step=%d" % (steps, B))
 
 
-def check(bufs, frames, B, cap, nf, world):
+def check(bufs, frames_of_rank, B, cap, nf, world):
+    """every rank's gathered slab against the oracle on THAT rank's frames"""
     torch.cuda.synchronize()
     o = O.Oracle(nf)
     for r in range(world):
         got = sharding.unpack_slab(bufs[r].cpu().numpy(), B, cap)
+        frames = frames_of_rank(r)
         for f in range(B):
             mono, k, d = o.extract(frames[f])
             assert got[f][0] == mono and got[f][1].tobytes() == k.tobytes() and np.array_equal(got[f][2], d), "rank %d frame %d" % (r, f)

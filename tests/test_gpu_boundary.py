@@ -1,0 +1,170 @@
+"""The boundary of round 4 on the GPU, through the C ABI: the reference class's two public stage methods (ComputePyramid,
+ComputeKeyPointsOctTree: inc/ORBextractor.h:87-90), the one-copy pyramid fetch behind mvImagePyramid (:85), the host-in / host-out call of
+one frame (results written by the kernels into the pinned result slab: no copy command), the result slab of a batch (one D2H copy), the
+leaf-table guard, and the launch forms a call reports."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import extractorb_amd as X
+from extractorb_amd import synth
+from helpers import assert_same_result, load_gray
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_run(img, nf=1000, lap=(0, 1000)):
+    o = O.Oracle(nf, 1.2, 8, 20, 7)
+    return o, o.extract(img, lap)
+
+
+@pytest.mark.parametrize("shape,nf,variant", [((480, 640), 1000, "textured"), ((512, 512), 1500, "tum"), ((1080, 1920), 2000, "noise"), ((333, 517), 700, "sparse")])
+def test_stage_methods_equal_the_oracle(shape, nf, variant):
+    """main_orb_extractor.cpp:43-46: ComputePyramid(image), then ComputeKeyPointsOctTree(allKeypoints): level coordinates, angles set."""
+    img = load_gray("tum_room4_gray.png") if variant == "tum" else synth.frames(variant, 5, 1, *shape)[0]
+    o, _ = oracle_run(img, nf)
+    ex = X.ORBextractor(nf, 1.2, 8, 20, 7, max_width=img.shape[1], max_height=img.shape[0])
+    ex.ComputePyramid(img)
+    for l, (got, gotb) in enumerate(zip(ex.fetch_pyramid(), ex.fetch_pyramid(bordered=True))):      # mvImagePyramid right after ComputePyramid
+        assert np.array_equal(got, o.level(l)) and np.array_equal(gotb, o.level(l, bordered=True)), "level %d" % l
+    lvl = ex.ComputeKeyPointsOctTree()
+    assert [len(x) for x in lvl] == [len(o.level_keypoints(l)) for l in range(8)]
+    for l in range(8):
+        assert lvl[l].tobytes() == o.level_keypoints(l).tobytes(), "level %d" % l
+    if variant == "tum":
+        assert sum(len(x) for x in lvl) == 1420          # img_folder/Screenshot.png (tests/test_reference_pin.py)
+    # the stages again on the same pyramid give the same answer; a full call afterwards is unaffected
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(ex.ComputeKeyPointsOctTree(), lvl))
+    mono, k, d, lvl2 = ex(img)
+    assert_same_result((mono, k, d), o.extract(img, (0, 1000)), "operator() after the stage methods")
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(lvl2, lvl))
+
+
+def test_stage_method_on_the_pyramid_of_a_full_call_and_without_one():
+    img = synth.frames("textured", 8, 1, 480, 640)[0]
+    o, want = oracle_run(img)
+    ex = X.ORBextractor(1000)
+    with pytest.raises(X.OrbxError):
+        ex.ComputeKeyPointsOctTree()                      # no pyramid yet
+    ex(img)
+    lvl = ex.ComputeKeyPointsOctTree()                    # the pyramid operator() left
+    assert all(lvl[l].tobytes() == o.level_keypoints(l).tobytes() for l in range(8))
+    # ... and frame 0 of a batch's
+    frames = synth.frames("noise", 20, 3, 480, 640)
+    exb = X.ORBextractor(1000, max_batch=3)
+    exb.extract_batch(frames)
+    o0, _ = oracle_run(frames[0])
+    lvl = exb.ComputeKeyPointsOctTree()
+    assert all(lvl[l].tobytes() == o0.level_keypoints(l).tobytes() for l in range(8))
+
+
+def test_pyramid_fetch_of_every_frame_of_a_batch():
+    frames = synth.frames("textured", 30, 5, 300, 400)
+    ex = X.ORBextractor(500, max_width=400, max_height=300, max_batch=8)
+    ex.extract_batch(frames)
+    for f in (0, 3, 4):
+        o, _ = oracle_run(frames[f], 500)
+        for l, (a, b) in enumerate(zip(ex.fetch_pyramid(f), ex.fetch_pyramid(f, bordered=True))):
+            assert np.array_equal(a, o.level(l)) and np.array_equal(b, o.level(l, bordered=True)), (f, l)
+    with pytest.raises(X.OrbxError):
+        ex.fetch_pyramid(5)                               # not a frame of the last batch
+
+
+def _extract_view(ex, img, lap=(0, 1000), want_levels=1):
+    L, h = ex._L, ex._h
+    k, d, lk, lc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n, mono = C.c_int(), C.c_int()
+    rc = L.orbx_extract_view(h, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1], want_levels, C.byref(k), C.byref(d),
+                             C.byref(n), C.byref(mono), C.byref(lk), C.byref(lc))
+    assert rc == 0, L.orbx_last_error(h)
+    kk = np.frombuffer((C.c_uint8 * (28 * n.value)).from_address(k.value), X.KEYPOINT_DTYPE).copy()
+    dd = np.frombuffer((C.c_uint8 * (32 * n.value)).from_address(d.value), np.uint8).reshape(-1, 32).copy()
+    lv = None
+    if want_levels:
+        counts = np.frombuffer((C.c_int32 * ex.nlevels).from_address(lc.value), np.int32).copy()
+        lv = np.frombuffer((C.c_uint8 * (28 * n.value)).from_address(lk.value), X.KEYPOINT_DTYPE).copy(), counts
+    return mono.value, kk, dd, lv
+
+
+@pytest.mark.parametrize("zero_copy", ["1", "0"])
+def test_one_frame_host_call_forms(zero_copy, monkeypatch):
+    """orbx_extract_view / orbx_extract on pageable, strided and pinned images: results written by the kernels into pinned host memory
+    (default) or copied back in one piece (ORBX_ZERO_COPY=0) are the oracle's."""
+    monkeypatch.setenv("ORBX_ZERO_COPY", zero_copy)
+    big = synth.frames("textured", 60, 1, 500, 700)[0]
+    sub = big[7:487, 13:653]                              # a cv::Mat ROI: 640x480, step 700, unaligned start
+    o, want = oracle_run(np.ascontiguousarray(sub), 1000, (100, 300))
+    ex = X.ORBextractor(1000)
+    for img in (sub, np.ascontiguousarray(sub)):
+        mono, k, d, (lk, counts) = _extract_view(ex, img, (100, 300))
+        assert_same_result((mono, k, d), want, "view, zero copy %s" % zero_copy)
+        assert counts.tolist() == [len(o.level_keypoints(l)) for l in range(8)]
+        assert lk.tobytes() == b"".join(o.level_keypoints(l).tobytes() for l in range(8))
+        mono, k, d, _ = _extract_view(ex, img, (100, 300), want_levels=0)
+        assert_same_result((mono, k, d), want, "view without levels")
+        assert_same_result(ex(img, None, (100, 300))[:3], want, "orbx_extract")
+    pin = X.pinned_empty((480, 640))
+    pin[...] = sub
+    assert_same_result(_extract_view(ex, pin, (100, 300))[:3], want, "pinned image")
+    X.pinned_free(pin)
+
+
+def test_batch_results_come_back_in_one_slab():
+    """A batch through the host-buffer path (one D2H copy of the result slab), with and without the per-level arrays, odd sizes."""
+    frames = synth.frames("noise", 70, 5, 480, 640)
+    ex = X.ORBextractor(1000, max_batch=8)
+    out = ex.extract_batch(frames[:5], lapping=(0, 0))
+    for f in range(5):
+        o, want = oracle_run(frames[f], 1000, (0, 0))
+        assert_same_result(out[f][:3], want, "frame %d" % f)
+        assert all(out[f][3][l].tobytes() == o.level_keypoints(l).tobytes() for l in range(8))
+    one = ex.extract_batch(frames[4:5])                   # one frame through the batch entry point (zero-copy slab again)
+    assert_same_result(one[0][:3], oracle_run(frames[4])[1], "batch of one")
+
+
+def test_a_call_that_dies_between_fast_and_quadtree_leaves_no_stale_leaf_tables():
+    """the leaf tables k_fast fills are only zero again once k_octree has consumed them.  A call that returns in between
+    (injected: ORBX_TEST_FAIL_AFTER_FAST, one shot) must not inflate the next call's counts."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["ORBX_TEST_FAIL_AFTER_FAST"] = "1"
+import numpy as np
+import extractorb_amd as X, oracle_lib as O
+from extractorb_amd import synth
+img = synth.frames("noise", 3, 2, 480, 640)
+ex = X.ORBextractor(1000)
+try:
+    ex(img[0]); print("NOFAIL")
+except X.OrbxError as e:
+    assert "ORBX_TEST_FAIL_AFTER_FAST" in str(e), e
+mono, k, d, lvl = ex(img[1])
+wm, wk, wd = O.Oracle(1000).extract(img[1], (0, 1000))
+assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd), "stale leaf tables"
+print("OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "NOFAIL" not in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shape,nf,B,form", [((480, 640), 1000, 1, 0), ((480, 640), 1000, 64, 0), ((720, 1280), 1500, 1, 0), ((1080, 1920), 2000, 1, 0),
+                                             ((1080, 1920), 2000, 24, 3)])
+def test_reported_launch_forms(shape, nf, B, form):
+    """the published single-frame and traffic figures assume the region-major pyramid; a sizing regression that quietly
+    falls back to the tile forms must fail a test, not just change a timing."""
+    frames = synth.frames("noise", 0, min(B, 2), *shape)
+    frames = np.concatenate([frames] * ((B + len(frames) - 1) // len(frames)))[:B]
+    ex = X.ORBextractor(nf, max_width=shape[1], max_height=shape[0], max_batch=B)
+    out = ex.extract_batch(frames)
+    pyr, cut, blur = ex.last_forms()
+    assert pyr == form, (pyr, cut, blur)
+    if form == 0:
+        assert cut in (40, 56, 80, 112)
+    o, want = oracle_run(frames[B - 1], nf)
+    assert_same_result(out[B - 1][:3], want, "%s x %d" % (shape, B))
