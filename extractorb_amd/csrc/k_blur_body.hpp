@@ -65,6 +65,61 @@ __device__ __forceinline__ void blurBlock(Load load, Store store) {
     }
 }
 
+// The same arithmetic for a run of nOut output rows whose length is only known at run time (k_pyr_cols: a region's share of a level, dealt over
+// the threads that blur): input rows i = 0 .. nOut + 5 through load(i, ...), output row r through store(r, word).  Two rows per trip, so that
+// which halves of which pairs an output row uses stays static (an even row first: the run starts on an even i); an odd nOut computes one
+// output more than it stores.
+template <class Load, class Store>
+__device__ __forceinline__ void blurRun(const int nOut, Load load, Store store) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](unsigned pair, unsigned short w0, unsigned short w1, unsigned acc) {
+        return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), u16x2{w0, w1}, acc, false);
+    };
+    unsigned P[4][4] = {}, lo[4] = {};
+    auto hsums = [&](int i, unsigned (&hn)[4]) {
+        unsigned d0, d1, d2;
+        load(i, d0, d1, d2);
+        hn[0] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1));
+        hn[1] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2));
+        hn[2] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3));
+        hn[3] = hsum4(d1, d2);
+    };
+    auto pack = [](const unsigned (&t)[4]) {
+        const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(t[3], t[2], 0x0C0C0602u);
+        return (p23 << 16) | p01;
+    };
+    auto even = [&](int i) {          // row i (even) arrives: it waits for its partner
+        unsigned hn[4];
+        hsums(i, hn);
+#pragma unroll
+        for (int j = 0; j < 4; j++) lo[j] = hn[j];
+    };
+    auto odd = [&](int i) {           // row i (odd) arrives: the pair (i - 1, i) is complete
+        unsigned hn[4];
+        hsums(i, hn);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            P[0][j] = P[1][j]; P[1][j] = P[2][j]; P[2][j] = P[3][j];
+            P[3][j] = (hn[j] << 16) | lo[j];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 6; i += 2) { even(i); odd(i + 1); }
+    for (int i = 6; i < nOut + 6; i += 2) {
+        unsigned t[4];
+        even(i);                      // rows i-6 .. i = P[1], P[2], P[3], the waiting even row
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            t[j] = min(dot2(lo[j], 18, 0, dot2(P[3][j], 49, 34, dot2(P[2][j], 49, 55, dot2(P[1][j], 18, 34, 32768u)))), 0x00FFFFFFu);
+        store(i - 6, pack(t));
+        odd(i + 1);                   // rows i-5 .. i+1 = high half of P[0], P[1], P[2], P[3]
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            t[j] = min(dot2(P[3][j], 34, 18, dot2(P[2][j], 55, 49, dot2(P[1][j], 34, 49, dot2(P[0][j], 0, 18, 32768u)))), 0x00FFFFFFu);
+        if (i - 5 < nOut) store(i - 5, pack(t));
+    }
+}
+
 // items: one per (level, row block); lanes of the whole grid.x enumerate (item, column group) pairs; laneItem[lane]
 // names the lane's item (a per-thread binary search would start every workgroup with eight dependent loads).
 template <int kBlurRows>

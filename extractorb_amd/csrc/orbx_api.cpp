@@ -27,7 +27,7 @@ size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchLdsPollute(hipStream_t, int, int, unsigned*);
 void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
-void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, int, int, bool, int, int, int);
+void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, uint8_t*, int, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
@@ -139,6 +139,8 @@ struct orbx_handle {
     long long pyrColsWgs = 0;           // ORBX_PYR_COLS_WGS: largest grid it is preferred for (0: default)
     int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
     long long fastWideWgs = 0;          // ORBX_FAST_WIDE_WGS: most cells per call it is used for (0: 4 per CU)
+    int blurInCols = -1;                // ORBX_BLUR_IN_COLS: 1 = the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken, 0 = never, default: by the batch size
+    long long blurInColsMinFrames = 1LL << 40;      // ORBX_BLUR_IN_COLS_MIN_FRAMES: smallest batch (frames per launch) the default takes it for
     int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
     long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
     size_t chainCap = 0;
@@ -149,8 +151,10 @@ struct orbx_handle {
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
     unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
     size_t laneCap = 0;
-    int nBlurLanes[3] = {0, 0, 0};     // [2]: 32-row blocks of the levels no resize launch blurs (level 0 and the last one)
-    size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
+    int nBlurLanes[4] = {0, 0, 0, 0};     // [2]: 32-row blocks of the levels no resize launch blurs (level 0 and the last one); [3]: of the levels k_pyr_cols<.., BLUR> leaves (>= blurInLevels)
+    size_t blurItemOff[4] = {0, 0, 0, 0}, blurLaneOff[4] = {0, 0, 0, 0};
+    int blurInLevels = 5;              // ORBX_BLUR_IN_LEVELS: the finest levels the region-major pyramid blurs itself when it carries the blur (the halo compounds
+                                       // down the chain: 640x480, 112-px regions, derived pixels +3 % for 3 levels = 70 % of the blur's pixels, +9 % for 5 = 89 %, +30 % for all 8)
     bool fuseBlur = false;             // ORBX_FUSE_BLUR=1: large batches blur levels 1 .. n-2 inside the resize launches (HBM traffic 8.56 -> 7.67 MB per frame,
                                        // but 1.7x the instructions for that share: +2.5 % step time)
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
@@ -183,6 +187,7 @@ struct orbx_handle {
     struct OutView { Keypoint* k = nullptr; uint8_t* d = nullptr; int* n = nullptr; int* mono = nullptr; Keypoint* lk = nullptr; int* lc = nullptr; };
     OutView dev, host;
     bool pyramidOnly = false;          // the last call was orbx_compute_pyramid: the handle holds a pyramid (and blurred levels) but no results
+    int blurAsync = -1;                // ORBX_BLUR_ASYNC: 1 = the blur runs on a side stream beside FAST and the quad-tree whatever the batch, 0 = never, default: large batches
     bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
     bool testFailAfterFast = false;    // ORBX_TEST_FAIL_AFTER_FAST (test aid)
     bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
@@ -209,7 +214,9 @@ struct orbx_handle {
     // the internal stream and the events of the two-half overlap (enqueueBatch)
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    int splitMode = 1;                 // ORBX_SPLIT=0: never split a batch over the two streams
+    hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
+    hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
+    int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream; 0 = no overlap of any kind; 2 = round 2's two half-batches side by side
     bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
@@ -282,6 +289,8 @@ void freeAll(orbx_handle* h) {
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->aux) (void)hipStreamDestroy(h->aux);
+    if (h->aux2) (void)hipStreamDestroy(h->aux2);
+    for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); }
     void* host[] = {h->h_candStat, h->h_lap, h->h_out, h->h_in, h->h_pyr};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -291,7 +300,7 @@ void freeAll(orbx_handle* h) {
 // Uploads the tables of h->geom (already laid out) and checks they fit the arenas.
 int installGeometry(orbx_handle* h, int rows, int cols) {
     FrameGeom g;
-    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->fuseBlur, h->colPx);
+    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->fuseBlur, h->colPx, h->blurInLevels);
     if (!why.empty()) return fail(h, why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED, why);
     layoutArenas(g, h->maxB);
     const LevelGeom& last = g.lv[g.nlevels - 1];
@@ -344,13 +353,15 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         }
     {
         size_t n = 0, nc = 0;
-        for (FrameGeom::ColumnSet& cs : g.colSets) {
+        for (std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
+        for (FrameGeom::ColumnSet& cs : *sets) {
             if (n + cs.columns.size() > h->colsCap || nc + cs.coef.size() > h->colCoefCap) cs.fit = false;      // (a region size far below the default ones: the other forms serve)
             if (!cs.fit) continue;
             HIP_TRY(h, hipMemcpy(h->d_cols + n, cs.columns.data(), sizeof(PyrColumn) * cs.columns.size(), hipMemcpyHostToDevice));
             HIP_TRY(h, hipMemcpy(h->d_colCoef + nc, cs.coef.data(), sizeof(ResizeX) * cs.coef.size(), hipMemcpyHostToDevice));
-            h->colsOff[&cs - g.colSets.data()] = n;
-            h->colCoefOff[&cs - g.colSets.data()] = nc;
+            const size_t slot = (&cs - sets->data()) + (sets == &g.colSetsBlur ? 4 : 0);      // (at most four cuts per geometry: kColPx)
+            h->colsOff[slot] = n;
+            h->colCoefOff[slot] = nc;
             n += cs.columns.size();
             nc += cs.coef.size();
         }
@@ -359,6 +370,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         for (int l = 0; l < g.nlevels; l++) {
             c.w[l] = g.lv[l].w; c.h[l] = g.lv[l].h; c.pyrStride[l] = g.lv[l].pyrStride; c.rxOff[l] = g.lv[l].rxOff; c.ryOff[l] = g.lv[l].ryOff;
             c.pyrOff[l] = g.lv[l].pyrOff; c.pyrFrameBytes[l] = g.lv[l].pyrFrameBytes;
+            c.blurStride[l] = g.lv[l].blurStride; c.blurOff[l] = g.lv[l].blurOff; c.blurFrameBytes[l] = g.lv[l].blurFrameBytes;
         }
         HIP_TRY(h, hipMemcpy(h->d_colLevels, &c, sizeof(c), hipMemcpyHostToDevice));
     }
@@ -369,11 +381,13 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
-        const int blockRows[3] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows};
-        for (int v = 0; v < 3; v++) {
+        const int blockRows[4] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows, kBlurBlockRows};
+        for (int v = 0; v < 4; v++) {
             const size_t t0 = tiles.size(), l0 = laneItem.size();
             int lanes = 0;
+            if (v == 3 && h->blurInLevels >= g.nlevels) { h->nBlurLanes[v] = 0; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
             for (int l = 0; l < g.nlevels; l++) {
+                if (v == 3 && l < h->blurInLevels) continue;               // the region-major pyramid blurs the finest levels itself
                 if (v == 2 && l >= 1 && l <= g.nlevels - 2) continue;      // levels 1 .. n-2 are blurred by the resize launches of levels 2 .. n-1
                 for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
                     laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)(tiles.size() - t0));
@@ -469,8 +483,18 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
     auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
+    // Overlap inside one call (round 4): the blurred levels are read by k_description only, the LAST launch, so the blur of a large batch runs on
+    // a side stream beside FAST and the quad-tree: pyramid -> {blur | FAST -> quad-tree} -> description.  k_blur is the one HBM-bound kernel of the
+    // path (0.53 of the issue rate), k_fast sits at the issue ceiling with idle memory pipes: 512 x 640x480 2016-2040 us unsplit, 1981-1988 as two
+    // halves side by side (round 2's form), 1915-1933 with the blur aside (two halves AND the blur aside: 1932-1937); 256 frames 1035-1055 / 1001-1014 /
+    // 999-1007; 128 x 1080p 3094-3136 (halves) -> 3021-3029; 128 frames of 640x480 and fewer: no difference.  A low-priority side stream only starts
+    // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time), 2: round 2's halves.
+    const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
+    const bool blurSide = (h->blurAsync > 0 || (h->blurAsync < 0 && h->splitMode == 1 && bigBatch)) && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
+    bool blurJoin[2] = {false, false};
     auto front = [&](hipStream_t st, int f0, int Bn) {
         bool fused = false;      // set when the per-level resize launches below also blur their source levels
+        int blurInside = 0;      // > 0: the region-major pyramid launch has written that many of the finest blurred levels as well
         // smallest batches (one or two frames): the whole pyramid in ONE launch, every tile of every level derived from the caller's image
         const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
                          (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
@@ -479,11 +503,23 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         // 640x480, us per call, tile forms -> this: 1 frame (40-px regions) 46.0 -> 40.9, 2 (56 px) 53.5 -> 45.7, 4: 66.2 -> 58.8, 8 (112 px): 93.4 -> 71.2,
         // 16: 133 -> 113, 32: 193 -> 172, 64: 309 -> 293, 128: 588 -> 582; 256 frames: 1043 -> 1062, the per-level launches win)
         const FrameGeom::ColumnSet* cs = nullptr;
-        if (h->pyrCols != 0 && g.colsPacked && !h->resizeBytewise)      // (its steps are the packed ones: the regions carry quad records)
-            for (const FrameGeom::ColumnSet& c : g.colSets) {
+        auto pickCut = [&](const std::vector<FrameGeom::ColumnSet>& sets) {
+            const FrameGeom::ColumnSet* best = nullptr;
+            for (const FrameGeom::ColumnSet& c : sets) {
                 if (!c.fit || c.ldsBytes > 60 * 1024) continue;
-                if (!cs || (long long)c.columns.size() * Bn >= 3LL * h->numCUs / 4) cs = &c;
+                if (!best || (long long)c.columns.size() * Bn >= 3LL * h->numCUs / 4) best = &c;
             }
+            return best;
+        };
+        if (h->pyrCols != 0 && g.colsPacked && !h->resizeBytewise) {     // (its steps are the packed ones: the regions carry quad records)
+            cs = pickCut(g.colSets);
+            // ... and the regions blur what they own of every level before they move on (one launch and the blur's read of the pyramid fewer)
+            const bool blurIn = h->blurInCols > 0 || (h->blurInCols < 0 && (long long)Bn >= h->blurInColsMinFrames);
+            if (cs && blurIn) {
+                const FrameGeom::ColumnSet* cb = pickCut(g.colSetsBlur);
+                if (cb && cb->px == cs->px) cs = cb;
+            }
+        }
         // (frames up to half a megapixel: for every batch size - 512 frames of 640x480: 2016 -> 1979 us per call, the per-level tiles of such
         // small levels are poorly filled; larger frames: while the coarsest cut stays below ~12 workgroups per CU - 1280x720: 16 frames 236 -> 226 us,
         // 32: equal, 64: 767 vs 788; 1920x1080: 16 frames 431 -> 422, 64: 1530 vs 1582, 128: 3119 vs 3222)
@@ -500,9 +536,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             const int colsShape = (long long)cs->columns.size() * Bn <= h->numCUs ? (cs->px <= 56 ? 6 : 4) : 1;
             Prof p(h, S_RESIZE, st);
             pollute(st);
-            launchPyrCols(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_cols + h->colsOff[cs - g.colSets.data()], (int)cs->columns.size(), h->d_colLevels, g.nlevels,
-                          h->d_colCoef + h->colCoefOff[cs - g.colSets.data()], cs->coefSlot, h->d_pyr, cs->ldsBytes, cs->evenBytes, g.colsPacked && !h->resizeBytewise,
-                          h->colsVariant >= 0 ? h->colsVariant : colsShape, f0, Bn);
+            const size_t slot = cs->blurLevels ? 4 + (cs - g.colSetsBlur.data()) : (cs - g.colSets.data());
+            launchPyrCols(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_cols + h->colsOff[slot], (int)cs->columns.size(), h->d_colLevels, g.nlevels,
+                          h->d_colCoef + h->colCoefOff[slot], cs->coefSlot, h->d_pyr, cs->blurLevels ? h->d_blur : nullptr, cs->blurLevels, cs->ldsBytes, cs->evenBytes,
+                          g.colsPacked && !h->resizeBytewise, h->colsVariant >= 0 ? h->colsVariant : colsShape, f0, Bn);
+            blurInside = cs->blurLevels;
         } else if (all) {
             Prof p(h, S_RESIZE, st);
             pollute(st);
@@ -540,14 +578,30 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
-        h->lastBlurForm = blurRidesWithFast(Bn) ? 1 : (fused ? 2 : 0);
-        h->blurOwed = blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
-        if (!blurRidesWithFast(Bn)) {
+        h->lastBlurForm = blurInside ? 3 : (blurRidesWithFast(Bn) ? 1 : (fused ? 2 : 0));
+        h->blurOwed = !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
+        if (blurInside) {
+            if (h->nBlurLanes[3] > 0) {      // the coarse levels the regions do not blur
+                Prof p(h, S_BLUR, st);
+                pollute(st);
+                launchBlur(st, h->d_tiles + h->blurItemOff[3], h->d_laneItem + h->blurLaneOff[3], h->nBlurLanes[3], kBlurBlockRows, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+            }
+        } else if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
             const int v = fused ? 2 : blurVariant(Bn);
             pollute(st);
-            launchBlur(st, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows,
+            // the blurred levels are only read by k_describe, the last launch: with ORBX_BLUR_ASYNC=1 an unsplit batch blurs on the internal
+            // stream, beside k_fast and the quad-tree (pyramid -> {blur, FAST -> quad-tree} -> description)
+            hipStream_t bs = st;
+            const int half = f0 ? 1 : 0;
+            if (blurSide) {
+                (void)hipEventRecord(h->evPyr[half], st);
+                (void)hipStreamWaitEvent(h->aux2, h->evPyr[half], 0);
+                bs = h->aux2;
+            }
+            launchBlur(bs, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows,
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+            if (blurSide) { (void)hipEventRecord(h->evBlur[half], h->aux2); blurJoin[half] = true; }
         }
     };
     bool injected = false;
@@ -600,6 +654,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
             h->leafDirty = false;
         }
+        if (blurJoin[f0 ? 1 : 0]) { (void)hipStreamWaitEvent(st, h->evBlur[f0 ? 1 : 0], 0); blurJoin[f0 ? 1 : 0] = false; }
         {
             Prof p(h, S_DESCRIBE, st);
             pollute(st);
@@ -607,14 +662,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                            h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
         }
     };
-    // Overlap inside one call: a large batch runs as two half-batches side by side, one on the caller's stream and one on
-    // an internal stream (fork / join with events), so that kernels which leave vector-issue slots idle (memory or barrier
-    // latency: blur, copies, quad-tree) share the chip with kernels of the other half that fill them, and tails run under
-    // heads.  Measured (profiles/r02_split_sweep.md): +3 % at 512 x 640x480, +1.5 % at 256, -9 % at 128 frames (kernel tails
-    // of the smaller launches), so parts of fewer than h->splitMinPixels pyramid pixels are not made.  Staggering the halves
-    // (front of one under FAST of the other, events between the streams at every stage) and four parts were both slower.
-    // ORBX_SPLIT=0 turns it off; event profiling always runs unsplit so that one launch is one batch.
-    const bool split = h->splitMode > 0 && !h->profiling && B >= 2 && (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
+    // Round 2's overlap (now ORBX_SPLIT=2 only; the blur on a side stream, above, replaced it as the default): a large batch as two half-batches
+    // side by side, one on the caller's stream and one on an internal stream (fork / join with events).  Measured (profiles/r02_split_sweep.md):
+    // +3 % at 512 x 640x480, +1.5 % at 256, -9 % at 128 frames.  Staggering the halves and four parts were both slower.
+    const bool split = h->splitMode == 2 && !h->profiling && B >= 2 && bigBatch;
+    struct BlurJoin {      // a blur left on the side stream by an early return is still joined into the caller's stream
+        orbx_handle* h; hipStream_t st; bool* pending;
+        ~BlurJoin() { for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0); }
+    } blurGuard{h, st, blurJoin};
     const bool doFront = (stages & kStageFront) != 0, doBack = (stages & kStageBack) != 0;
     if (!split || !doFront || !doBack) {
         if (doFront) front(st, 0, B);
@@ -767,6 +822,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->scaleFactor = scale_factor;
     h->maxW = max_width; h->maxH = max_height; h->maxB = max_batch;
     h->tabs = makeScaleTables(nfeatures, scale_factor, nlevels);
+    if (const char* e = getenv("ORBX_BLUR_IN_LEVELS")) h->blurInLevels = std::max(1, std::min(atoi(e), (int)kMaxLevels));
     std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom, true);      // (sizes the LDS tile for either form)
     if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
     layoutArenas(h->maxGeom, max_batch);
@@ -779,8 +835,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->selEntries = (size_t)(mg.selPerFrame + 8 * nlevels) * max_batch;
     h->cellCap = roomy(mg.cells.size());
     h->rxCap = (size_t)(max_width > max_height ? max_width : max_height) * nlevels + 64;
-    h->tileCap = roomy((size_t)(2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
-    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * (2 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 3) * nlevels);
+    h->tileCap = roomy((size_t)(3 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 4) * nlevels);
+    h->laneCap = roomy((size_t)((max_width + 3) / 4 + 1) * (3 * ((max_height + 31) / 32) + (max_height + kBlurBlockRowsSmall - 1) / kBlurBlockRowsSmall + 4) * nlevels);
     // quad-tree node arrays: LDS, or an HBM arena when the per-level quotas run into the thousands (orbx_geometry.hpp: octreeSizing)
     {
         const OctSizing z = octreeSizing(mg, nlevels, octreeLdsBytes);
@@ -853,8 +909,10 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->fastWide = getenv("ORBX_FAST_WIDE") ? atoi(getenv("ORBX_FAST_WIDE")) : -1;
     h->fastWideWgs = getenv("ORBX_FAST_WIDE_WGS") ? atoll(getenv("ORBX_FAST_WIDE_WGS")) : 0;
     h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
+    h->blurInCols = getenv("ORBX_BLUR_IN_COLS") ? atoi(getenv("ORBX_BLUR_IN_COLS")) : -1;
+    if (const char* e = getenv("ORBX_BLUR_IN_COLS_MIN_FRAMES")) h->blurInColsMinFrames = atoll(e);
     h->colsCap = 0;
-    for (int px : kColPx) h->colsCap += (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);
+    for (int px : kColPx) h->colsCap += 2 * (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);      // (every cut with and without the blur's halo)
     h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)
     h->colsCap = roomy(h->colsCap);
     CREATE_ALLOC(h->d_colCoef, sizeof(ResizeX) * h->colCoefCap);
@@ -867,11 +925,14 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->outBytes = outLayout(max_batch, h->outCap, nlevels).all;
     CREATE_ALLOC(h->d_out, h->outBytes);
     h->testFailAfterFast = getenv("ORBX_TEST_FAIL_AFTER_FAST") && atoi(getenv("ORBX_TEST_FAIL_AFTER_FAST")) != 0;
+    h->blurAsync = getenv("ORBX_BLUR_ASYNC") ? atoi(getenv("ORBX_BLUR_ASYNC")) : -1;
     h->zeroCopy = !(getenv("ORBX_ZERO_COPY") && atoi(getenv("ORBX_ZERO_COPY")) == 0);
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
     CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));      // (default priority: a low-priority blur only starts when everything else is done - 1928 -> 2022 us; high = default)
+    for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming)); }
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 1;

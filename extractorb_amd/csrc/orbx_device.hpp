@@ -159,6 +159,8 @@ struct ColLevels {      // what the kernel needs of the level tables, by value (
     int nlevels, pad;
     int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];
     long long pyrOff[kMaxLevels], pyrFrameBytes[kMaxLevels];
+    int blurStride[kMaxLevels];
+    long long blurOff[kMaxLevels], blurFrameBytes[kMaxLevels];      // the blurred levels (k_pyr_cols<.., BLUR> writes them too)
 };
 
 #ifdef __HIPCC__

@@ -380,16 +380,20 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     assert_same_result((mono, k, d), want, "%s=%s clustered" % (switch, value))
 
 
-@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True)])
+@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True), (300, "halves"), (257, "halves"),
+                                     (-300, "halves")])
 def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
-    # a large batch runs as two halves on two streams (odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small
-    # frames count as large, ORBX_SPLIT=0 turns the overlap off
+    # a large batch overlaps inside the call: its blur on a side stream beside FAST and the quad-tree (the default, round 4), or as two
+    # halves on two streams (ORBX_SPLIT=2, round 2's form; odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small frames count as
+    # large, ORBX_SPLIT=0 turns every overlap off
     if B < 0:      # (negative: the pyramid as one launch per level, the form of large batches of large frames, instead of the region-major one)
         monkeypatch.setenv("ORBX_PYR_COLS", "0")
         B = -B
     if split:
         monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
+        if split == "halves":
+            monkeypatch.setenv("ORBX_SPLIT", "2")
     else:
         monkeypatch.setenv("ORBX_SPLIT", "0")
     fr = synth.frames("textured", 40, B, 240, 320)
@@ -401,6 +405,12 @@ def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B,
         assert_same_result(out[f][:3], (mono, k, d), "frame %d of %d" % (f, B))
     o, want = oracle_run(fr[B - 1], 500)
     assert_same_result(out[B - 1][:3], want, "last frame of %d vs oracle" % B)
+    # calls back to back on the same handle: the next call's pyramid and blur must not overtake this call's description (side streams)
+    fr2 = np.ascontiguousarray(fr[::-1])
+    ex.extract_batch(fr)
+    out2 = ex.extract_batch(fr2)
+    assert_same_result(out2[0][:3], want, "second call, frame 0 = the first call's last")
+    assert_same_result(out2[B - 1][:3], out[0][:3], "second call, last frame = the first call's frame 0")
 
 
 @pytest.mark.parametrize("B,shape,split", [(72, (240, 320), False), (40, (480, 640), False), (300, (240, 320), True), (24, (333, 517), False)])
@@ -496,6 +506,46 @@ def test_region_major_pyramid_every_cut(px, monkeypatch):
         assert_same_result(out[f][:3], want, "px %d batch frame %d" % (px, f))
         for l in range(8):
             assert np.array_equal(ex.image_pyramid_level(l, frame=f, bordered=True), o.level(l, bordered=True)), "frame %d level %d" % (f, l)
+
+
+@pytest.mark.parametrize("px,nb", [(40, 5), (56, 3), (80, 5), (112, 5), (80, 8), (112, 2), (56, 8)])
+def test_region_major_pyramid_with_the_blur_inside(px, nb, monkeypatch):
+    """k_pyr_cols<.., BLUR>: the regions also blur what they own of the finest `nb` levels (7x7 sigma 2 of the border-less level, REFLECT_101:
+    ORBextractor.cc:1126-1127) out of rectangles that carry the blur's halo as virtual columns / mirrored rows; k_blur keeps the coarse levels.
+    Every blurred level, every bordered level and the final arrays against the oracle, for every cut, several level counts, odd shapes, a
+    batch, and every workgroup shape of the kernel (the blur's items are dealt over its roles)."""
+    monkeypatch.setenv("ORBX_PYR_COLS", "1")
+    monkeypatch.setenv("ORBX_PYR_COL_PX", str(px))
+    monkeypatch.setenv("ORBX_BLUR_IN_COLS", "1")
+    monkeypatch.setenv("ORBX_BLUR_IN_LEVELS", str(nb))
+    took = 0
+    for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "noise", {}),
+                                   ((480, 640), 900, "natural", dict(nlevels=12, sf=1.1)), ((241, 322), 300, "textured", dict(nlevels=2, sf=1.2)),
+                                   ((482, 643), 800, "noise", {})):
+        nlevels, sf = kw.get("nlevels", 8), kw.get("sf", 1.2)
+        img = synth.frames(variant, 53, 1, *shape)[0]
+        o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
+        ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
+        mono, k, d, lvl = ex(img, None, (0, 0))
+        took += ex.last_forms()[2] == 3
+        for l in range(nlevels):
+            if not len(o.level_keypoints(l)):      # (the reference - and the oracle - only blur levels that hold keypoints, :1122-1127)
+                continue
+            assert np.array_equal(ex.debug_blurred(l), o.blurred(l)), "px %d nb %d %s %s: blurred level %d (forms %s)" % (px, nb, shape, kw, l, ex.last_forms())
+        check_stages(ex, o, lvl, nlevels)
+        assert_same_result((mono, k, d), want, "px %d nb %d %s %s" % (px, nb, shape, kw))
+    assert took >= 3, "the cut with the blur's halo was taken %d times only" % took      # (a cut whose records do not fit falls back to k_blur: still exact, but then this test tests nothing)
+    frames = synth.frames("noise", 54, 5, 480, 640)
+    for shape_variant in ("", "0", "1", "2", "3", "4", "5", "6"):
+        if shape_variant:
+            monkeypatch.setenv("ORBX_PYR_COLS_VARIANT", shape_variant)
+        ex = X.ORBextractor(1000, max_batch=5)
+        out = ex.extract_batch(frames)
+        for f in (0, 4):
+            o, want = oracle_run(frames[f], 1000)
+            assert_same_result(out[f][:3], want, "px %d nb %d shape %s batch frame %d" % (px, nb, shape_variant, f))
+            for l in range(8):
+                assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "shape %s frame %d blurred level %d" % (shape_variant, f, l)
 
 
 def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):
