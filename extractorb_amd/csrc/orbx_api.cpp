@@ -216,7 +216,8 @@ struct orbx_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
     hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
-    int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream; 0 = no overlap of any kind; 2 = round 2's two half-batches side by side
+    int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream (the largest also stagger
+                                       // their tails: enqueueBatch); 0 = no overlap of any kind; 2 = round 2's two half-batches side by side; 3 = staggered tails for every large batch
     bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
@@ -490,8 +491,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // 999-1007; 128 x 1080p 3094-3136 (halves) -> 3021-3029; 128 frames of 640x480 and fewer: no difference.  A low-priority side stream only starts
     // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time), 2: round 2's halves.
     const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
-    const bool blurSide = (h->blurAsync > 0 || (h->blurAsync < 0 && h->splitMode == 1 && bigBatch)) && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
+    const bool blurSide = (h->blurAsync > 0 || (h->blurAsync < 0 && (h->splitMode == 1 || h->splitMode == 3) && bigBatch)) && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
     bool blurJoin[2] = {false, false};
+    int blurF0[2] = {0, 0}, blurBn[2] = {0, 0};
     auto front = [&](hipStream_t st, int f0, int Bn) {
         bool fused = false;      // set when the per-level resize launches below also blur their source levels
         int blurInside = 0;      // > 0: the region-major pyramid launch has written that many of the finest blurred levels as well
@@ -601,15 +603,19 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             }
             launchBlur(bs, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows,
                        h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
-            if (blurSide) { (void)hipEventRecord(h->evBlur[half], h->aux2); blurJoin[half] = true; }
+            if (blurSide) { (void)hipEventRecord(h->evBlur[half], h->aux2); blurJoin[half] = true; blurF0[half] = f0; blurBn[half] = Bn; }
         }
     };
     bool injected = false;
-    auto back = [&](hipStream_t st, int f0, int Bn) {
-        // small batches: k_fast's emit does the quad-tree's first sweep (leaf counters and best keys in L2); k_octree loads and clears them
+    // small batches: k_fast's emit does the quad-tree's first sweep (leaf counters and best keys in L2); k_octree loads and clears them
+    auto leafTables = [&](int f0, int Bn) {
         LeafTables lt{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
         if (h->leafFrames && f0 + Bn <= h->leafFrames)
             lt = LeafTables{h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_leafCode + (size_t)g.nlevels * h->octXT, h->octR, h->octXT, g.nlevels, h->leafFrames};
+        return lt;
+    };
+    auto backFast = [&](hipStream_t st, int f0, int Bn) {
+        const LeafTables lt = leafTables(f0, Bn);
         {
             Prof p(h, S_FAST, st);
             const bool carry = h->blurOwed && blurRidesWithFast(Bn);
@@ -625,7 +631,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                        h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
                        h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= (h->fastWideWgs > 0 ? h->fastWideWgs : 4LL * h->numCUs)));
         }
+    };
+    auto backTail = [&](hipStream_t st, int f0, int Bn) {
         if (injected) return;
+        const LeafTables lt = leafTables(f0, Bn);
         {
             Prof p(h, S_OCTREE, st);
             // small batches: while every (frame, level) workgroup is resident at once, the largest workgroup that still lets
@@ -654,7 +663,8 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
             h->leafDirty = false;
         }
-        if (blurJoin[f0 ? 1 : 0]) { (void)hipStreamWaitEvent(st, h->evBlur[f0 ? 1 : 0], 0); blurJoin[f0 ? 1 : 0] = false; }
+        for (int i = 0; i < 2; i++)      // every blur still on the side stream that covers frames of this part
+            if (blurJoin[i] && blurF0[i] < f0 + Bn && f0 < blurF0[i] + blurBn[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0);
         {
             Prof p(h, S_DESCRIBE, st);
             pollute(st);
@@ -662,6 +672,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                            h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
         }
     };
+    auto back = [&](hipStream_t st, int f0, int Bn) { backFast(st, f0, Bn); backTail(st, f0, Bn); };
     // Round 2's overlap (now ORBX_SPLIT=2 only; the blur on a side stream, above, replaced it as the default): a large batch as two half-batches
     // side by side, one on the caller's stream and one on an internal stream (fork / join with events).  Measured (profiles/r02_split_sweep.md):
     // +3 % at 512 x 640x480, +1.5 % at 256, -9 % at 128 frames.  Staggering the halves and four parts were both slower.
@@ -671,7 +682,27 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         ~BlurJoin() { for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0); }
     } blurGuard{h, st, blurJoin};
     const bool doFront = (stages & kStageFront) != 0, doBack = (stages & kStageBack) != 0;
-    if (!split || !doFront || !doBack) {
+    // Staggered tails (the largest batches: twice the pixels of `bigBatch`; ORBX_SPLIT=3: every big batch): FAST in two halves back to back on the
+    // caller's stream; the first half's quad-tree and description (barrier- and latency-bound: 0.4-0.6 of the issue rate) run on the internal
+    // stream under the second half's FAST.  512 x 640x480: 1913-1914 -> 1888-1894 us; 256 frames and 128 x 1080p: no difference (k_fast fills the chip;
+    // what runs beside it mostly adds its own issue time)
+    const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 4 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
+                         !h->profiling && B >= 2 && bigBatch && doFront && doBack;
+    if (stagger) {
+        struct Join {
+            orbx_handle* h; hipStream_t st; bool armed = false;
+            ~Join() { if (armed) { (void)hipEventRecord(h->evJoin, h->aux); (void)hipStreamWaitEvent(st, h->evJoin, 0); } }
+        } join{h, st};
+        const int B0 = (B + 1) / 2;
+        front(st, 0, B);
+        backFast(st, 0, B0);
+        HIP_TRY(h, hipEventRecord(h->evFork, st));
+        HIP_TRY(h, hipStreamWaitEvent(h->aux, h->evFork, 0));
+        join.armed = true;
+        backTail(h->aux, 0, B0);
+        backFast(st, B0, B - B0);
+        backTail(st, B0, B - B0);
+    } else if (!split || !doFront || !doBack) {
         if (doFront) front(st, 0, B);
         if (doBack) back(st, 0, B);
     } else {

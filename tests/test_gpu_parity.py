@@ -381,7 +381,7 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
 
 
 @pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True), (300, "halves"), (257, "halves"),
-                                     (-300, "halves")])
+                                     (-300, "halves"), (300, "stagger"), (257, "stagger"), (-301, "stagger")])
 def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
     # a large batch overlaps inside the call: its blur on a side stream beside FAST and the quad-tree (the default, round 4), or as two
@@ -394,6 +394,8 @@ def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B,
         monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
         if split == "halves":
             monkeypatch.setenv("ORBX_SPLIT", "2")
+        if split == "stagger":      # FAST in two halves back to back, the first half's quad-tree + description on the internal stream under the second half's FAST
+            monkeypatch.setenv("ORBX_SPLIT", "3")
     else:
         monkeypatch.setenv("ORBX_SPLIT", "0")
     fr = synth.frames("textured", 40, B, 240, 320)
