@@ -615,6 +615,9 @@ def main():
                               % (bestrun["frames"], variant, cols, rows, bestrun["threads"], bestrun["seconds"], n1, sec1))
         extras = {}
         if N == 1 and args.workload == "mono640" and not args.no_extras and not distributed:
+            if not args.no_verify:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O      # the checker (hd1080_verified); never the product path
             # (a) PCIe-inclusive rate (SURVEY.md §8d "end-to-end"): pinned host frames in, host arrays out, two handles used alternately
             #     so one batch's transfers overlap the other's kernels.  Never `value`.
             Bh = min(B, 64)
@@ -661,6 +664,21 @@ def main():
             extras["hd1080_fps"] = round(B2 * 10 / dt, 1)
             extras["hd1080_note"] = "1920x1080 x 2000 features (BASELINE.json configs[2]), %d noise frames per call, device-resident, %.0f keypoints per frame" % (B2, n2)
             extras["hd1080_path_frac"] = round(B2 * 10 / dt * e2.algorithmic_bytes(w2["rows"], w2["cols"], int(round(n2))) / 1e9 / HBM_PEAK_GBS, 5)
+            if not args.no_verify:      # the slab of the last timed call against the oracle: first / middle / last frame
+                h2n = s2[l2["n"]:l2["n"] + 4 * B2].cpu().numpy().view(np.int32); h2m = s2[l2["mono"]:l2["mono"] + 4 * B2].cpu().numpy().view(np.int32)
+                o2 = O.Oracle(w2["nfeatures"], 1.2, 8, 20, 7)
+                bad2 = []
+                for f in (0, B2 // 2, B2 - 1):
+                    wm, wk, wd = o2.extract(f2[f].cpu().numpy(), w2["lapping"])
+                    n = int(h2n[f])
+                    gk = s2[l2["keypoints"] + f * cap2 * 28: l2["keypoints"] + f * cap2 * 28 + n * 28].cpu().numpy().tobytes() if 0 <= n <= cap2 else b""
+                    gd = s2[l2["descriptors"] + f * cap2 * 32: l2["descriptors"] + f * cap2 * 32 + n * 32].cpu().numpy().tobytes() if 0 <= n <= cap2 else b""
+                    if not (n == len(wk) and int(h2m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
+                        bad2.append(f)
+                extras["hd1080_verified"] = dict(frames=[0, B2 // 2, B2 - 1], against="oracle (CPU restatement)", bit_exact=not bad2, mismatching_frames=bad2)
+                if bad2:
+                    bad.append(("hd1080", bad2))
+                    print("bench.py: hd1080 RESULTS DIFFER FROM THE ORACLE on frames %s" % bad2, file=sys.stderr, flush=True)
             del e2
             # (c) the reference's own call shape: ONE 640x480 frame per call (Frame::ExtractORB), device-resident, back to back
             w1 = WORKLOADS["mono640"]
@@ -692,6 +710,25 @@ def main():
             dt = back_to_back(run1)
             extras["single_frame_us"] = round(dt * 1e6, 1)
             extras["single_frame_note"] = "one 640x480 frame per call (the reference's call shape), device-resident, back to back (median of 6 runs of 50 calls): %.0f calls/s" % (1 / dt)
+            # (c') ... and as a maintainer's Frame::ExtractORB gets it (Frame.cc:419-427): a PAGEABLE host image in, host arrays out, every call
+            # waited for (orbx_extract_view: pinned staging + one H2D copy, kernels write the pinned result slab, no D2H copy command)
+            import ctypes as C
+            him = synth.frames("noise", 0, 1, w1["rows"], w1["cols"])[0].copy()
+            pk, pd, plk, plc, hn_, hm_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+            hkps = np.zeros(e1.capacity, X.KEYPOINT_DTYPE); hdesc = np.zeros((e1.capacity, 32), np.uint8)
+
+            def host_call():
+                rc = e1._L.orbx_extract_view(e1._h, him.ctypes.data_as(C.c_void_p), w1["rows"], w1["cols"], w1["cols"], w1["lapping"][0], w1["lapping"][1], 0,
+                                             C.byref(pk), C.byref(pd), C.byref(hn_), C.byref(hm_), C.byref(plk), C.byref(plc))
+                assert rc == 0
+                C.memmove(hkps.ctypes.data, pk.value, 28 * hn_.value); C.memmove(hdesc.ctypes.data, pd.value, 32 * hn_.value)      # into the caller's arrays, as the shim does
+
+            for _ in range(20):
+                host_call()
+            dth = back_to_back(host_call)
+            extras["single_frame_host_us"] = round(dth * 1e6, 1)
+            extras["single_frame_host_note"] = ("one pageable 640x480 host image in, host keypoints + descriptors out, every call waited for (orbx_extract_view + the "
+                                                "copy into the caller's arrays; PCIe-inclusive, never `value`): %.0f calls/s" % (1 / dth))
             del e1
             # (d) ... and a stereo pair per call (BASELINE.json configs[3]'s call shape: both eyes of one frame, 1200 features per eye)
             ws = WORKLOADS["stereo640"]

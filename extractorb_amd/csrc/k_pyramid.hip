@@ -435,7 +435,9 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     // step number would live in scratch)
     const ChainTile& ct = tiles[t];
     const int level = ct.level;
-    uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // region j lives in buf[j & 1]
+    // region j lives in buffer j & 1.  (An offset from `lds`, not an entry of a pointer table: indexed at run time such a table holds GENERIC
+    // pointers and every access through it becomes a FLAT instruction - tools/isa/kernel_table.py)
+    auto bufOf = [&](int j) { return lds + ((j & 1) ? bufEvenBytes : 0); };
     struct { int w, h, pyrRows, pyrStride; long long pyrOff, pyrFrameBytes; } d{ct.w, ct.h, ct.pyrRows, ct.pyrStride, ct.pyrOff, ct.pyrFrameBytes};
     const int nd = (kPadL - kEdge + d.w + 2 * kEdge + 3) / 4, wB = d.w + 2 * kEdge;      // dwords of a bordered row (rowDwords)
     if constexpr (FROM_IMAGE) {
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
             src = pyr + ct.srcOff + (long long)f * ct.srcFrameBytes + (long long)(kEdge + r.y0) * ct.srcStride + kPadL + r.x0;
             srcStride = ct.srcStride;
         }
-        unsigned* dst = (unsigned*)buf[kStart & 1];
+        unsigned* dst = (unsigned*)bufOf(kStart);
         CSTAMP(20);
         // the region's dwords are dealt flat (dword i of the region = row i / nDw, column i % nDw; the LDS copy is contiguous in i)
         constexpr int kLoads = ((FROM_IMAGE ? kChainMaxH0 : kChainMaxH) * kChainMaxW / 4 + kChainThreads - 1) / kChainThreads;
@@ -569,8 +571,8 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     for (int j = kStart + 1; j < level; j++) {
         const ChainRegion rnext = ct.region[j + 1 < kMaxLevels ? j + 1 : j];      // requested a step ahead: no wait at the top of the next step
         const int ss = (rs.w + 3) & ~3, ds = (rd.w + 3) & ~3;
-        const uint8_t* S = buf[(j - 1) & 1];
-        uint8_t* D = buf[j & 1];
+        const uint8_t* S = bufOf(j - 1);
+        uint8_t* D = bufOf(j);
         const ResizeX *cxs = coef + off, *cys = cxs + rd.w;
         chainStep<PACKED>(S, D, rs, rd, cxs, cys, ss, ds, tid);
         off += rd.w + rd.h;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const 
     if (tid < kChainTileDw * kChainTileRows) {
         const ChainRegion rs = ct.region[level - 1];
         const int ss = (rs.w + 3) & ~3;
-        const uint8_t* S = buf[(level - 1) & 1];
+        const uint8_t* S = bufOf(level - 1);
         const ResizeX *cxs = coef + off, *cys = cxs + 4 * kChainTileDw;
         const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col, row = ct.tileY * kChainTileRows + (tid >> 4);
         if (dw < nd && row < d.pyrRows) {
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
                                         lv.blurOff[tid] + (long long)f * lv.blurFrameBytes[tid]};
     CSTAMP(0);
     CSPAN_BEGIN;
-    uint8_t* buf[2] = {lds, lds + bufEvenBytes};            // level j's rectangle lives in buf[j & 1]
+    auto bufOf = [&](int j) { return lds + ((j & 1) ? bufEvenBytes : 0); };      // level j's rectangle lives in buffer j & 1 (an LDS offset, never a generic pointer)
     // the rectangles of the first nine levels are read with STATIC indices: one batch of wave-uniform loads (k_pyr_chain has the reasons)
     constexpr int kStatic = 8;
     ChainRegion rj[kStatic + 1];
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         const ChainRegion r = rj[0];
         const int nDw = r.w >> 2, total = nDw * r.h;
         const uint8_t* src = img.p + (long long)f * img.frame + (long long)r.y0 * img.stride + r.x0;
-        unsigned* dst = (unsigned*)buf[0];
+        unsigned* dst = (unsigned*)bufOf(0);
         constexpr int kLoads = (kChainMaxH0 * kChainMaxW / 4 + T - 1) / T;
         const float inv = __frcp_rn((float)nDw);
         unsigned w[kLoads];
@@ -687,12 +689,12 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
     // one level: the next level's rectangle first (the critical path), then this level's owned bytes; both only read S
     auto doLevel = [&](const int j, const ChainRegion rs, const ChainRegion rd) {
         const int ss = (rs.w + 3) & ~3;
-        const uint8_t* S = buf[j & 1];
+        const uint8_t* S = bufOf(j);
         constexpr int TW = TD < T ? T - TD : T;      // threads of the writing role
         if (j < top) {
             const ResizeX* cxs = coef + off;                        // the level's quad records, then its y records (PyrColumn's layout)
             const int nqUnits = 6 * ((rd.w + 3) >> 2);
-            if (tid < TD) chainStep<true, TD, true>(S, buf[(j + 1) & 1], rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
+            if (tid < TD) chainStep<true, TD, true>(S, bufOf(j + 1), rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
             off += nqUnits + ((rd.h + 1) & ~1);
         }
         // (the last level has nothing to derive: every thread writes)

@@ -168,3 +168,21 @@ def test_reported_launch_forms(shape, nf, B, form):
         assert cut in (40, 56, 80, 112)
     o, want = oracle_run(frames[B - 1], nf)
     assert_same_result(out[B - 1][:3], want, "%s x %d" % (shape, B))
+
+
+@pytest.mark.parametrize("shape,nf,B", [((480, 640), 1000, 512), ((1080, 1920), 2000, 64), ((1080, 1920), 2000, 128)])
+def test_the_benchmarks_own_batch_shapes(shape, nf, B):
+    """BASELINE.md §3 / bench.py's lines under the DEFAULT launch policy: 512 x 640x480 x 1000 (region-major pyramid,
+    256-thread queued quad-tree, no leaf tables, the blur on its side stream, staggered tails) and 64 / 128 x 1920x1080 x 2000 (per-level pyramid
+    launches, 1024-thread queued quad-tree): first / middle / last frames of the batch against the oracle, as bench.py's `verified` does."""
+    base = synth.frames("noise", 0, 16, *shape)
+    frames = np.concatenate([base] * (B // 16))
+    frames[B // 2 - 1] = synth.frames("textured", 1, 1, *shape)[0]      # (not only noise)
+    ex = X.ORBextractor(nf, max_width=shape[1], max_height=shape[0], max_batch=B)
+    out = ex.extract_batch(frames)
+    picks = sorted({0, B // 2 - 1, B // 2, B - 1})
+    for f in picks:
+        o, want = oracle_run(frames[f], nf)
+        assert_same_result(out[f][:3], want, "%s x %d frame %d (forms %s)" % (shape, B, f, ex.last_forms()))
+    out2 = ex.extract_batch(frames[::-1].copy())          # the same handle again: what the timed steps of bench.py do
+    assert_same_result(out2[B - 1][:3], out[0][:3], "second call")

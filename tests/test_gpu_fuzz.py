@@ -1,6 +1,6 @@
 """Bounded, seeded randomised parity sweep under -m gpu: tools/fuzz_parity.py's generator (random image sizes, feature counts,
 level counts, scale factors 1.1-2.0, thresholds, lapping areas, content), every stage and the final arrays against the oracle,
-under each kernel-variant switch.  The totals are written to gpurun_out/r03_fuzz_parity.json on the GPU box (copied to
+under each kernel-variant switch.  The totals are written to gpurun_out/r04_fuzz_parity.json on the GPU box (copied to
 profiles/r02_fuzz_parity.md)."""
 import json
 import os
@@ -34,7 +34,11 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            # small batches start the quad-tree from k_fast's leaf tables by default (round 3); these keep the kernel's own first sweep under test
            ({"ORBX_LEAF_FRAMES": "0"}, 8, 115), ({"ORBX_LEAF_FRAMES": "0", "ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            # ... and the leaf tables with poisoned allocations (they must be zero between calls whatever hipMalloc returned)
-           ({"ORBX_POISON": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116)]
+           ({"ORBX_POISON": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116),
+           # round 4: the region-major pyramid that also blurs (the finest five levels, and all of them), the copy-back form of the one-frame host call
+           ({"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1"}, 8, 124),
+           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_BLUR_IN_COLS": "1", "ORBX_BLUR_IN_LEVELS": "8", "ORBX_LDS_POLLUTE": "99"}, 8, 125),
+           ({"ORBX_ZERO_COPY": "0", "ORBX_POISON": "33"}, 8, 126)]
 _totals = []
 
 
@@ -50,7 +54,7 @@ def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        json.dump(_totals, open(os.path.join(out, "r03_fuzz_parity.json"), "w"), indent=1)
+        json.dump(_totals, open(os.path.join(out, "r04_fuzz_parity.json"), "w"), indent=1)
     except OSError:
         pass
 
@@ -61,3 +65,16 @@ def test_seeded_batch_shape_sweep():
     import fuzz_batches
     done, skipped, checked = fuzz_batches.run(24, 31)
     assert done + skipped == 24 and done >= 20 and checked >= 2 * done
+
+
+@pytest.mark.parametrize("env", [{"ORBX_SPLIT_MIN_MPX": "0"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "2"},
+                                 {"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1", "ORBX_SPLIT_MIN_MPX": "0"}],
+                         ids=["blur-aside", "staggered-tails", "halves", "blur-in-regions"])
+def test_seeded_batch_shape_sweep_under_the_overlap_policies(env, monkeypatch):
+    """The same sweep with every batch counted as large (ORBX_SPLIT_MIN_MPX=0), so that the overlap forms of large batches - the blur on its side
+    stream (the default), staggered tails, round 2's halves - and the blurring pyramid meet every batch shape, not only the benchmark's."""
+    import fuzz_batches
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    done, skipped, checked = fuzz_batches.run(10, 37)
+    assert done + skipped == 10 and done >= 8 and checked >= 2 * done

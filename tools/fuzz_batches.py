@@ -21,9 +21,10 @@ def run(n_cases, seed, progress=False):
     t0 = time.time()
     for t in range(n_cases):
         B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 31, 32, 33, 48, 64, 65, 96, 127, 128, 129, 160]))
-        rows, cols = [(480, 640), (240, 320), (333, 517), (376, 1241), (720, 1280), (480, 752)][int(rng.integers(0, 6))]
-        if rows * cols * B > 40e6:
-            B = max(1, int(40e6 // (rows * cols)))
+        rows, cols = [(480, 640), (240, 320), (333, 517), (376, 1241), (720, 1280), (480, 752), (1080, 1920)][int(rng.integers(0, 7))]
+        cap = 140e6 if rows == 1080 else 40e6      # (1080p: up to 67 frames, so that its per-level pyramid launches and the 1024-thread queued quad-tree are drawn too)
+        if rows * cols * B > cap:
+            B = max(1, int(cap // (rows * cols)))
         nf = int(rng.choice([300, 500, 1000, 1200, 2000]))
         variant = ["noise", "textured", "sparse", "natural"][int(rng.integers(0, 4))]
         frames = synth.frames(variant, 9000 + t, min(B, 8), rows, cols)
