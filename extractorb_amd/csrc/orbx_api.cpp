@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,11 @@ using namespace orbx;
 
 static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
 static_assert(sizeof(orbx_proj_query) == sizeof(ProjQuery), "orbx_proj_query layout");
+
+static double g_hostT[8];
+static long g_hostN;
+static const bool g_hostTiming = getenv("ORBX_HOST_TIMING") && atoi(getenv("ORBX_HOST_TIMING")) != 0;      // tools/host_call_anatomy.py
+static inline double nowSec() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 namespace {
 constexpr float kPrefilterDensity = 0.02f;   // candidates per pixel below which the prefilter variant of k_fast is faster
@@ -686,8 +692,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // caller's stream; the first half's quad-tree and description (barrier- and latency-bound: 0.4-0.6 of the issue rate) run on the internal
     // stream under the second half's FAST.  512 x 640x480: 1913-1914 -> 1888-1894 us; 256 frames and 128 x 1080p: no difference (k_fast fills the chip;
     // what runs beside it mostly adds its own issue time)
+    // (never with the blur riding in the FAST launch, the form of SMALL batches, which an ORBX_SPLIT_MIN_MPX=0 test run also counts as big: the
+    // whole-batch pyramid would leave the blur to the FIRST half's FAST launch only — found by the batch-shape fuzz)
     const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 4 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
-                         !h->profiling && B >= 2 && bigBatch && doFront && doBack;
+                         !h->profiling && B >= 2 && bigBatch && doFront && doBack && !blurRidesWithFast(B);
     if (stagger) {
         struct Join {
             orbx_handle* h; hipStream_t st; bool armed = false;
@@ -744,11 +752,15 @@ int uploadFrames(orbx_handle* h, int B, const uint8_t* imgs, int rows, int cols,
     hipStream_t st = h->stream;
     const size_t tight = (size_t)rows * cols, total = tight * B;
     bool pinned = false;
+    const double ta = g_hostTiming ? nowSec() : 0;
     {
         hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, imgs) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
         else (void)hipGetLastError();      // (older runtimes report unregistered memory as an error)
     }
+    const double tb = g_hostTiming ? nowSec() : 0;
+    if (g_hostTiming) g_hostT[2] += tb - ta;
+    struct Tail { double t; ~Tail() { if (g_hostTiming) g_hostT[4] += nowSec() - t; } } tail{tb};      // [3] staging memcpy, [4] staging + enqueue of the copy
     if (!pinned && total <= h->hInBytes) {
         for (int f = 0; f < B; f++) {
             const uint8_t* src = imgs + f * frame_stride;
@@ -756,6 +768,7 @@ int uploadFrames(orbx_handle* h, int B, const uint8_t* imgs, int rows, int cols,
             if (stride == cols) std::memcpy(dst, src, tight);
             else for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * cols, src + (ptrdiff_t)y * stride, (size_t)cols);
         }
+        if (g_hostTiming) g_hostT[3] += nowSec() - tb;
         HIP_TRY(h, hipMemcpyAsync(h->d_input, h->h_in, total, hipMemcpyHostToDevice, st));
     } else if (stride == cols && frame_stride == (ptrdiff_t)tight) {
         HIP_TRY(h, hipMemcpyAsync(h->d_input, imgs, total, hipMemcpyHostToDevice, st));
@@ -1146,6 +1159,14 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff
                               mono_out, level_kps, level_counts);
 }
 
+// ORBX_HOST_TIMING=1: where a one-frame host call spends its wall time (tools/host_call_anatomy.py): seconds accumulated per phase
+int orbx_debug_host_timing(double* out8, long* calls) {
+    if (!out8 || !calls) return ORBX_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < 8; i++) { out8[i] = g_hostT[i]; g_hostT[i] = 0; }
+    *calls = g_hostN; g_hostN = 0;
+    return ORBX_OK;
+}
+
 int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1, int want_levels,
                       const orbx_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_out, const orbx_keypoint** level_kps,
                       const int** level_counts) {
@@ -1154,10 +1175,13 @@ int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, pt
     if (!kps || !desc || !n_out || !mono_out || stride < cols || (want_levels && (!level_kps || !level_counts)))
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "null output pointer or stride < cols");
     const int lap[2] = {lap0, lap1};
+    const double t0 = g_hostTiming ? nowSec() : 0;
     int rc = orbx_extract_batch_begin(h, 1, img, rows, cols, stride, (ptrdiff_t)rows * stride, lap, want_levels);
     if (rc != ORBX_OK) return rc;
     h->pendingB = 0;
+    const double t1 = g_hostTiming ? nowSec() : 0;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (g_hostTiming) { const double t2 = nowSec(); g_hostT[0] += t1 - t0; g_hostT[1] += t2 - t1; g_hostN++; }
     const int n = h->host.n[0];
     if (n < 0 || n > h->outCap) return fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the handle's capacity (internal bound violated)");
     *kps = (const orbx_keypoint*)h->host.k; *desc = h->host.d; *n_out = n; *mono_out = h->host.mono[0];

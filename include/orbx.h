@@ -372,6 +372,10 @@ int orbx_debug_search_rounds(int* out4);
  * FAST launch, 2 = inside the k_resize launches, 3 = inside k_pyr_cols. */
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
 
+/* ORBX_HOST_TIMING=1 in the environment: wall seconds of the one-frame host call (orbx_extract_view) accumulated per phase since the last read:
+ * out8[0] enqueue (staging + copy + launches), [1] wait, [2] pointer query, [3] staging memcpy, [4] staging + H2D enqueue; *calls = calls summed. */
+int orbx_debug_host_timing(double* out8, long* calls);
+
 /* Stage outputs of frame `frame` of the last batch, copied to host.  Candidates are the reference's
  * vToDistributeKeys of one level (ORBextractor.cc:786-864) in rectangle coordinates; their order is
  * unspecified (the octree result does not depend on it), sort before comparing. */
