@@ -1,22 +1,22 @@
 // k_pyramid.hip — image pyramid: bordered level-0 copy and the fixed-point bilinear resize chain
 // (reference ORBextractor.cc:1164-1219; cv::resize / copyMakeBorder semantics: SURVEY.md A.1, A.4).
 //
-// One workgroup = one 256 x 32 tile of a bordered destination level; a thread owns one aligned dword column
-// (4 pixels) over 8 rows, so stores are coalesced 256-B wave stores.  The tile's source footprint — a rectangle
-// the host derives from the coefficient tables (they are monotonic and REFLECT_101 only folds indices back inside)
-// — is staged in LDS with coalesced dword loads (12 in flight per thread); a thread then reads the three dwords
-// that hold the taps of its four pixels and cuts the tap pairs out with v_alignbyte / v_perm (packed form, when the
-// host found the taps of every dword column within 8 source bytes), or reads single bytes (any scale factor).
-// copyMakeBorder(REFLECT_101) is fused: a border byte recomputes the interior pixel it mirrors.
-// Level l depends on the rounded u8 pixels of level l-1 (the reference's 7-deep chain), hence one launch per
-// level; the first launch builds level 0 (copy) AND level 1 (resized straight from the caller's image).
+// Two forms, chosen by the host (orbx_api.cpp: enqueueBatch), bit-identical results:
+//  * k_pyr_cols (the default): ONE launch; a workgroup takes a region of the image through EVERY level in LDS (end of this file);
+//  * one launch per level (large batches of frames above half a megapixel, and geometries whose column quads do not fit the packed
+//    step: scale factors above 2): k_pyr_first builds level 0 (bordered copy) and level 1 (resized straight from the caller's image),
+//    k_resize level l from level l - 1.  One workgroup = one 256 x 32 tile of a bordered destination level; a thread owns one
+//    aligned dword column (4 pixels) over 8 rows, so stores are coalesced 256-B wave stores.  The tile's source footprint — a
+//    rectangle the host derives from the coefficient tables — is staged in LDS with coalesced dword loads (12 in flight per thread);
+//    a thread then reads the three dwords that hold the taps of its four pixels and cuts the tap pairs out with v_alignbyte / v_perm
+//    (packed form), or reads single bytes (any scale factor).  copyMakeBorder(REFLECT_101) is fused: a border byte recomputes the
+//    interior pixel it mirrors.
+// Level l depends on the rounded u8 pixels of level l-1 (the reference's 7-deep chain) in both forms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <cstdlib>
-#include <algorithm>
 
 #include "orbx_device.hpp"
-#include "k_blur_body.hpp"      // blurBlock: the level a resize tile has staged is blurred out of the same LDS tile
+#include "k_blur_body.hpp"      // blurRun: a region of k_pyr_cols<.., BLUR> blurs what it owns of a level out of its LDS rectangle
 
 namespace orbx {
 
@@ -30,7 +30,6 @@ constexpr int kPyrRows = kResizeTileRows / 4;   // destination rows per thread
 constexpr int kTileCols = 64;    // dword columns per workgroup tile (256 pixels)
 constexpr int kTileRowGroups = 4;
 constexpr int kTileRows = kPyrRows * kTileRowGroups;   // destination rows per workgroup tile
-constexpr int kFusedBlurRows = 8;                      // output rows per work item of the blur that rides in a resize tile
 
 static __host__ __device__ inline int rowDwords(const LevelGeom& g) { return (kPadL - kEdge + g.w + 2 * kEdge + 3) / 4; }
 
@@ -64,8 +63,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <bool PACKED>
 __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d, const ResizeX* __restrict__ xt,
                                            const ResizeX* __restrict__ yt, const TileFoot ft, uint8_t* __restrict__ pyr,
-                                           int tileX, int tileY, int f, uint8_t* tile, int ldsStride, const LevelGeom* sg,
-                                           uint8_t* __restrict__ blur) {
+                                           int tileX, int tileY, int f, uint8_t* tile, int ldsStride) {
     const int tid = threadIdx.x, col = tid & (kTileCols - 1), rgrp = tid / kTileCols;
     const int nd = rowDwords(d), wB = d.w + 2 * kEdge;
     const int dw = tileX * kTileCols + col;
@@ -190,31 +188,6 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
         if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = o;
     }
     }
-    // ---- the 7x7 blur of the SOURCE level (reference :1126-1127) out of the same LDS tile: this tile's share [bx0, bx1) x [by0, by1)
-    //      of level l - 1, in work items of four columns x kFusedBlurRows rows (the tile holds the 3-pixel halo: orbx_geometry.hpp).
-    //      The level is then never read from HBM a second time by k_blur (1.16 MB per 640x480 frame + the 6-in-32 halo rows). ----
-    if (sg != nullptr && ft.bx1 > ft.bx0) {
-        const int gw = (ft.bx1 - ft.bx0 + 3) >> 2, gh = ft.by1 - ft.by0, nrb = (gh + kFusedBlurRows - 1) / kFusedBlurRows;
-        uint8_t* bout = blur + sg->blurOff + (long long)f * sg->blurFrameBytes;
-        const int bstride = sg->blurStride;
-        const float ginv = __frcp_rn((float)gw);
-        for (int item = tid; item < gw * nrb; item += 256) {
-            const int rb = (int)(((float)item + 0.5f) * ginv), cg = item - rb * gw;      // exact: item < 2^12, quotient >= 0.5 / gw away from an integer
-            const int x0 = ft.bx0 + 4 * cg, y0 = ft.by0 + rb * kFusedBlurRows;
-            const uint8_t* lp = tile + (y0 - 3 - fy0) * ldsStride + (x0 - 4 - fx0);         // pixels x0-4 .. of input row y0-3
-            const int lastIn = nRows - 1 - (y0 - 3 - fy0);                                  // rows past the staged tile are clamped (their outputs are not stored)
-            const int rowsValid = min(kFusedBlurRows, ft.by1 - y0);
-            uint8_t* dp = bout + (long long)y0 * bstride + x0;
-            blurBlock<kFusedBlurRows>(
-                [&](int i, unsigned& d0, unsigned& d1, unsigned& d2) {
-                    const unsigned* row = (const unsigned*)(lp + (i < lastIn ? i : lastIn) * ldsStride);
-                    d0 = row[0]; d1 = row[1]; d2 = row[2];
-                },
-                [&](int orow, unsigned w) {
-                    if (orow < rowsValid) *(unsigned*)(dp + orow * bstride) = w;
-                });
-        }
-    }
 }
 
 // bordered level 0 = the caller's image with a 19-px REFLECT_101 frame (:1213-1215)
@@ -263,7 +236,7 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
     } else {
         t -= nTiles0;
         const int tileY = t / tilesX1;
-        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride, nullptr, nullptr);
+        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride);
     }
 }
 
@@ -271,7 +244,7 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt,
                                                  const ResizeX* __restrict__ yt, const TileFoot* __restrict__ foot,
-                                                 uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int ldsStride, int f0, int nFrames) {
+                                                 uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
     SrcView sv;
     sv.p = pyr + s.pyrOff + (long long)kEdge * s.pyrStride + kPadL;
@@ -279,24 +252,10 @@ __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int ti
     int t, fr;
     if (!xcdChunkFrame(nFrames, t, fr)) return;   // neighbouring tiles of a frame (overlapping source footprints) on one XCD
     const int tileY = t / tilesX;
-    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride, blur ? &s : nullptr, blur);
+    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
 }
 
-// ---- small batches: levels 2.. in ONE launch --------------------------------------------------------------------------------
-// The level-by-level chain costs one launch (~6 us of latency, whatever its size) per level.  While a batch cannot fill the chip
-// anyway, every 64-byte x 16-row tile of every level >= 2 is instead computed by one workgroup straight from level 1 (which
-// k_pyr_first has just written): it loads the region of level 1 it depends on into LDS and re-derives, level by level, the interior
-// pixels of the levels in between (host-computed rectangles, ChainTile::region), ping-ponging between two LDS buffers; the last step
-// writes the tile with its REFLECT_101 border bytes.  Every intermediate pixel goes through the same rounded u8 arithmetic as in the
-// chain of launches, so the levels are bit-identical; the redundant work (a level-7 tile recomputes ~30 k pixels for its 1 k) is
-// irrelevant at these batch sizes.  640x480, one frame: six launches of 6 us -> one of ~11 us.
-
-__device__ __forceinline__ unsigned resizePixel(const uint8_t* r0, const uint8_t* r1, int c0, int c1, int a0, int a1, int b0, int b1) {
-    const int h0 = __mul24(r0[c0], a0) + __mul24(r0[c1], a1);
-    const int h1 = __mul24(r1[c0], a0) + __mul24(r1[c1], a1);
-    return (unsigned)(((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2);
-}
-
+// ---- stamped builds (-DORBX_CHAIN_STAMPS, tools/cols_stamps.py): s_memrealtime ticks of one region's stages and every region's span ----
 #ifdef ORBX_CHAIN_STAMPS
 __device__ unsigned long long g_chainStamps[32];
 #ifndef ORBX_CHAIN_STAMP_T
@@ -304,7 +263,7 @@ __device__ unsigned long long g_chainStamps[32];
 #endif
 #define CSTAMP(i) do { if (tid == 0 && t == ORBX_CHAIN_STAMP_T) g_chainStamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int orbx_debug_chain_stamps(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chainStamps), sizeof(unsigned long long) * 32); }
-// every tile's (start, end, level | XCC_ID << 8 | CU << 16) — tools/chain_spans.py
+// every region's (start, end, 0)
 __device__ unsigned long long g_chainSpans[3 * 2048];
 extern "C" int orbx_debug_chain_spans(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chainSpans), sizeof(g_chainSpans)); }
 #define CSPAN_BEGIN do { if (tid == 0 && t < 2048) g_chainSpans[3 * t] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -314,294 +273,63 @@ extern "C" int orbx_debug_chain_spans(unsigned long long* out) { return (int)hip
 #define CSPAN_BEGIN do {} while (0)
 #define CSPAN_END(lvl) do {} while (0)
 #endif
-constexpr int kChainThreads = 512;      // two waves per SIMD (1024 threads shorten a tile's steps but leave only two workgroups per CU: 18 -> 21 us)
 
-// One step of a chain: the interior rectangle rd of level j (LDS, row stride ds) resized from the rectangle rs of level j - 1 (LDS, row stride
-// ss); cxs / cys = the coefficient records of rd's columns / rows.
-// QUAD (k_pyr_cols): cxs holds one host-made QuadRec per column quad instead of one ResizeX per column.
-template <bool PACKED, int T = kChainThreads, bool QUAD = false>
-__device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ResizeX* cxs, const ResizeX* cys,
+// One level step of a region (k_pyr_cols): the rectangle rd of level j (LDS, row stride ds) resized from the rectangle rs of level j - 1 (LDS,
+// row stride ss); qrs = one host-made QuadRec per four adjacent columns of rd (tap window, v_perm selectors, weight pairs: orbx_geometry.hpp),
+// cys = the y records of rd's rows.  (The host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)
+// A thread owns four adjacent columns over a block of consecutive rows, so that the horizontal pass of a source row (three LDS dwords, two
+// v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it.  Threads are dealt quad-major (thread = row
+// block * quads + quad): every step keeps most of the T threads busy, each with few rows.
+template <int T>
+__device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ResizeX* qrs, const ResizeX* cys,
                                           const int ss, const int ds, const int tid) {
-    static_assert(PACKED || !QUAD, "quad records exist for the packed step only");
-    if constexpr (PACKED) {
-        // (the host checked that the 8 taps of ANY four adjacent columns lie inside 8 consecutive source bytes.)  A thread owns four
-        // adjacent columns over a block of consecutive rows, so that — as in resizeTile — the horizontal pass of a source row
-        // (three LDS dwords, two v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it:
-        // ~10 vector instructions per pixel instead of ~35 byte by byte.  The regions narrow from ~50 column quads to ~20 along
-        // the chain, so threads are dealt quad-major (thread = row block * quads + quad): every step keeps most of the 512
-        // threads busy, each with few rows.  The steps of a level-7 tile re-derive ~30 k pixels; they are its critical path.
-        const int nq = (rd.w + 3) >> 2, nb = T / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
-        const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
-        if (blk < nb && yb < ye) {
-            u16x2 wt[4];
-            unsigned sel[4];
-            int base;
-            unsigned sh;
-            if constexpr (QUAD) {
-                const uint4* qr = (const uint4*)((const QuadRec*)cxs + (x4 >> 2));      // three 16-byte LDS reads
-                const uint4 q0 = qr[0], q1 = qr[1];
-                const unsigned bs = ((const unsigned*)qr)[8];
-                sel[0] = q0.x; sel[1] = q0.y; sel[2] = q0.z; sel[3] = q0.w;
-                wt[0] = __builtin_bit_cast(u16x2, q1.x); wt[1] = __builtin_bit_cast(u16x2, q1.y); wt[2] = __builtin_bit_cast(u16x2, q1.z); wt[3] = __builtin_bit_cast(u16x2, q1.w);
-                base = (int)(bs & 0xffffu); sh = bs >> 16;
-            } else {
-            int c0[4], c1[4];
+    const int nq = (rd.w + 3) >> 2, nb = T / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
+    const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
+    if (blk < nb && yb < ye) {
+        u16x2 wt[4];
+        unsigned sel[4];
+        const uint4* qr = (const uint4*)((const QuadRec*)qrs + (x4 >> 2));      // three 16-byte LDS reads
+        const uint4 q0 = qr[0], q1 = qr[1];
+        const unsigned bs = ((const unsigned*)qr)[8];
+        sel[0] = q0.x; sel[1] = q0.y; sel[2] = q0.z; sel[3] = q0.w;
+        wt[0] = __builtin_bit_cast(u16x2, q1.x); wt[1] = __builtin_bit_cast(u16x2, q1.y); wt[2] = __builtin_bit_cast(u16x2, q1.z); wt[3] = __builtin_bit_cast(u16x2, q1.w);
+        const int base = (int)(bs & 0xffffu);
+        const unsigned sh = bs >> 16;
+        auto hrow = [&](int srow, unsigned (&h)[4]) {
+            const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
+            const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
+            const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const ResizeX cx = cxs[min(x4 + k, rd.w - 1)];
-                c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
-                wt[k] = u16x2{(unsigned short)cx.a0, (unsigned short)cx.a1};
-            }
-            const int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
-            base = lo & ~3;
-            sh = (unsigned)(lo & 3);
-#pragma unroll
-            for (int k = 0; k < 4; k++) sel[k] = 0x0C000C00u | (unsigned)(c0[k] - lo) | ((unsigned)(c1[k] - lo) << 16);
-            }
-            auto hrow = [&](int srow, unsigned (&h)[4]) {
-                const unsigned* rp = (const unsigned*)(S + __mul24(srow - rs.y0, ss) + base);
-                const unsigned p0 = rp[0], p1 = rp[1], p2 = rp[2];      // (up to 11 bytes past the last tap: the next row, or the buffers' tail padding)
-                const unsigned P0 = __builtin_amdgcn_alignbyte(p1, p0, sh), P1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
-            };
-            unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
-            int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
-            for (int y = yb; y < ye; y++) {
-                const ResizeX cy = cys[y];
-                const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
-                if (s0 != have0) {
-                    if (s0 == have1) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) H0[k] = H1[k];
-                    } else hrow(s0, H0);
-                    have0 = s0;
-                }
-                if (s1 != have1) {
-                    if (s1 == have0) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) H1[k] = H0[k];
-                    } else hrow(s1, H1);
-                    have1 = s1;
-                }
-                const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
-                unsigned t[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
-                const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
-                *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
-            }
-        }
-    } else {
-    // a thread owns four adjacent columns (their coefficients stay in registers) and walks down every eighth row: sixteen
-    // independent byte reads per step instead of a pixel-by-pixel chain of LDS round trips; one dword store per step
-    const int x4 = 4 * (tid & 63);
-    if (x4 < rd.w) {
-        ResizeX cx[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) cx[k] = cxs[min(x4 + k, rd.w - 1)];
-#pragma unroll 2
-        for (int y = tid >> 6; y < rd.h; y += T / 64) {
-            const ResizeX cy = cys[y];
-            const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
-            const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
-            unsigned o = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) o |= resizePixel(r0, r1, cx[k].sx0, cx[k].sx1, cx[k].a0, cx[k].a1, cy.a0, cy.a1) << (8 * k);
-            *(unsigned*)(D + y * ds + x4) = o;      // (columns past the region's width are padding of the 4-aligned stride)
-        }
-    }
-    }
-}
-
-
-// FROM_IMAGE (k_pyr_all's form): the chains start at the caller's image instead of level 1 — the tile list then holds the tiles of
-// level 1 (one step) and of level 0 (a bordered copy) too, and the WHOLE pyramid is one launch: one frame at 640x480 no longer waits
-// for k_pyr_first (7 us) before its chains start; a level-7 tile pays one more step (~13 k pixels) for it.
-template <bool PACKED, bool FROM_IMAGE>
-__global__ __launch_bounds__(kChainThreads) void k_pyr_chain(SrcView img, const ChainTile* __restrict__ tiles, const LevelGeom* __restrict__ lv,
-                                                              const ResizeX* __restrict__ rxAll, const ResizeX* __restrict__ ryAll,
-                                                              uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
-    constexpr int kStart = FROM_IMAGE ? 0 : 1;          // the level whose region is loaded from HBM
-    extern __shared__ __align__(16) uint8_t lds[];
-    __shared__ ResizeX coef[kChainCoefMax];
-    int t, fr;
-    if (!xcdChunkFrame(nFrames, t, fr)) return;
-    const int f = f0 + fr, tid = threadIdx.x;
-    CSTAMP(0);
-    CSPAN_BEGIN;
-    // (the tile record and the level table stay in memory and are read through wave-uniform loads: a by-value copy indexed by the
-    // step number would live in scratch)
-    const ChainTile& ct = tiles[t];
-    const int level = ct.level;
-    // region j lives in buffer j & 1.  (An offset from `lds`, not an entry of a pointer table: indexed at run time such a table holds GENERIC
-    // pointers and every access through it becomes a FLAT instruction - tools/isa/kernel_table.py)
-    auto bufOf = [&](int j) { return lds + ((j & 1) ? bufEvenBytes : 0); };
-    struct { int w, h, pyrRows, pyrStride; long long pyrOff, pyrFrameBytes; } d{ct.w, ct.h, ct.pyrRows, ct.pyrStride, ct.pyrOff, ct.pyrFrameBytes};
-    const int nd = (kPadL - kEdge + d.w + 2 * kEdge + 3) / 4, wB = d.w + 2 * kEdge;      // dwords of a bordered row (rowDwords)
-    if constexpr (FROM_IMAGE) {
-        if (level == 0) {      // bordered level 0 = the caller's image with a 19-px REFLECT_101 frame (:1213-1215), one dword per thread
-            const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col;
-            static_assert(kChainTile0Rows % (kChainThreads / kChainTileDw) == 0, "level-0 tile rows per pass");
-#pragma unroll
-            for (int rr = 0; rr < kChainTile0Rows; rr += kChainThreads / kChainTileDw) {      // all of a thread's loads in flight together
-                const int row = ct.tileY * kChainTile0Rows + rr + (tid >> 4);
-                if (dw < nd && row < d.pyrRows) {
-                const int bc0 = 4 * dw, x0 = bc0 - kPadL;       // interior x of the dword's first byte (a multiple of 4)
-                const uint8_t* srow = img.p + (long long)f * img.frame + (long long)reflect101(row - kEdge, d.h) * img.stride;
-                unsigned o;
-                if (img.aligned && x0 >= 0 && x0 + 3 < d.w) o = *(const unsigned*)(srow + x0);      // no reflection inside this dword
-                else {
-                    o = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        int bx = bc0 + k - (kPadL - kEdge);
-                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);      // bytes of a dword outside the bordered row are padding
-                        o |= (unsigned)srow[reflect101(bx - kEdge, d.w)] << (8 * k);
-                    }
-                }
-                *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + bc0) = o;
-                }
-            }
-            CSPAN_END(0);
-            return;
-        }
-    }
-    // the first eight steps' rectangles and table offsets are read with STATIC indices, i.e. as one batch of wave-uniform loads issued
-    // together (and here, ahead of the region's address arithmetic); indexed by a running j, every step waited for its own load (7 steps
-    // x one L2 round trip)
-    constexpr int kStatic = 8;
-    ChainRegion rj[kStatic + 1];
-    int xo[kStatic + 1], yo[kStatic + 1];
-#pragma unroll
-    for (int j = kStart; j <= kStatic; j++) { rj[j] = ct.region[j]; xo[j] = ct.rxOff[j]; yo[j] = ct.ryOff[j]; }
-    // ---- every load of the tile is issued up front: the first region (aligned dwords of level 1's bordered buffer, or of the
-    //      caller's image) and the coefficient records of ALL steps (x records of step j at coef[xo_j ..], y records behind them):
-    //      fetched step by step, each step would start with an L2 round trip ----
-    {
-        const ChainRegion r = rj[kStart];
-        const int nDw = r.w >> 2, total = nDw * r.h;
-        const uint8_t* src;
-        int srcStride;
-        if constexpr (FROM_IMAGE) {
-            src = img.p + (long long)f * img.frame + (long long)r.y0 * img.stride + r.x0;
-            srcStride = img.stride;
-        } else {
-            src = pyr + ct.srcOff + (long long)f * ct.srcFrameBytes + (long long)(kEdge + r.y0) * ct.srcStride + kPadL + r.x0;
-            srcStride = ct.srcStride;
-        }
-        unsigned* dst = (unsigned*)bufOf(kStart);
-        CSTAMP(20);
-        // the region's dwords are dealt flat (dword i of the region = row i / nDw, column i % nDw; the LDS copy is contiguous in i)
-        constexpr int kLoads = ((FROM_IMAGE ? kChainMaxH0 : kChainMaxH) * kChainMaxW / 4 + kChainThreads - 1) / kChainThreads;
-        const float inv = __frcp_rn((float)nDw);
-        unsigned w[kLoads];
-#pragma unroll
-        for (int i = 0; i < kLoads; i++) {
-            const int idx = min(tid + i * kChainThreads, total - 1);          // clamped: every lane loads a valid address
-            const int row = (int)(((float)idx + 0.5f) * inv), c = idx - row * nDw;      // exact: idx < 6144, the quotient is >= 0.5 / nDw away from an integer
-            const uint8_t* q = src + ((unsigned)__mul24(row, srcStride) + 4u * (unsigned)c);
-            if constexpr (FROM_IMAGE) {
-                const int x = r.x0 + 4 * c;
-                if (img.aligned && x + 3 < img.readableCols) w[i] = *(const unsigned*)q;
-                else {                                                          // a row's last dword, or an unaligned image: no byte past the row is read
-                    w[i] = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (x + b < img.readableCols) w[i] |= (unsigned)q[b] << (8 * b);
-                }
-            } else w[i] = *(const unsigned*)q;
-        }
-        // coefficient records: the steps' records form one flat list (x records of step j, then its y records, step after step;
-        // step `level` is the tile itself); a thread fetches entries tid, tid + T, ... — all loads are issued before the first
-        // result is stored, whichever step an entry belongs to
-        CSTAMP(21);
-        constexpr int kPerThread = (kChainCoefMax + kChainThreads - 1) / kChainThreads;
-        // which record a thread's slot holds is settled in registers first (a walk over the <= 7 steps with wave-uniform bounds: selects,
-        // no memory), THEN every slot issues its one load: a conditional load per step and slot serialised the steps' memory round trips
-        // (a level-7 tile: 2.1 us before its region could be stored)
-        int sel[kPerThread];                                 // element of rxAll (>= 0) or ~element of ryAll (< 0); INT_MIN: no record
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) sel[k] = (int)0x80000000;
-        int off = 0;
-        auto walk = [&](int j, const ChainRegion rj, int xo, int yo) {
-            const int nx = j < level ? rj.w : 4 * kChainTileDw, ny = j < level ? rj.h : kChainTileRows;
-            const int rx0 = j < level ? rj.x0 : 0, ry0 = j < level ? rj.y0 : 0;
-#pragma unroll
-            for (int k = 0; k < kPerThread; k++) {
-                const int i = tid + k * kChainThreads - off;
-                if (i >= 0 && i < nx + ny) {
-                    if (j < level) sel[k] = i < nx ? xo + rx0 + i : ~(yo + ry0 + i - nx);
-                    else if (i < nx) {
-                        int bx = 4 * ct.tileX * kChainTileDw + i - (kPadL - kEdge);
-                        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);            // bytes of a dword outside the bordered row are padding
-                        sel[k] = xo + reflect101(bx - kEdge, d.w);
-                    } else sel[k] = ~(yo + reflect101(min(ct.tileY * kChainTileRows + i - nx, d.pyrRows - 1) - kEdge, d.h));
-                }
-            }
-            off += nx + ny;
+            for (int k = 0; k < 4; k++)
+                h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
         };
-        {
+        unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
+        int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
+        for (int y = yb; y < ye; y++) {
+            const ResizeX cy = cys[y];
+            const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
+            if (s0 != have0) {
+                if (s0 == have1) {
 #pragma unroll
-            for (int j = kStart + 1; j <= kStatic; j++)
-                if (j <= level) walk(j, rj[j], xo[j], yo[j]);            // wave-uniform
-            for (int j = kStatic + 1; j <= level; j++) walk(j, ct.region[j], ct.rxOff[j], ct.ryOff[j]);      // (more than nine levels)
-        }
-        ResizeX cv[kPerThread];
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            const ResizeX* q = sel[k] >= 0 ? rxAll + sel[k] : ryAll + ~sel[k];
-            cv[k] = sel[k] != (int)0x80000000 ? *q : ResizeX{0, 0, 0, 0};
-        }
-        CSTAMP(22);
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++)
-            if (tid + k * kChainThreads < off) coef[tid + k * kChainThreads] = cv[k];
-        CSTAMP(23);
-#pragma unroll
-        for (int i = 0; i < kLoads; i++)
-            if (tid + i * kChainThreads < total) dst[tid + i * kChainThreads] = w[i];
-    }
-    __syncthreads();
-    CSTAMP(1);
-    // ---- the levels in between: interior pixels only ----
-    int off = 0;
-    ChainRegion rs = ct.region[kStart], rd = ct.region[kStart + 1 < kMaxLevels ? kStart + 1 : kStart];
-    for (int j = kStart + 1; j < level; j++) {
-        const ChainRegion rnext = ct.region[j + 1 < kMaxLevels ? j + 1 : j];      // requested a step ahead: no wait at the top of the next step
-        const int ss = (rs.w + 3) & ~3, ds = (rd.w + 3) & ~3;
-        const uint8_t* S = bufOf(j - 1);
-        uint8_t* D = bufOf(j);
-        const ResizeX *cxs = coef + off, *cys = cxs + rd.w;
-        chainStep<PACKED>(S, D, rs, rd, cxs, cys, ss, ds, tid);
-        off += rd.w + rd.h;
-        rs = rd; rd = rnext;
-        __syncthreads();
-        CSTAMP(j);
-    }
-    // ---- the tile itself: bordered bytes, the border mirrors the interior (copyMakeBorder REFLECT_101 fused) ----
-    if (tid < kChainTileDw * kChainTileRows) {
-        const ChainRegion rs = ct.region[level - 1];
-        const int ss = (rs.w + 3) & ~3;
-        const uint8_t* S = bufOf(level - 1);
-        const ResizeX *cxs = coef + off, *cys = cxs + 4 * kChainTileDw;
-        const int col = tid & (kChainTileDw - 1), dw = ct.tileX * kChainTileDw + col, row = ct.tileY * kChainTileRows + (tid >> 4);
-        if (dw < nd && row < d.pyrRows) {
-            const ResizeX cy = cys[tid >> 4];
-            const uint8_t* r0 = S + (cy.sx0 - rs.y0) * ss - rs.x0;
-            const uint8_t* r1 = S + (cy.sx1 - rs.y0) * ss - rs.x0;
-            unsigned o = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const ResizeX cx = cxs[4 * col + k];
-                o |= resizePixel(r0, r1, cx.sx0, cx.sx1, cx.a0, cx.a1, cy.a0, cy.a1) << (8 * k);
+                    for (int k = 0; k < 4; k++) H0[k] = H1[k];
+                } else hrow(s0, H0);
+                have0 = s0;
             }
-            *(unsigned*)(pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)row * d.pyrStride + 4 * dw) = o;
+            if (s1 != have1) {
+                if (s1 == have0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) H1[k] = H0[k];
+                } else hrow(s1, H1);
+                have1 = s1;
+            }
+            const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
+            unsigned t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
+            const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
+            *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
         }
     }
-    CSTAMP(level);
-    CSPAN_END(level);
 }
 
 // ---- region-major pyramid (orbx_device.hpp: PyrColumn): one workgroup = one region of the image through EVERY level.  The region's rectangle
@@ -639,7 +367,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
     CSTAMP(0);
     CSPAN_BEGIN;
     auto bufOf = [&](int j) { return lds + ((j & 1) ? bufEvenBytes : 0); };      // level j's rectangle lives in buffer j & 1 (an LDS offset, never a generic pointer)
-    // the rectangles of the first nine levels are read with STATIC indices: one batch of wave-uniform loads (k_pyr_chain has the reasons)
+    // the rectangles of the first nine levels are read with STATIC indices (a run-time index into the by-value record would go through scratch): one batch of wave-uniform loads
     constexpr int kStatic = 8;
     ChainRegion rj[kStatic + 1];
 #pragma unroll
@@ -694,7 +422,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         if (j < top) {
             const ResizeX* cxs = coef + off;                        // the level's quad records, then its y records (PyrColumn's layout)
             const int nqUnits = 6 * ((rd.w + 3) >> 2);
-            if (tid < TD) chainStep<true, TD, true>(S, bufOf(j + 1), rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
+            if (tid < TD) chainStep<TD>(S, bufOf(j + 1), rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
             off += nqUnits + ((rd.h + 1) & ~1);
         }
         // (the last level has nothing to derive: every thread writes)
@@ -809,10 +537,10 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
-    static const int blurMinRun = getenv("ORBX_BLUR_MIN_RUN") ? std::max(2, atoi(getenv("ORBX_BLUR_MIN_RUN"))) : 16;
+    constexpr int blurMinRun = 8;      // (measured, 512 x 640x480, three levels inside: runs of >= 8 rows 617 us, 16: 668, 24: 680, 32: 770 - few long runs leave most of a workgroup at the level's barrier)
 #define ORBX_COLS_LAUNCH(P, T, TD) do { \
         if (blur) hipLaunchKernelGGL((k_pyr_cols<P, T, TD, true>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, blur, blurLevels, blurMinRun, bufEvenBytes, f0, B); \
-        else hipLaunchKernelGGL((k_pyr_cols<P, T, TD, false>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, blur, 0, 16, bufEvenBytes, f0, B); \
+        else hipLaunchKernelGGL((k_pyr_cols<P, T, TD, false>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, blur, 0, blurMinRun, bufEvenBytes, f0, B); \
     } while (0)
     (void)packed;      // (the host only takes this form when the taps of every column quad fit the packed step's 8-byte window)
     if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
@@ -823,22 +551,6 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
     else if (variant == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
     else ORBX_COLS_LAUNCH(true, 256, 256);
 #undef ORBX_COLS_LAUNCH
-}
-
-void launchPyrRest(hipStream_t st, const ChainTile* tiles, int nTiles, const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry,
-                   uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
-    const SrcView none{};
-    if (packed) hipLaunchKernelGGL((k_pyr_chain<true, false>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, none, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
-    else hipLaunchKernelGGL((k_pyr_chain<false, false>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, none, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
-}
-// the whole pyramid (levels 0 .. nlevels-1) from the caller's image in one launch
-void launchPyrAll(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const ChainTile* tiles, int nTiles,
-                  const LevelGeom* lv, const ResizeX* rx, const ResizeX* ry, uint8_t* pyr, int ldsBytes, int bufEvenBytes, bool packed, int f0, int B) {
-    SrcView sv;
-    sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
-    sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
-    if (packed) hipLaunchKernelGGL((k_pyr_chain<true, true>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, sv, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
-    else hipLaunchKernelGGL((k_pyr_chain<false, true>), xcdGrid(nTiles, B), dim3(kChainThreads), (size_t)ldsBytes, st, sv, tiles, lv, rx, ry, pyr, bufEvenBytes, f0, B);
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,
@@ -854,13 +566,12 @@ void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long l
     else hipLaunchKernelGGL(k_pyr_first<false>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
                             g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
 }
-// blur != nullptr: the tiles also write their share of the blurred SOURCE level
 void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt,
-                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, uint8_t* blur, int ldsStride, int ldsRows, bool packed, int f0, int B) {
+                  const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {
     if (packed) hipLaunchKernelGGL(k_resize<true>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                                   tilesX, xt, yt, foot, pyr, blur, ldsStride, f0, B);
+                                   tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
     else hipLaunchKernelGGL(k_resize<false>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                            tilesX, xt, yt, foot, pyr, blur, ldsStride, f0, B);
+                            tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
 }
 
 }  // namespace orbx

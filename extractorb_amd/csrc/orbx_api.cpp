@@ -21,13 +21,11 @@ namespace orbx {
 void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
                     const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
 void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
-                  uint8_t*, uint8_t*, int, int, bool, int, int);
-void launchPyrRest(hipStream_t, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
+                  uint8_t*, int, int, bool, int, int);
 struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchLdsPollute(hipStream_t, int, int, unsigned*);
-void launchPyrAll(hipStream_t, const uint8_t*, long long, long long, int, const ChainTile*, int, const LevelGeom*, const ResizeX*, const ResizeX*, uint8_t*, int, int, bool, int, int);
 void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, uint8_t*, int, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
@@ -133,8 +131,6 @@ struct orbx_handle {
     LevelGeom* d_lv = nullptr;
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
-    ChainTile* d_chain = nullptr;       // tiles of the small-batch pyramid kernel
-    ChainTile* d_chainAll = nullptr;    // tiles of the one-launch pyramid (smallest batches)
     PyrColumn* d_cols = nullptr;        // regions of the region-major pyramid (k_pyr_cols)
     size_t colsCap = 0, colsOff[8] = {};   // first column of each cut of the geometry in d_cols
     ResizeX* d_colCoef = nullptr;       // the regions' coefficient lists, cut after cut
@@ -142,27 +138,18 @@ struct orbx_handle {
     ColLevels* d_colLevels = nullptr;
     int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
     int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
-    long long pyrColsWgs = 0;           // ORBX_PYR_COLS_WGS: largest grid it is preferred for (0: default)
     int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
-    long long fastWideWgs = 0;          // ORBX_FAST_WIDE_WGS: most cells per call it is used for (0: 4 per CU)
-    int blurInCols = -1;                // ORBX_BLUR_IN_COLS: 1 = the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken, 0 = never, default: by the batch size
-    long long blurInColsMinFrames = 1LL << 40;      // ORBX_BLUR_IN_COLS_MIN_FRAMES: smallest batch (frames per launch) the default takes it for
+    int blurInCols = 0;                 // ORBX_BLUR_IN_COLS=1: the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken (opt-in: slower)
     int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
-    long long pyrAllWgs = 0;            // ORBX_PYR_ALL_WGS: largest one-launch pyramid grid still preferred to k_pyr_first + k_pyr_rest (0: default, < 0: never)
-    size_t chainCap = 0;
-    bool pyrChain = true;               // ORBX_PYR_CHAIN=0: small batches keep one launch per level
-    long long pyrChainWgs = 0;          // ORBX_PYR_CHAIN_WGS: largest k_pyr_rest grid (workgroups) still preferred to the per-level launches (default 16 per CU: six 640x480 frames - 112 -> 102 us; eight: equal; twelve: 140 -> 175 us)
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
     unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
     size_t laneCap = 0;
-    int nBlurLanes[4] = {0, 0, 0, 0};     // [2]: 32-row blocks of the levels no resize launch blurs (level 0 and the last one); [3]: of the levels k_pyr_cols<.., BLUR> leaves (>= blurInLevels)
-    size_t blurItemOff[4] = {0, 0, 0, 0}, blurLaneOff[4] = {0, 0, 0, 0};
+    int nBlurLanes[3] = {0, 0, 0};     // [0]: 32-row blocks of every level, [1]: 8-row blocks (small batches), [2]: 32-row blocks of the levels k_pyr_cols<.., BLUR> leaves (>= blurInLevels)
+    size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
     int blurInLevels = 5;              // ORBX_BLUR_IN_LEVELS: the finest levels the region-major pyramid blurs itself when it carries the blur (the halo compounds
                                        // down the chain: 640x480, 112-px regions, derived pixels +3 % for 3 levels = 70 % of the blur's pixels, +9 % for 5 = 89 %, +30 % for all 8)
-    bool fuseBlur = false;             // ORBX_FUSE_BLUR=1: large batches blur levels 1 .. n-2 inside the resize launches (HBM traffic 8.56 -> 7.67 MB per frame,
-                                       // but 1.7x the instructions for that share: +2.5 % step time)
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
     uint8_t* d_octArena = nullptr;
@@ -170,7 +157,6 @@ struct orbx_handle {
     // small batches: per-(frame, level, root) leaf counters / best keys filled by k_fast's emit, consumed and cleared by k_octree
     // (orbx_device.hpp: LeafTables); d_leafCode = [2][nlevels][octXT] host-built x / y path codes of the current geometry
     int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 128; 0 = off)
-    int octSmallT = 0;             // ORBX_OCT_SMALL_T: quad-tree workgroup size of the small-batch form (0 = by the largest level quota)
     int* d_leafHist = nullptr;
     unsigned* d_leafBest = nullptr;
     uint8_t* d_leafCode = nullptr;
@@ -193,7 +179,6 @@ struct orbx_handle {
     struct OutView { Keypoint* k = nullptr; uint8_t* d = nullptr; int* n = nullptr; int* mono = nullptr; Keypoint* lk = nullptr; int* lc = nullptr; };
     OutView dev, host;
     bool pyramidOnly = false;          // the last call was orbx_compute_pyramid: the handle holds a pyramid (and blurred levels) but no results
-    int blurAsync = -1;                // ORBX_BLUR_ASYNC: 1 = the blur runs on a side stream beside FAST and the quad-tree whatever the batch, 0 = never, default: large batches
     bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
     bool testFailAfterFast = false;    // ORBX_TEST_FAIL_AFTER_FAST (test aid)
     bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
@@ -223,7 +208,7 @@ struct orbx_handle {
     hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
     hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
     int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream (the largest also stagger
-                                       // their tails: enqueueBatch); 0 = no overlap of any kind; 2 = round 2's two half-batches side by side; 3 = staggered tails for every large batch
+                                       // their tails: enqueueBatch); 0 = no overlap of any kind; 3 = staggered tails for every large batch
     bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
     bool statPending = false;
@@ -288,7 +273,7 @@ orbx_handle::OutView outView(uint8_t* base, const OutLayout& o) {
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_chain, h->d_chainAll, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -307,7 +292,7 @@ void freeAll(orbx_handle* h) {
 // Uploads the tables of h->geom (already laid out) and checks they fit the arenas.
 int installGeometry(orbx_handle* h, int rows, int cols) {
     FrameGeom g;
-    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->fuseBlur, h->colPx, h->blurInLevels);
+    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->colPx, h->blurInLevels);
     if (!why.empty()) return fail(h, why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED, why);
     layoutArenas(g, h->maxB);
     const LevelGeom& last = g.lv[g.nlevels - 1];
@@ -350,14 +335,6 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
         fo += g.foot[l].size();
     }
-    for (std::vector<ChainTile>* list : {&g.chain, &g.chainAll})      // the tiles carry what they need of the level tables (orbx_device.hpp: ChainTile)
-        for (ChainTile& c : *list) {
-            const LevelGeom& L = g.lv[c.level];
-            c.w = L.w; c.h = L.h; c.pyrRows = L.pyrRows; c.pyrStride = L.pyrStride; c.pyrOff = L.pyrOff; c.pyrFrameBytes = L.pyrFrameBytes;
-            const LevelGeom& S = g.lv[g.nlevels > 1 ? 1 : 0];
-            c.srcOff = S.pyrOff; c.srcFrameBytes = S.pyrFrameBytes; c.srcStride = S.pyrStride; c.pad2 = 0;
-            for (int j = 0; j < kMaxLevels; j++) { c.rxOff[j] = j < g.nlevels ? g.lv[j].rxOff : 0; c.ryOff[j] = j < g.nlevels ? g.lv[j].ryOff : 0; }
-        }
     {
         size_t n = 0, nc = 0;
         for (std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
@@ -381,21 +358,16 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         }
         HIP_TRY(h, hipMemcpy(h->d_colLevels, &c, sizeof(c), hipMemcpyHostToDevice));
     }
-    if (g.chain.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
-    if (!g.chain.empty()) HIP_TRY(h, hipMemcpy(h->d_chain, g.chain.data(), sizeof(ChainTile) * g.chain.size(), hipMemcpyHostToDevice));
-    if (g.chainAll.size() > h->chainCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "pyramid chain table does not fit");
-    if (!g.chainAll.empty()) HIP_TRY(h, hipMemcpy(h->d_chainAll, g.chainAll.data(), sizeof(ChainTile) * g.chainAll.size(), hipMemcpyHostToDevice));
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
-        const int blockRows[4] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows, kBlurBlockRows};
-        for (int v = 0; v < 4; v++) {
+        const int blockRows[3] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows};
+        for (int v = 0; v < 3; v++) {
             const size_t t0 = tiles.size(), l0 = laneItem.size();
             int lanes = 0;
-            if (v == 3 && h->blurInLevels >= g.nlevels) { h->nBlurLanes[v] = 0; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
+            if (v == 2 && h->blurInLevels >= g.nlevels) { h->nBlurLanes[v] = 0; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
             for (int l = 0; l < g.nlevels; l++) {
-                if (v == 3 && l < h->blurInLevels) continue;               // the region-major pyramid blurs the finest levels itself
-                if (v == 2 && l >= 1 && l <= g.nlevels - 2) continue;      // levels 1 .. n-2 are blurred by the resize launches of levels 2 .. n-1
+                if (v == 2 && l < h->blurInLevels) continue;               // the region-major pyramid blurs the finest levels itself
                 for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
                     laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)(tiles.size() - t0));
                     tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
@@ -495,21 +467,20 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // path (0.53 of the issue rate), k_fast sits at the issue ceiling with idle memory pipes: 512 x 640x480 2016-2040 us unsplit, 1981-1988 as two
     // halves side by side (round 2's form), 1915-1933 with the blur aside (two halves AND the blur aside: 1932-1937); 256 frames 1035-1055 / 1001-1014 /
     // 999-1007; 128 x 1080p 3094-3136 (halves) -> 3021-3029; 128 frames of 640x480 and fewer: no difference.  A low-priority side stream only starts
-    // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time), 2: round 2's halves.
+    // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time).  (Round 2's two
+    // half-batches side by side - removed in round 4 - are the "halves" figures above; profiles/r02_split_sweep.md.)
     const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
-    const bool blurSide = (h->blurAsync > 0 || (h->blurAsync < 0 && (h->splitMode == 1 || h->splitMode == 3) && bigBatch)) && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
+    const bool blurSide = h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
     bool blurJoin[2] = {false, false};
     int blurF0[2] = {0, 0}, blurBn[2] = {0, 0};
     auto front = [&](hipStream_t st, int f0, int Bn) {
-        bool fused = false;      // set when the per-level resize launches below also blur their source levels
         int blurInside = 0;      // > 0: the region-major pyramid launch has written that many of the finest blurred levels as well
-        // smallest batches (one or two frames): the whole pyramid in ONE launch, every tile of every level derived from the caller's image
-        const bool all = h->pyrChain && h->pyrAllWgs >= 0 && g.nlevels > 2 && g.chainAllFits && g.chainAllLdsBytes <= 60 * 1024 &&
-                         (long long)g.chainAll.size() * Bn <= (h->pyrAllWgs > 0 ? h->pyrAllWgs : 10LL * h->numCUs);      // 640x480: one or two frames (four: 94 vs 85 us)
-        // ... or, with far less arithmetic, region by region: one workgroup takes a region of the image through every level
-        // (the coarsest cut that still gives the chip ~3/4 workgroup per CU, else the finest; while the coarsest cut stays below ~12 per CU.
-        // 640x480, us per call, tile forms -> this: 1 frame (40-px regions) 46.0 -> 40.9, 2 (56 px) 53.5 -> 45.7, 4: 66.2 -> 58.8, 8 (112 px): 93.4 -> 71.2,
-        // 16: 133 -> 113, 32: 193 -> 172, 64: 309 -> 293, 128: 588 -> 582; 256 frames: 1043 -> 1062, the per-level launches win)
+        // The pyramid region by region: one workgroup takes a region of the image through every level (k_pyr_cols; the coarsest cut that still
+        // gives the chip ~3/4 workgroup per CU, else the finest).  Frames up to half a megapixel: for every batch size (512 frames of 640x480:
+        // 2016 -> 1979 us per call against one launch per level, whose tiles are poorly filled on such small levels); larger frames: while the
+        // coarsest cut stays below ~12 workgroups per CU - 1280x720: 16 frames 236 -> 226 us, 32: equal, 64: 767 vs 788; 1920x1080: 16 frames
+        // 431 -> 422, 64: 1530 vs 1582, 128: 3119 vs 3222.  (Round 2's per-tile chains, k_pyr_chain, lost to it at every size and were removed in
+        // round 4; a geometry whose regions do not fit the kernel's staging - none of the tested ones - takes one launch per level.)
         const FrameGeom::ColumnSet* cs = nullptr;
         auto pickCut = [&](const std::vector<FrameGeom::ColumnSet>& sets) {
             const FrameGeom::ColumnSet* best = nullptr;
@@ -521,22 +492,17 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         };
         if (h->pyrCols != 0 && g.colsPacked && !h->resizeBytewise) {     // (its steps are the packed ones: the regions carry quad records)
             cs = pickCut(g.colSets);
-            // ... and the regions blur what they own of every level before they move on (one launch and the blur's read of the pyramid fewer)
-            const bool blurIn = h->blurInCols > 0 || (h->blurInCols < 0 && (long long)Bn >= h->blurInColsMinFrames);
-            if (cs && blurIn) {
+            // ORBX_BLUR_IN_COLS=1: the regions also blur what they own of the finest levels before they move on (bit-exact; slower than k_blur
+            // beside FAST: DESIGN.md §4)
+            if (cs && h->blurInCols > 0) {
                 const FrameGeom::ColumnSet* cb = pickCut(g.colSetsBlur);
                 if (cb && cb->px == cs->px) cs = cb;
             }
         }
-        // (frames up to half a megapixel: for every batch size - 512 frames of 640x480: 2016 -> 1979 us per call, the per-level tiles of such
-        // small levels are poorly filled; larger frames: while the coarsest cut stays below ~12 workgroups per CU - 1280x720: 16 frames 236 -> 226 us,
-        // 32: equal, 64: 767 vs 788; 1920x1080: 16 frames 431 -> 422, 64: 1530 vs 1582, 128: 3119 vs 3222)
         const bool smallFrame = (long long)g.rows * g.cols <= 512 * 1024;
-        if (cs && h->pyrCols < 0 && (h->pyrColsWgs > 0 || !smallFrame) &&
-            (long long)cs->columns.size() * Bn > (h->pyrColsWgs > 0 ? h->pyrColsWgs : 12LL * h->numCUs)) cs = nullptr;
-        if (cs && h->pyrCols < 0 && h->fuseBlur) cs = nullptr;      // ORBX_FUSE_BLUR=1 asks for the per-level launches (which then carry the blur)
+        if (cs && h->pyrCols < 0 && !smallFrame && (long long)cs->columns.size() * Bn > 12LL * h->numCUs) cs = nullptr;
         h->lastPyrCut = cs ? cs->px : 0;
-        h->lastPyrForm = cs ? 0 : (all ? 1 : 2);
+        h->lastPyrForm = cs ? 0 : 1;
         if (cs) {
             // workgroup shape (launchPyrCols): while every workgroup has a CU to itself, more threads shorten its levels - 1024 (512 derive, 512
             // write) for the fine cuts, 768 (256 + 512) for the coarse ones, whose levels write more than they derive; else 512 (256 + 256).
@@ -549,54 +515,34 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                           h->d_colCoef + h->colCoefOff[slot], cs->coefSlot, h->d_pyr, cs->blurLevels ? h->d_blur : nullptr, cs->blurLevels, cs->ldsBytes, cs->evenBytes,
                           g.colsPacked && !h->resizeBytewise, h->colsVariant >= 0 ? h->colsVariant : colsShape, f0, Bn);
             blurInside = cs->blurLevels;
-        } else if (all) {
-            Prof p(h, S_RESIZE, st);
-            pollute(st);
-            launchPyrAll(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_chainAll, (int)g.chainAll.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr,
-                         g.chainAllLdsBytes, g.chainAllEvenBytes, g.chainAllPacked && !h->resizeBytewise, f0, Bn);
         } else {
-        {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
-            Prof p(h, S_LEVEL0, st);
-            pollute(st);
-            launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
-                           g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
-                           g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
-        }
-        // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above), or - while the batch
-        // cannot fill the chip anyway - ONE launch in which every tile re-derives what it needs of the levels in between (k_pyr_rest)
-        const bool chain = h->pyrChain && g.nlevels > 2 && !g.chain.empty() && g.chainFits && g.chainLdsBytes <= 60 * 1024 &&
-                           (long long)g.chain.size() * Bn <= (h->pyrChainWgs > 0 ? h->pyrChainWgs : 16LL * h->numCUs);
-        if (!chain) h->lastPyrForm = 3;
-        if (chain) {
-            Prof p(h, S_RESIZE, st);
-            pollute(st);
-            launchPyrRest(st, h->d_chain, (int)g.chain.size(), h->d_lv, h->d_rx, h->d_ry, h->d_pyr, g.chainLdsBytes, g.chainEvenBytes, g.chainPacked && !h->resizeBytewise, f0, Bn);
-        } else {
-            // large batches: the resize of level l blurs level l - 1 out of the tile it has staged (the blur kernel then only does level 0
-            // and the last level); small batches keep the short-chain blur that rides with FAST
-            fused = h->fuseBlur && g.blurFused && g.nlevels >= 3 && blurVariant(Bn) == 0;
-            for (int l = 2; l < g.nlevels; l++) {
+            {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
+                Prof p(h, S_LEVEL0, st);
+                pollute(st);
+                launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
+                               g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
+                               g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
+            }
+            for (int l = 2; l < g.nlevels; l++) {      // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above)
                 Prof p(h, S_RESIZE, st);
                 pollute(st);
                 launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
-                             h->d_foot + h->footOff[l], h->d_pyr, fused ? h->d_blur : nullptr, g.tileLdsStride, g.tileLdsRows,
-                             g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
+                             h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
             }
-        }
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
-        h->lastBlurForm = blurInside ? 3 : (blurRidesWithFast(Bn) ? 1 : (fused ? 2 : 0));
+        h->lastBlurForm = blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0);
         h->blurOwed = !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
         if (blurInside) {
-            if (h->nBlurLanes[3] > 0) {      // the coarse levels the regions do not blur
+            if (h->nBlurLanes[2] > 0) {      // the coarse levels the regions do not blur
                 Prof p(h, S_BLUR, st);
                 pollute(st);
-                launchBlur(st, h->d_tiles + h->blurItemOff[3], h->d_laneItem + h->blurLaneOff[3], h->nBlurLanes[3], kBlurBlockRows, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+                launchBlur(st, h->d_tiles + h->blurItemOff[2], h->d_laneItem + h->blurLaneOff[2], h->nBlurLanes[2], kBlurBlockRows, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
             }
         } else if (!blurRidesWithFast(Bn)) {
             Prof p(h, S_BLUR, st);
-            const int v = fused ? 2 : blurVariant(Bn);
+            const int v = blurVariant(Bn);
             pollute(st);
             // the blurred levels are only read by k_describe, the last launch: with ORBX_BLUR_ASYNC=1 an unsplit batch blurs on the internal
             // stream, beside k_fast and the quad-tree (pyramid -> {blur, FAST -> quad-tree} -> description)
@@ -635,7 +581,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
                        h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
-                       h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= (h->fastWideWgs > 0 ? h->fastWideWgs : 4LL * h->numCUs)));
+                       h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs));
         }
     };
     auto backTail = [&](hipStream_t st, int f0, int Bn) {
@@ -659,7 +605,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                 // (nfeatures 1200, level-0 quota 261: 512 threads 14.1 us, 1024 threads 15.1 - its last pass ranks up to 256 multi-key nodes
                 // against each other, one packed key per node; before the packed key the larger workgroup won, 18.0 vs 19.3)
                 int need = q + 4 <= 256 ? 256 : (q + 4 <= 512 ? 512 : residentT);
-                if (h->octSmallT) need = h->octSmallT;   // ORBX_OCT_SMALL_T: measurement override
                 if (need < residentT) residentT = need;
             }
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
@@ -679,10 +624,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) { backFast(st, f0, Bn); backTail(st, f0, Bn); };
-    // Round 2's overlap (now ORBX_SPLIT=2 only; the blur on a side stream, above, replaced it as the default): a large batch as two half-batches
-    // side by side, one on the caller's stream and one on an internal stream (fork / join with events).  Measured (profiles/r02_split_sweep.md):
-    // +3 % at 512 x 640x480, +1.5 % at 256, -9 % at 128 frames.  Staggering the halves and four parts were both slower.
-    const bool split = h->splitMode == 2 && !h->profiling && B >= 2 && bigBatch;
     struct BlurJoin {      // a blur left on the side stream by an early return is still joined into the caller's stream
         orbx_handle* h; hipStream_t st; bool* pending;
         ~BlurJoin() { for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0); }
@@ -710,22 +651,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         backTail(h->aux, 0, B0);
         backFast(st, B0, B - B0);
         backTail(st, B0, B - B0);
-    } else if (!split || !doFront || !doBack) {
+    } else {
         if (doFront) front(st, 0, B);
         if (doBack) back(st, 0, B);
-    } else {
-        struct Join {      // the internal stream is always joined back into the caller's, also on an early error return
-            orbx_handle* h; hipStream_t st; bool armed = false;
-            ~Join() { if (armed) { (void)hipEventRecord(h->evJoin, h->aux); (void)hipStreamWaitEvent(st, h->evJoin, 0); } }
-        } join{h, st};
-        HIP_TRY(h, hipEventRecord(h->evFork, st));
-        HIP_TRY(h, hipStreamWaitEvent(h->aux, h->evFork, 0));
-        join.armed = true;
-        const int B0 = (B + 1) / 2;
-        front(st, 0, B0);
-        back(st, 0, B0);
-        front(h->aux, B0, B - B0);
-        back(h->aux, B0, B - B0);
     }
     // statistics for the next batches' kernel choice; nobody waits for this copy.  Once a density is known the stream is sampled every 32nd
     // call only: the copy is a 4-us blit kernel on the stream, 7 % of a single-frame call
@@ -867,7 +795,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->maxW = max_width; h->maxH = max_height; h->maxB = max_batch;
     h->tabs = makeScaleTables(nfeatures, scale_factor, nlevels);
     if (const char* e = getenv("ORBX_BLUR_IN_LEVELS")) h->blurInLevels = std::max(1, std::min(atoi(e), (int)kMaxLevels));
-    std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom, true);      // (sizes the LDS tile for either form)
+    std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom);
     if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
     layoutArenas(h->maxGeom, max_batch);
     const FrameGeom& mg = h->maxGeom;
@@ -924,7 +852,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     // 64: 306 -> 296, 128: 562 -> 556, 256: 1040 -> 1046, 512: 2040 -> 2053; 1920x1080: 16 frames 519 -> 431, 32: 904 -> 827, 128: 3108 -> 3092)
     h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 128;
     if (h->leafFrames > max_batch) h->leafFrames = max_batch;
-    if (const char* e = getenv("ORBX_OCT_SMALL_T")) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) h->octSmallT = t; }
     if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree
     if (h->leafFrames) {
         const size_t n = (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves;
@@ -943,18 +870,11 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_ry, sizeof(ResizeX) * h->rxCap);
     CREATE_ALLOC(h->d_tiles, sizeof(BlurItem) * h->tileCap);
     CREATE_ALLOC(h->d_laneItem, sizeof(unsigned short) * h->laneCap);
-    h->chainCap = roomy((size_t)(((max_width + 38 + 32 + 63) / 64 + 1) * ((max_height + 38 + 15) / 16 + 1)) * nlevels);
-    CREATE_ALLOC(h->d_chain, sizeof(ChainTile) * h->chainCap);
-    CREATE_ALLOC(h->d_chainAll, sizeof(ChainTile) * h->chainCap);
-    h->pyrAllWgs = getenv("ORBX_PYR_ALL_WGS") ? atoll(getenv("ORBX_PYR_ALL_WGS")) : 0;
     h->pyrCols = getenv("ORBX_PYR_COLS") ? atoi(getenv("ORBX_PYR_COLS")) : -1;
     h->colPx = getenv("ORBX_PYR_COL_PX") ? atoi(getenv("ORBX_PYR_COL_PX")) : 0;
-    h->pyrColsWgs = getenv("ORBX_PYR_COLS_WGS") ? atoll(getenv("ORBX_PYR_COLS_WGS")) : 0;
     h->fastWide = getenv("ORBX_FAST_WIDE") ? atoi(getenv("ORBX_FAST_WIDE")) : -1;
-    h->fastWideWgs = getenv("ORBX_FAST_WIDE_WGS") ? atoll(getenv("ORBX_FAST_WIDE_WGS")) : 0;
     h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
-    h->blurInCols = getenv("ORBX_BLUR_IN_COLS") ? atoi(getenv("ORBX_BLUR_IN_COLS")) : -1;
-    if (const char* e = getenv("ORBX_BLUR_IN_COLS_MIN_FRAMES")) h->blurInColsMinFrames = atoll(e);
+    h->blurInCols = getenv("ORBX_BLUR_IN_COLS") ? atoi(getenv("ORBX_BLUR_IN_COLS")) : 0;
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += 2 * (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);      // (every cut with and without the blur's halo)
     h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)
@@ -962,14 +882,11 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_colCoef, sizeof(ResizeX) * h->colCoefCap);
     CREATE_ALLOC(h->d_cols, sizeof(PyrColumn) * h->colsCap);
     CREATE_ALLOC(h->d_colLevels, sizeof(ColLevels));
-    h->pyrChain = !(getenv("ORBX_PYR_CHAIN") && atoi(getenv("ORBX_PYR_CHAIN")) == 0);
-    h->pyrChainWgs = getenv("ORBX_PYR_CHAIN_WGS") ? atoll(getenv("ORBX_PYR_CHAIN_WGS")) : 0;      // 0: 16 workgroups per CU
     h->footCap = roomy((size_t)((max_width + 38 + 255) / 256 + 1) * ((max_height + 38 + 31) / 32 + 1) * nlevels);
     CREATE_ALLOC(h->d_foot, sizeof(TileFoot) * h->footCap);
     h->outBytes = outLayout(max_batch, h->outCap, nlevels).all;
     CREATE_ALLOC(h->d_out, h->outBytes);
     h->testFailAfterFast = getenv("ORBX_TEST_FAIL_AFTER_FAST") && atoi(getenv("ORBX_TEST_FAIL_AFTER_FAST")) != 0;
-    h->blurAsync = getenv("ORBX_BLUR_ASYNC") ? atoi(getenv("ORBX_BLUR_ASYNC")) : -1;
     h->zeroCopy = !(getenv("ORBX_ZERO_COPY") && atoi(getenv("ORBX_ZERO_COPY")) == 0);
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
@@ -986,7 +903,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
     h->octRoomyForced = getenv("ORBX_OCT_ROOMY") != nullptr;
-    h->fuseBlur = getenv("ORBX_FUSE_BLUR") && atoi(getenv("ORBX_FUSE_BLUR")) != 0;
     if (const char* e = getenv("ORBX_LDS_POLLUTE")) h->ldsPollute = atoi(e) & 255;
     {
         int cus = 0;

@@ -114,39 +114,21 @@ constexpr int kResizeTileRows = ORBX_RESIZE_TILE_ROWS;   // destination rows per
 
 // Source footprint of one 256 x kResizeTileRows destination tile of the resize kernel (host-computed from the coefficient tables)
 // A resize tile's staged source rectangle: first column (a multiple of 4; negative = inside the level's border), dwords per row, first
-// row, rows — the tile's tap footprint, widened (levels >= 2) by the part of the SOURCE level this tile blurs: [bx0, bx1) x [by0, by1)
-// (bx multiples of 4; the tiles' blur rectangles partition the source level; empty when the tile blurs nothing) plus the blur's halo.
-struct TileFoot { short fx0, nDw, fy0, nRows, bx0, bx1, by0, by1; };
+// row, rows: the tile's tap footprint.
+struct TileFoot { short fx0, nDw, fy0, nRows; };
 
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
 
-// Small-batch pyramid (k_pyr_rest): one 64-byte x 16-row tile of the bordered level `level` (>= 2) is computed by ONE workgroup straight
-// from level 1, re-deriving in LDS the interior pixels of the levels in between that it depends on.  region[j] (1 <= j < level) is the
-// rectangle of level j's interior the tile needs: x0 (a multiple of 4 for j = 1), y0, width, height.
-constexpr int kChainTileDw = 16;     // dword columns per tile
-constexpr int kChainTileRows = 16;
-constexpr int kChainTile0Rows = 64;  // rows of a LEVEL-0 tile of the one-launch pyramid: a bordered copy needs no LDS staging, and 363 sixteen-row
-                                     // workgroups pushed the grid (1261) past the 1024 that fit the chip at once; 99 tall ones keep it in one round
-constexpr int kChainMaxW = 256, kChainMaxH = 64, kChainMaxH0 = 96, kChainCoefMax = 1280;   // (and coefficient records of all steps of one tile)   // largest region (any level) the kernel's staging holds
+// Largest rectangle (any level / the loaded one) and most coefficient records (all steps of one region) k_pyr_cols' LDS staging holds
+constexpr int kChainMaxW = 256, kChainMaxH0 = 96, kChainCoefMax = 1280;
 struct ChainRegion { short x0, y0, w, h; };
-// (everything the kernel needs of the level tables rides in the tile record itself, filled by installGeometry: one wave-uniform load, then
-// the region and coefficient loads can all be issued — a look-up in the level table first cost a third dependent memory round trip)
-struct ChainTile {
-    short level, tileX, tileY, pad;
-    ChainRegion region[kMaxLevels];
-    int w, h, pyrRows, pyrStride;                 // the tile's own level
-    long long pyrOff, pyrFrameBytes;
-    long long srcOff, srcFrameBytes;              // level 1 (the source of the chains that start there)
-    int srcStride, pad2;
-    int rxOff[kMaxLevels], ryOff[kMaxLevels];     // first coefficient record of level j in the handle's x / y tables
-};
 
 // Region-major pyramid (k_pyr_cols): the image is cut into RX x RY regions; ONE workgroup builds its region of EVERY level, level after level
 // in LDS (level l + 1 is resized from the rounded pixels of level l, as the reference's chain does), and writes the bordered bytes it owns of
 // each level as it goes.  region[l] = the rectangle of level l's interior the workgroup holds (what it owns of level l, the pixels its border
 // bytes mirror, and the taps of region[l + 1]; x0 a multiple of 4); own[l] = the dword columns x rows of the BORDERED level l it writes (the
-// own rectangles of the columns partition every level).  Against the tile chains (k_pyr_chain) nothing is derived twice except the regions'
-// overlap: 640x480, 48 regions: 0.7 M pixels derived per frame instead of 6.6 M, and the longest chain of steps handles 14 k pixels, not 31 k.
+// own rectangles of the columns partition every level).  Nothing is derived twice except the regions' overlap: 640x480, levels 1-7 = 0.64 M pixels,
+// the four cuts derive 1.40 / 1.10 / 0.86 / 0.81 M per frame (round 2's per-tile chains, removed in round 4, re-derived 6.6 M).
 // What a thread of the packed resize step needs of its four adjacent columns, worked out by the host per region and level (k_pyr_cols): the
 // aligned start and the byte shift of the 8-byte tap window inside the region's row, the v_perm selectors that cut each column's two taps out of
 // it, the weight pairs.  (Derived in the kernel from four ResizeX records it was ~45 of the ~100 vector instructions of a one-row step.)

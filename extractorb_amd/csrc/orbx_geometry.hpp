@@ -115,14 +115,6 @@ struct FrameGeom {
     int maxRoiW = 0, maxRoiH = 0;            // largest FAST ROI over all cells
     int maxNodes = 0;                        // largest quad-tree node count over all levels
     long long sumPixels = 0;                 // S of SURVEY.md §8d
-    std::vector<ChainTile> chain;            // tiles of levels 2.. for the small-batch pyramid kernel (k_pyr_rest)
-    bool chainFits = true;                   // every intermediate region within kChainMaxW x kChainMaxH
-    bool chainPacked = true;                 // the 8 taps of any four adjacent columns of a level >= 2 lie within 8 source bytes (k_pyr_rest<true>)
-    bool blurFused = false;                  // the resize tiles of levels >= 2 carry blur rectangles of their source levels
-    std::vector<ChainTile> chainAll;         // tiles of EVERY level for the one-launch pyramid (k_pyr_all: regions down to the caller's image)
-    bool chainAllFits = true, chainAllPacked = true;
-    int chainAllLdsBytes = 0, chainAllEvenBytes = 0;
-    int chainLdsBytes = 0, chainEvenBytes = 0;   // two ping-pong region buffers able to hold the largest regions (even-level buffer first)
     // region-major pyramid (k_pyr_cols): the image cut into RX x RY regions (row-major) of about px x px level-0 pixels, for several px:
     // a launch takes the coarsest cut that still gives the chip enough workgroups (few frames: small regions, short chains of small steps;
     // more frames: large regions, less overlap)
@@ -142,10 +134,9 @@ struct FrameGeom {
 constexpr int kColPx[] = {40, 56, 80, 112};
 
 // Returns an empty string on success, else the reason the geometry is unsupported.
-// fuseBlur: the resize tiles of levels >= 2 also carry the blur of their source level (wider staged rectangles, blur rectangles set)
 // colPx: side (level-0 pixels) of the regions of the region-major pyramid (0: the sizes of kColPx)
 // blurInLevels: the cuts of colSetsBlur carry the blur's halo for that many of the finest levels
-inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, bool fuseBlur = false, int colPx = 0, int blurInLevels = kMaxLevels) {
+inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, int colPx = 0, int blurInLevels = kMaxLevels) {
     g = FrameGeom();
     g.rows = rows; g.cols = cols; g.nlevels = t.nlevels;
     for (int l = 0; l < t.nlevels; l++) {
@@ -258,29 +249,11 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     }
                     fy0[ty] = sy0; fy1[ty] = sy1;
                 }
-                // levels >= 2: the resize of level l also blurs level l - 1 out of the tile it has staged.  The tiles' blur rectangles
-                // partition the source level along the footprints' first columns / rows (monotone; x boundaries multiples of 4).
-                const LevelGeom& S = g.lv[l - 1];
-                const bool fuse = fuseBlur && l >= 2;
-                g.blurFused = fuseBlur;
-                std::vector<int> X(g.tilesX[l] + 1, 0), Y(g.tilesY[l] + 1, 0);
-                for (int tx = 1; tx < g.tilesX[l]; tx++) X[tx] = std::min(std::max(X[tx - 1], fx0[tx] & ~3), S.w);
-                X[g.tilesX[l]] = S.w;
-                for (int ty = 1; ty < g.tilesY[l]; ty++) Y[ty] = std::min(std::max(Y[ty - 1], fy0[ty]), S.h);
-                Y[g.tilesY[l]] = S.h;
                 for (int ty = 0; ty < g.tilesY[l]; ty++)
                     for (int tx = 0; tx < g.tilesX[l]; tx++) {
                         TileFoot t{};
                         int x0 = fx0[tx] & ~3, x1 = fx1[tx] + 1, y0 = fy0[ty], y1 = fy1[ty] + 1;      // [x0, x1) x [y0, y1)
-                        if (fuse && X[tx + 1] > X[tx] && Y[ty + 1] > Y[ty]) {
-                            t.bx0 = (short)X[tx]; t.bx1 = (short)X[tx + 1]; t.by0 = (short)Y[ty]; t.by1 = (short)Y[ty + 1];
-                            // the blur reads pixels x-4 .. x+7 of every four-column group and rows y-3 .. y+3; row blocks of
-                            // kFusedBlurRows rows: the last block of the rectangle may run up to kFusedBlurRows - 1 rows past it
-                            x0 = std::min(x0, X[tx] - 4);
-                            x1 = std::max(x1, ((X[tx + 1] + 3) & ~3) + 4);
-                            y0 = std::min(y0, Y[ty] - 3);
-                            y1 = std::max(y1, Y[ty + 1] + 3);
-                        }
+                        const LevelGeom& S = g.lv[l - 1];
                         // the bordered source holds columns -19 .. w+18 (dword-aligned reads: -16 .. ((w+19) & ~3) - 1) and rows -19 .. h+18
                         x0 = std::max(x0, -16); x1 = std::min(x1, (S.w + kEdge) & ~3);
                         y0 = std::max(y0, -kEdge); y1 = std::min(y1, S.h + kEdge);
@@ -292,83 +265,6 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     }
             }
         }
-    }
-    // ---- small-batch pyramid: per 64-byte x 16-row tile of a level, the chain of source regions down to the level the kernel
-    //      loads: level 1 (k_pyr_rest after k_pyr_first: tiles of levels >= 2) or the caller's image (k_pyr_all: tiles of every
-    //      level; a level-0 tile is a bordered copy and has no regions) ----
-    {
-        auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
-        auto build = [&](int start, std::vector<ChainTile>& out, bool& fits, int& ldsBytes, int& evenBytes, int maxW, int maxH) {
-            int maxEven = 0, maxOdd = 0;     // bytes of the largest region kept in buffer (j & 1)
-            for (int l = t.nlevels - 1; l >= start; l--) {      // coarsest level first: its tiles have the longest chains and should start first
-                const LevelGeom& L = g.lv[l];
-                const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
-                const int tileRows = (l == 0) ? kChainTile0Rows : kChainTileRows;      // (level-0 tiles exist only in the from-image list)
-                const int tx = (nd + kChainTileDw - 1) / kChainTileDw, ty = (L.pyrRows + tileRows - 1) / tileRows;
-                if (l == start && start != 0) break;            // (the loaded level itself is written by k_pyr_first)
-                for (int iy = 0; iy < ty; iy++)
-                    for (int ix = 0; ix < tx; ix++) {
-                        ChainTile c{};
-                        c.level = (short)l; c.tileX = (short)ix; c.tileY = (short)iy;
-                        // interior hull of the tile's bordered bytes / rows (the kernel clamps and reflects exactly like this)
-                        int x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
-                        for (int b = ix * kChainTileDw * 4; b < (ix + 1) * kChainTileDw * 4; b++) {
-                            int bx = b - (kPadL - kEdge);
-                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
-                            const int v = refl(bx - kEdge, L.w);
-                            x0 = std::min(x0, v); x1 = std::max(x1, v);
-                        }
-                        for (int r = iy * tileRows; r < (iy + 1) * tileRows; r++) {
-                            const int br = r < L.pyrRows ? r : L.pyrRows - 1;
-                            const int v = refl(br - kEdge, L.h);
-                            y0 = std::min(y0, v); y1 = std::max(y1, v);
-                        }
-                        for (int j = l - 1; j >= start; j--) {       // region of level j that [x0,x1] x [y0,y1] of level j + 1 is resized from
-                            const std::vector<ResizeX>& X = g.rx[j + 1];
-                            const std::vector<ResizeX>& Y = g.ry[j + 1];
-                            int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
-                            for (int x = x0; x <= x1; x++) { sx0 = std::min(sx0, (int)std::min(X[x].sx0, X[x].sx1)); sx1 = std::max(sx1, (int)std::max(X[x].sx0, X[x].sx1)); }
-                            for (int y = y0; y <= y1; y++) { sy0 = std::min(sy0, (int)std::min(Y[y].sx0, Y[y].sx1)); sy1 = std::max(sy1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
-                            if (j == start) sx0 &= ~3;           // the first region is loaded from HBM in aligned dwords
-                            int w = sx1 - sx0 + 1;
-                            if (j == start) w = (w + 3) & ~3;    // (level 1: up to 3 px past the need, still inside the level's right border; the image: the kernel never reads past a row)
-                            c.region[j] = ChainRegion{(short)sx0, (short)sy0, (short)w, (short)(sy1 - sy0 + 1)};
-                            const int bytes = ((w + 3) & ~3) * (sy1 - sy0 + 1);
-                            if (j == start ? (bytes > maxW * maxH) : (w > kChainMaxW)) fits = false;      // (the loaded region: the staging's loads in flight; in between: one column quad per lane; the height only costs LDS, checked by the caller)
-                            if (j & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
-                            x0 = sx0; x1 = sx0 + w - 1 < g.lv[j].w ? sx0 + w - 1 : g.lv[j].w - 1; y0 = sy0; y1 = sy1;
-                            if (j == start) x1 = sx1;            // (the padding columns of the loaded region are never sources of a needed pixel)
-                        }
-                        int coefs = 4 * kChainTileDw + kChainTileRows;
-                        for (int j = start + 1; j < l; j++) coefs += c.region[j].w + c.region[j].h;
-                        if (coefs > kChainCoefMax) fits = false;
-                        out.push_back(c);
-                    }
-            }
-            evenBytes = (maxEven + 15) & ~15;
-            ldsBytes = evenBytes + ((maxOdd + 15) & ~15) + 32;
-        };
-        build(1, g.chain, g.chainFits, g.chainLdsBytes, g.chainEvenBytes, kChainMaxW, kChainMaxH);
-        build(0, g.chainAll, g.chainAllFits, g.chainAllLdsBytes, g.chainAllEvenBytes, kChainMaxW, kChainMaxH0);
-        // the packed horizontal pass of the in-between steps: region columns start anywhere, so every group of four adjacent
-        // columns is checked (the last step, the tile itself, goes byte by byte)
-        auto packedFrom = [&](int first) {
-            for (int l = first; l < t.nlevels - 1; l++) {
-                const std::vector<ResizeX>& X = g.rx[l];
-                const int w = g.lv[l].w;
-                for (int x = 0; x < w; x++) {
-                    int lo = 1 << 30, hi = -1;
-                    for (int k = 0; k < 4; k++) {
-                        const ResizeX& c = X[std::min(x + k, w - 1)];
-                        lo = std::min(lo, (int)std::min(c.sx0, c.sx1)); hi = std::max(hi, (int)std::max(c.sx0, c.sx1));
-                    }
-                    if (hi - lo > 7) return false;
-                }
-            }
-            return true;
-        };
-        g.chainPacked = packedFrom(2);
-        g.chainAllPacked = g.chainPacked && (t.nlevels < 3 || packedFrom(1));
     }
     // ---- region-major pyramid (k_pyr_cols, orbx_device.hpp: PyrColumn): RX x RY regions; per region and level the owned part of the bordered
     //      level (the regions' parts partition its dword columns and rows) and the interior rectangle held in LDS, coarsest level first:

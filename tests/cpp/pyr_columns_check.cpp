@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     ScaleTables t = makeScaleTables(1000, sf, nlevels);
     FrameGeom g;
     const int blurIn = argc > 5 ? atoi(argv[5]) : 5;
-    const std::string why = makeFrameGeom(t, rows, cols, g, false, 0, blurIn);
+    const std::string why = makeFrameGeom(t, rows, cols, g, 0, blurIn);
     if (!why.empty()) { printf("rejected: %s\n", why.c_str()); return 0; }
     layoutArenas(g, 1);
     // the image and the whole levels, resized level by level

@@ -154,7 +154,7 @@ print("OK")
 
 
 @pytest.mark.parametrize("shape,nf,B,form", [((480, 640), 1000, 1, 0), ((480, 640), 1000, 64, 0), ((720, 1280), 1500, 1, 0), ((1080, 1920), 2000, 1, 0),
-                                             ((1080, 1920), 2000, 24, 3)])
+                                             ((1080, 1920), 2000, 24, 1)])
 def test_reported_launch_forms(shape, nf, B, form):
     """the published single-frame and traffic figures assume the region-major pyramid; a sizing regression that quietly
     falls back to the tile forms must fail a test, not just change a timing."""

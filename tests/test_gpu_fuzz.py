@@ -22,9 +22,7 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            # the 128-VGPR quad-tree variants (short phase-2 passes) at every workgroup size; seed 103 draws sparse levels
            ({"ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 103), ({"ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            ({"ORBX_OCT_THREADS": "1024", "ORBX_OCT_ROOMY": "1"}, 8, 108),
-           # the pyramid of a single frame as two launches (k_pyr_first + chains from level 1) and as one launch per level
-           ({"ORBX_PYR_COLS": "0", "ORBX_PYR_ALL_WGS": "-1"}, 8, 109), ({"ORBX_PYR_COLS": "0", "ORBX_PYR_CHAIN": "0"}, 8, 110),
-           # ... as one launch tile by tile (the default before the region-major pyramid), and region by region with the coarser cuts
+           # the pyramid as one launch per level (the form of large batches of large frames), and region by region with the coarser cuts
            ({"ORBX_PYR_COLS": "0"}, 8, 117), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "56"}, 8, 118), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "112"}, 8, 119),
            ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_RESIZE_BYTEWISE": "1", "ORBX_LDS_POLLUTE": "201"}, 8, 120),
            # every device allocation of the handle filled with a byte pattern: nothing may depend on what hipMalloc returns
@@ -67,12 +65,12 @@ def test_seeded_batch_shape_sweep():
     assert done + skipped == 24 and done >= 20 and checked >= 2 * done
 
 
-@pytest.mark.parametrize("env", [{"ORBX_SPLIT_MIN_MPX": "0"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "2"},
+@pytest.mark.parametrize("env", [{"ORBX_SPLIT_MIN_MPX": "0"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3"},
                                  {"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1", "ORBX_SPLIT_MIN_MPX": "0"}],
-                         ids=["blur-aside", "staggered-tails", "halves", "blur-in-regions"])
+                         ids=["blur-aside", "staggered-tails", "blur-in-regions"])
 def test_seeded_batch_shape_sweep_under_the_overlap_policies(env, monkeypatch):
     """The same sweep with every batch counted as large (ORBX_SPLIT_MIN_MPX=0), so that the overlap forms of large batches - the blur on its side
-    stream (the default), staggered tails, round 2's halves - and the blurring pyramid meet every batch shape, not only the benchmark's."""
+    stream (the default), staggered tails - and the blurring pyramid meet every batch shape, not only the benchmark's."""
     import fuzz_batches
     for k, v in env.items():
         monkeypatch.setenv(k, v)

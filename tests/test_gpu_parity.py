@@ -264,7 +264,7 @@ def test_device_path_with_padded_rows_and_frames():
         assert d_lc[f].cpu().numpy().tolist() == [len(o.level_keypoints(l)) for l in range(8)]
 
 
-@pytest.mark.parametrize("form", ["default", "ORBX_PYR_COLS=0", "ORBX_PYR_COLS=0,ORBX_PYR_ALL_WGS=-1", "ORBX_PYR_COLS=1,ORBX_PYR_COL_PX=112"])
+@pytest.mark.parametrize("form", ["default", "ORBX_PYR_COLS=0", "ORBX_PYR_COLS=1,ORBX_PYR_COL_PX=112", "ORBX_PYR_COLS=1,ORBX_BLUR_IN_COLS=1"])
 @pytest.mark.parametrize("B,offset,stride", [(1, 1, 643), (2, 3, 641), (3, 2, 650), (1, 0, 640)])
 def test_device_path_with_unaligned_pointer_and_stride(B, offset, stride, form, monkeypatch):
     """cv::Mat ROIs handed over on the device: a base pointer and a row step that are not multiples of 4 (every pyramid form stages
@@ -350,14 +350,13 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
-                                          ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1"),
-                                          ("ORBX_PYR_COLS,ORBX_PYR_ALL_WGS", "0,-1"), ("ORBX_PYR_COLS,ORBX_PYR_CHAIN", "0,0")] +
+                                          ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1")] +
                                          [("ORBX_PYR_COLS_VARIANT", str(v)) for v in range(7)] +     # every workgroup shape of k_pyr_cols
                                          [("ORBX_FAST_WIDE", "0"), ("ORBX_FAST_WIDE,ORBX_FAST_PREFILTER", "1,0")])      # FAST: a wave / a workgroup per cell
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
-    # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid of
-    # a small batch is one launch region by region (round 3), one launch tile by tile (from the image), two (level 0/1, then chains from
-    # level 1) or one per level; the host picks by batch size / image area / tap geometry, and every choice must give the reference result
+    # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid is one
+    # launch region by region (k_pyr_cols) or one launch per level; the host picks by batch size / image area / tap geometry, and every
+    # choice must give the reference result
     for sw, v in zip(switch.split(","), value.split(",")):
         monkeypatch.setenv(sw, v)
     for shape, nf, variant in (((480, 640), 1000, "noise"), ((333, 517), 700, "textured"), ((480, 640), 1200, "natural")):
@@ -380,20 +379,18 @@ def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     assert_same_result((mono, k, d), want, "%s=%s clustered" % (switch, value))
 
 
-@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True), (300, "halves"), (257, "halves"),
-                                     (-300, "halves"), (300, "stagger"), (257, "stagger"), (-301, "stagger")])
+@pytest.mark.parametrize("B,split", [(72, False), (136, False), (300, False), (300, True), (257, True), (-136, False), (-300, True), (300, "stagger"), (257, "stagger"),
+                                     (-301, "stagger")])
 def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B, split, monkeypatch):
     # 8 levels x B workgroups: all resident with 1024 threads up to B = 64, with 512 up to 128, 256 threads above;
-    # a large batch overlaps inside the call: its blur on a side stream beside FAST and the quad-tree (the default, round 4), or as two
-    # halves on two streams (ORBX_SPLIT=2, round 2's form; odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small frames count as
-    # large, ORBX_SPLIT=0 turns every overlap off
+    # a large batch overlaps inside the call: its blur on a side stream beside FAST and the quad-tree (the default, round 4), the largest
+    # also with staggered tails (ORBX_SPLIT=3: for every large batch; odd B: unequal halves); ORBX_SPLIT_MIN_MPX=0 makes these small frames
+    # count as large, ORBX_SPLIT=0 turns every overlap off
     if B < 0:      # (negative: the pyramid as one launch per level, the form of large batches of large frames, instead of the region-major one)
         monkeypatch.setenv("ORBX_PYR_COLS", "0")
         B = -B
     if split:
         monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
-        if split == "halves":
-            monkeypatch.setenv("ORBX_SPLIT", "2")
         if split == "stagger":      # FAST in two halves back to back, the first half's quad-tree + description on the internal stream under the second half's FAST
             monkeypatch.setenv("ORBX_SPLIT", "3")
     else:
@@ -413,28 +410,6 @@ def test_large_batches_pick_other_quadtree_sizes_and_agree_with_single_frames(B,
     out2 = ex.extract_batch(fr2)
     assert_same_result(out2[0][:3], want, "second call, frame 0 = the first call's last")
     assert_same_result(out2[B - 1][:3], out[0][:3], "second call, last frame = the first call's frame 0")
-
-
-@pytest.mark.parametrize("B,shape,split", [(72, (240, 320), False), (40, (480, 640), False), (300, (240, 320), True), (24, (333, 517), False)])
-def test_blur_inside_the_resize_launches(B, shape, split, monkeypatch):
-    """ORBX_FUSE_BLUR=1: in large batches the resize of level l also blurs level l - 1 out of the tile it has staged (k_blur is left with
-    level 0 and the last level): every blurred level and the final arrays against the oracle."""
-    monkeypatch.setenv("ORBX_FUSE_BLUR", "1")
-    monkeypatch.setenv("ORBX_SPLIT_MIN_MPX" if split else "ORBX_SPLIT", "0")
-    fr = synth.frames("textured", 41, B, *shape)
-    ex = X.ORBextractor(700, max_width=shape[1], max_height=shape[0], max_batch=B)
-    out = ex.extract_batch(fr)
-    prof_before = None
-    for f in (0, B // 2, B - 1):
-        o, want = oracle_run(fr[f], 700)
-        assert_same_result(out[f][:3], want, "frame %d of %d" % (f, B))
-        for l in range(8):
-            assert np.array_equal(ex.debug_blurred(l, f), o.blurred(l)), "blur level %d of frame %d" % (l, f)
-    ex.profile(True)
-    ex.extract_batch(fr)
-    p = ex.profile_read()
-    ex.profile(False)
-    assert p["k_resize"][1] == 6 and p["k_blur"][1] == 1      # the fused form really ran: six resize launches, one (short) blur launch
 
 
 @pytest.mark.parametrize("shape,nf", [((480, 640), 10000), ((376, 1241), 10000), ((480, 640), 25000), ((480, 752), 6000)])
@@ -529,7 +504,7 @@ def test_region_major_pyramid_with_the_blur_inside(px, nb, monkeypatch):
         o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
         ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
         mono, k, d, lvl = ex(img, None, (0, 0))
-        took += ex.last_forms()[2] == 3
+        took += ex.last_forms()[2] == 2
         for l in range(nlevels):
             if not len(o.level_keypoints(l)):      # (the reference - and the oracle - only blur levels that hold keypoints, :1122-1127)
                 continue
