@@ -8,6 +8,9 @@
 // neither vendored in the reference nor installed in this image, and the reference ships no tests or golden vectors
 // (SURVEY.md §4, §8c).  It holds one recorded result: img_folder/Screenshot.png, "ORB_SLAM3 has total 1420 keypoints", printed by
 // src/orb_extractor/main_orb_extractor.cpp:34-53 (nFeatures 1500) on pic/TUM/dataset-room4_512_16/.../1520531124150444163.png.
+// (An assumption rides on that: today's main constructs ORBextractor(5 * nFeatures) = 7500 features (:43), which gives 1547 on that frame, not
+// 1420; the screenshot is taken to predate that line - with 1500 features the count is exact AND the 1420 positions sit on the circles the
+// screenshot's image window shows.  tests/test_reference_pin.py asserts both readings.)
 // This file returns exactly 1420 there (tests/test_reference_pin.py); `enum Mutation` below measures which restated semantics
 // that count decides (resize rounding, level chain and sizes, FAST strictness, per-cell strict NMS, threshold retry, 30-px grid,
 // the ">= N" stop rule) and which it does not.  PARITY UNPINNED for: keypoint order, GaussianBlur taps, fastAtan2, cosf/sinf, the

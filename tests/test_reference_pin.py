@@ -2,7 +2,15 @@
 
 /root/reference/img_folder/Screenshot.png is a capture of the author's IDE after running the demo main
 (src/orb_extractor/main_orb_extractor.cpp:34-53: nFeatures = 1500, scale 1.2, 8 levels, FAST 20/7; ComputePyramid +
-ComputeKeyPointsOctTree; the sum of the per-level vector sizes is printed).  Its console pane reads
+ComputeKeyPointsOctTree; the sum of the per-level vector sizes is printed).
+
+ASSUMPTION, stated because the file has moved on since the capture: TODAY's main_orb_extractor.cpp:43 constructs `ORBextractor(5 * nFeatures,
+...)` = 7500 features and reads another picture (../pic/robot/866_im.jpg, :16).  With 7500 features the oracle gives 1547 on the screenshot's
+frame, not 1420 (test_todays_demo_constructor_gives_1547 below); with the 1500 of the yaml block it gives exactly 1420 AND its 1420 positions sit
+on the 1420 circles the screenshot's image window shows (test_oracle_keypoints_sit_where_the_reference_drew_them).  So the screenshot is taken to
+come from an EARLIER build of the demo that passed nFeatures itself; count and picture together are what supports that reading.
+
+Its console pane reads
 
     The ../pic/TUM/dataset-room4_512_16/ma...     (image path, cut off by the pane)
     ORB_SLAM3 has total 1420 keypoints
@@ -53,6 +61,15 @@ def test_oracle_reproduces_the_reference_screenshot_count():
     # FAST candidate (127, 63, 61 < quota): the sum tests both regimes
     o = O.Oracle(*REFERENCE_PARAMS)
     assert counts[:5] == o.features_per_level[:5].tolist() and all(c < q for c, q in zip(counts[5:], o.features_per_level[5:]))
+
+
+def test_todays_demo_constructor_gives_1547():
+    """main_orb_extractor.cpp:43 as it stands today: ORBextractor(5 * nFeatures = 7500, ...).  On the screenshot's frame every FAST candidate
+    survives the quad-tree on every level: 1547 keypoints - NOT the screenshot's 1420, which is why the pin assumes the earlier 1500-feature build."""
+    o = O.Oracle(7500, 1.2, 8, 20, 7)
+    o.extract(load_gray("tum_room4_gray.png"), (0, 1000))
+    counts = [len(o.level_keypoints(l)) for l in range(8)]
+    assert sum(counts) == 1547 and all(c < q for c, q in zip(counts, o.features_per_level)), counts
 
 
 def test_golden_file_of_the_pinned_frame_sums_to_the_reference_count():
