@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "orbx_device.hpp"
+#include "k_blur_body.hpp"      // blurRun: the patch-blur form blurs a keypoint's 37 x 37 patch out of its raw 43 x 43 tile
 
 namespace orbx {
 // ================================================================================================
@@ -81,6 +82,13 @@ constexpr int kRawStride = 36;                        // 3 + 31 bytes -> 9 dword
 constexpr int kBlurRows = 2 * kBriefReach + 1;        // 37
 constexpr int kBlurStride = 40;                       // 3 + 37 bytes -> 10 dwords
 constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per keypoint (dword multiple)
+// Patch-blur form (PB): ONE raw tile of 43 rows (v = -21 .. 21) x 44 bytes (byte t <-> u = t - 22: one spare column in front, so that the blur's
+// aligned dword triples x0 - 4 .. x0 + 7 of output group g start at dword g), re-aligned to the patch when it is staged; the 37 x 37 blurred
+// patch the descriptor reads is computed from it into the blurred tile (same layout as above, no misalignment).
+constexpr int kPbRows = 2 * (kBriefReach + 3) + 1;    // 43
+constexpr int kPbStride = 44;                         // 11 dwords
+constexpr int kPbRawBytes = (kPbRows * kPbStride + 15) & ~15;               // 1904
+constexpr int kPbLds = kPbRawBytes + kBlurRows * kBlurStride;               // 3384 bytes per keypoint
 
 // One half-wave (32 lanes) per kept keypoint; the two keypoints of a wave share a level (selOff is even):
 //   * both patches are staged in LDS with aligned dword loads that are all in flight at once: a half-wave covers
@@ -98,6 +106,12 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out) { return (int)hip
 #else
 #define DSTAMP(i) do {} while (0)
 #endif
+// PB (patch blur, large frames with few features per pixel: orbx_api.cpp): the blurred LEVELS are never made - a half-wave stages the raw
+// 43 x 43 patch around its keypoint (the bordered pyramid's REFLECT_101 frame is the reflection of the level itself, which is what the
+// reference's border-less clone blurs against: ORBextractor.cc:1126-1127), blurs the 37 x 37 patch the rotated pattern can reach with the same
+// integer arithmetic (blurRun) and describes from that.  1920x1080 x 2000 features: 2000 x 43 x 37 = 3.2 M pixels of horizontal pass against
+// 6.4 M for the whole pyramid, no 6.4-MB write + 5.5-MB sparse re-read of blurred levels per frame.
+template <bool PB>
 __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels,
                                                    const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                    const uint2* __restrict__ sel, int selPerFrame,
@@ -105,14 +119,25 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                    Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
                                                    int* __restrict__ nOut, int* __restrict__ monoOut,
                                                    Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts, int f0, int nFrames) {
-    __shared__ __align__(16) uint8_t smem[2 * kDescWaves * kPatchLds];
-    __shared__ __align__(16) unsigned wtab[2][16][8];   // [m10 weights | disc mask][|v|][dword of the aligned row]
+    __shared__ __align__(16) uint8_t smem[2 * kDescWaves * (PB ? kPbLds : kPatchLds)];
+    __shared__ __align__(16) unsigned wtab[2][16][PB ? 12 : 8];   // [m10 weights | disc mask][|v|][dword of the aligned row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
     int chunk, fr;
     if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all keypoints of a frame on one XCD: overlapping patches share its L2
     const int f = f0 + fr;
     DSTAMP(0);
-    {   // weight words of row |v| = a, bytes k = 0..31 <-> u = k - 15
+    if constexpr (PB) {   // weight words of row |v| = a over the re-aligned tile row: byte t = 4 j + b <-> u = t - 22
+        for (int e = tid; e < 2 * 16 * 12; e += 256) {
+            const int which = e / 192, a = (e / 12) & 15, j = e % 12;
+            unsigned w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int u = 4 * j + b - (kBriefReach + 4), au = u < 0 ? -u : u;
+                if (au <= kHalfPatch && au <= c_umax[a]) w |= (unsigned)(which ? 1 : u + 16) << (8 * b);
+            }
+            wtab[which][a][j] = w;
+        }
+    } else {   // weight words of row |v| = a, bytes k = 0..31 <-> u = k - 15
         const int which = tid >> 7, a = (tid >> 3) & 15, j = tid & 7;
         unsigned w = 0;
 #pragma unroll
@@ -155,11 +180,72 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     ky = min(max(ky, kEdge), gh - kEdge - 1);
 
     DSTAMP(2);
+    int m10 = 0, m01 = 0;
+    uint8_t* blurT;
+    int blurMis;
+    if constexpr (PB) {
+        // ---- stage the raw 43 x 44 tile, re-aligned: 16 lanes per tile row (12 load a source dword, 11 store a re-aligned one), two rows per step ----
+        uint8_t* rawT = smem + (wave * 2 + half) * kPbLds;
+        blurT = rawT + kPbRawBytes;
+        blurMis = 0;
+        constexpr int kSteps = (kPbRows + 1) / 2;            // 22
+        const int l16 = hl & 15, rsub = hl >> 4;
+        const int col0 = kPadL + kx - (kBriefReach + 4), mis = col0 & 3;
+        const int rOff = __mul24(kEdge + ky - (kBriefReach + 3) + rsub, pyrStride) + (col0 - mis) + 4 * l16;
+        unsigned wr[kSteps];
+#pragma unroll
+        for (int s = 0; s < kSteps; s++)
+            wr[s] = (l16 < 12 && rsub + 2 * s < kPbRows) ? *(const unsigned*)(pyrL + ((unsigned)rOff + (unsigned)(2 * s * pyrStride))) : 0u;
+        uint8_t* rdst = rawT + rsub * kPbStride + 4 * l16;
+#pragma unroll
+        for (int s = 0; s < kSteps; s++) {
+            const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wr[s], 0x101, 0xF, 0xF, false);      // row_shl:1: the next dword of the same tile row
+            const unsigned v = __builtin_amdgcn_alignbyte(nxt, wr[s], (unsigned)mis);
+            if (l16 < 11 && rsub + 2 * s < kPbRows) *(unsigned*)(rdst + 2 * s * kPbStride) = v;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        DSTAMP(3);
+        // ---- IC_Angle (:75-102): lane = patch row v = hl - 15 = tile row hl + 6; the weight words know the layout (u = t - 22) ----
+        if (hl < kRawRows) {
+            const int v = hl - kHalfPatch, a = v < 0 ? -v : v;
+            const unsigned* row = (const unsigned*)(rawT + (hl + 6) * kPbStride);
+            unsigned s1 = 0, s0 = 0;
+#pragma unroll
+            for (int j = 1; j <= 9; j++) {          // bytes 7 .. 37 lie in dwords 1 .. 9
+                const unsigned px = row[j];
+                s1 = __builtin_amdgcn_udot4(px, wtab[0][a][j], s1, false);
+                s0 = __builtin_amdgcn_udot4(px, wtab[1][a][j], s0, false);
+            }
+            m10 = (int)s1 - 16 * (int)s0;     // sum u*I
+            m01 = v * (int)s0;                // v * sum I
+        }
+        // ---- the 7x7 blur of the 37 x 37 patch (:1126-1127): lane = (run of rows, column group); outputs o = 13 r .. read tile rows o .. o + 6 ----
+        if (hl < 30) {
+            const int r = (hl * 205) >> 11, g4 = hl - 10 * r;      // hl / 10 for hl < 32
+            const int o0 = 13 * r, nOut = r == 2 ? kBlurRows - 26 : 13;
+            const uint8_t* src = rawT + o0 * kPbStride + 4 * g4;
+            uint8_t* dst = blurT + o0 * kBlurStride + 4 * g4;
+            blurRun(nOut,
+                    [&](int i, unsigned& d0, unsigned& d1, unsigned& d2) {
+                        const unsigned* row = (const unsigned*)(src + min(i, nOut + 5) * kPbStride);
+                        d0 = row[0]; d1 = row[1]; d2 = row[2];
+                    },
+                    [&](int rr, unsigned word) { *(unsigned*)(dst + rr * kBlurStride) = word; });
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    } else {
     // ---- stage both patches: raw level rows/cols +-15 (IC_Angle), blurred level rows/cols +-18 (rBRIEF) ----
     uint8_t* rawT = smem + (wave * 2 + half) * kPatchLds;
-    uint8_t* blurT = rawT + kRawRows * kRawStride;
+    blurT = rawT + kRawRows * kRawStride;
     const int rawCol0 = kPadL + kx - kHalfPatch, rawMis = rawCol0 & 3;
-    const int blurCol0 = kx - kBriefReach, blurMis = blurCol0 & 3;
+    const int blurCol0 = kx - kBriefReach;
+    blurMis = blurCol0 & 3;
     {
         constexpr int kRawDw = kRawStride / 4, kBlurDw = kBlurStride / 4;            // 9, 10 dwords per tile row
         constexpr int kRawSteps = (kRawRows + 2) / 3, kBlurSteps = (kBlurRows + 2) / 3;   // 11, 13
@@ -194,7 +280,6 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
 
     DSTAMP(3);
     // ---- IC_Angle (:75-102): integer moments over the radius-15 disc of the unblurred level ----
-    int m10 = 0, m01 = 0;
     if (hl < kRawRows) {
         const int v = hl - kHalfPatch, a = v < 0 ? -v : v;
         const unsigned* row = (const unsigned*)(rawT + hl * kRawStride);
@@ -211,6 +296,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
         }
         m10 = (int)s1 - 16 * (int)s0;     // sum u*I
         m01 = v * (int)s0;                // v * sum I
+    }
     }
     // reduce inside the half-wave: four DPP steps cover a row of 16 lanes, one cross-lane exchange joins the two rows
     auto rowSum = [](int v) {
@@ -277,11 +363,16 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
 void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint8_t* pyr, const uint8_t* blur,
                     const uint2* sel, int selPerFrame, const int* levelCount, const int* levelLap, Keypoint* outK,
                     uint8_t* outD, int capacity, int* nOut, int* monoOut, Keypoint* outLevelK, int* outLevelCounts,
-                    int f0, int B) {
+                    bool patchBlur, int f0, int B) {
     const int perBlock = 2 * kDescWaves;
-    hipLaunchKernelGGL(k_describe, xcdGrid((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
-                       pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
-                       outLevelCounts, f0, B);
+    if (patchBlur)
+        hipLaunchKernelGGL(k_describe<true>, xcdGrid((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
+                           pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
+                           outLevelCounts, f0, B);
+    else
+        hipLaunchKernelGGL(k_describe<false>, xcdGrid((selPerFrame + perBlock - 1) / perBlock, B), dim3(256), 0, st, lv, nlevels,
+                           pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
+                           outLevelCounts, f0, B);
 }
 static const int8_t kHostPattern[1024] = {
 #include "orbx_brief_pattern.inc"

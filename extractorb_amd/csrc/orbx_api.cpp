@@ -35,7 +35,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
                   unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*, LeafTables);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
-                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, int, int);
+                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, bool, int, int);
 hipError_t uploadUmax(const int* umax16);
 hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
 struct StereoParams {
@@ -139,6 +139,7 @@ struct orbx_handle {
     int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
     int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
     int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
+    int patchBlur = -1;                 // ORBX_PATCH_BLUR: 1 = k_describe blurs each keypoint's patch itself (no blurred levels), 0 = never, default: by features per pixel (enqueueBatch)
     int blurInCols = 0;                 // ORBX_BLUR_IN_COLS=1: the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken (opt-in: slower)
     int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
     TileFoot* d_foot = nullptr;
@@ -461,6 +462,13 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
     auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
+    // Patch blur (k_describe<PB>): no blurred levels at all - every keypoint's 37 x 37 patch is blurred out of its raw 43 x 43 tile.  It pays where
+    // the keypoints' patches are not a much larger job than the whole pyramid (nfeatures x 43 x 37 pixels of horizontal pass against the pyramid's
+    // pixels) and the blur would be a launch of its own (not the small-batch form that rides in the FAST launch) - k_describe is bound by its sparse
+    // patch reads at large frames, and the one raw tile is fewer bytes than a raw + a blurred one.  Measured (us per step, k_blur beside FAST ->
+    // patch blur): 128 x 1920x1080 x 2000 (ratio 0.50) 3041-3052 -> 2717-2723; 128 x 1280x720 x 1500 (0.84) 1448-1455 -> 1358-1364; 512 x 640x480 x
+    // 1000 (1.67) 1929-1937 -> 1993-2000: taken up to a ratio of 1.25.  ORBX_PATCH_BLUR=1 / 0 forces / forbids it.
+    const bool patchBlur = h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (long long)h->nfeatures * 43 * 37 * 4 <= 5LL * g.sumPixels);
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     // Overlap inside one call (round 4): the blurred levels are read by k_description only, the LAST launch, so the blur of a large batch runs on
     // a side stream beside FAST and the quad-tree: pyramid -> {blur | FAST -> quad-tree} -> description.  k_blur is the one HBM-bound kernel of the
@@ -494,7 +502,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             cs = pickCut(g.colSets);
             // ORBX_BLUR_IN_COLS=1: the regions also blur what they own of the finest levels before they move on (bit-exact; slower than k_blur
             // beside FAST: DESIGN.md §4)
-            if (cs && h->blurInCols > 0) {
+            if (cs && h->blurInCols > 0 && !patchBlur) {
                 const FrameGeom::ColumnSet* cb = pickCut(g.colSetsBlur);
                 if (cb && cb->px == cs->px) cs = cb;
             }
@@ -532,9 +540,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
-        h->lastBlurForm = blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0);
-        h->blurOwed = !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
-        if (blurInside) {
+        h->lastBlurForm = patchBlur ? 3 : (blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0));
+        h->blurOwed = !patchBlur && !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
+        if (patchBlur) {
+            // (k_describe blurs per keypoint: no blurred level is written)
+        } else if (blurInside) {
             if (h->nBlurLanes[2] > 0) {      // the coarse levels the regions do not blur
                 Prof p(h, S_BLUR, st);
                 pollute(st);
@@ -620,7 +630,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             Prof p(h, S_DESCRIBE, st);
             pollute(st);
             launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
-                           h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, f0, Bn);
+                           h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, patchBlur, f0, Bn);
         }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) { backFast(st, f0, Bn); backTail(st, f0, Bn); };
@@ -875,6 +885,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->fastWide = getenv("ORBX_FAST_WIDE") ? atoi(getenv("ORBX_FAST_WIDE")) : -1;
     h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
     h->blurInCols = getenv("ORBX_BLUR_IN_COLS") ? atoi(getenv("ORBX_BLUR_IN_COLS")) : 0;
+    h->patchBlur = getenv("ORBX_PATCH_BLUR") ? atoi(getenv("ORBX_PATCH_BLUR")) : -1;
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += 2 * (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);      // (every cut with and without the blur's halo)
     h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)

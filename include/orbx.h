@@ -368,7 +368,8 @@ int orbx_debug_search_rounds(int* out4);
 
 /* Which launch forms the last call took (results never depend on them; the parity tests assert the form they mean to cover and the
  * published timings name theirs): pyramid_form 0 = k_pyr_cols (region-major, *pyramid_cut_px = side of its regions), 1 = k_pyr_first +
- * one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the FAST launch, 2 = inside k_pyr_cols (k_blur keeps the coarse levels). */
+ * one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the FAST launch, 2 = inside k_pyr_cols (k_blur keeps the coarse levels), 3 = per
+ * keypoint inside k_describe (no blurred level exists: orbx_debug_get_blurred has nothing to show). */
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
 
 /* ORBX_HOST_TIMING=1 in the environment: wall seconds of the one-frame host call (orbx_extract_view) accumulated per phase since the last read:

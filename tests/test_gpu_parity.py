@@ -34,7 +34,7 @@ def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
             fail("pyramid level %d" % l)
         if not np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)):
             fail("border %d" % l)
-        if len(o.level_keypoints(l)):      # the reference only blurs levels that hold keypoints (:1122-1127)
+        if len(o.level_keypoints(l)) and ex.last_forms()[2] != 3:      # the reference only blurs levels that hold keypoints (:1122-1127); form 3 blurs per keypoint: no blurred level exists
             if not np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)):
                 fail("blur level %d" % l)
         # k_fast's per-cell segments, read segment by segment, ARE vToDistributeKeys in the reference's order (cell row,
@@ -523,6 +523,38 @@ def test_region_major_pyramid_with_the_blur_inside(px, nb, monkeypatch):
             assert_same_result(out[f][:3], want, "px %d nb %d shape %s batch frame %d" % (px, nb, shape_variant, f))
             for l in range(8):
                 assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "shape %s frame %d blurred level %d" % (shape_variant, f, l)
+
+
+@pytest.mark.parametrize("pyr_cols", ["1", "0"])
+def test_patch_blur_inside_the_description(pyr_cols, monkeypatch):
+    """k_describe<PB> (the default of large batches of large frames; forced here for every size): no blurred level is made, every keypoint's
+    37 x 37 patch is blurred out of its raw 43 x 43 tile of the bordered pyramid.  Final arrays and per-level keypoints against the oracle:
+    keypoints on the FAST rectangle's rim (their patches reach 2 px into the REFLECT_101 frame), odd shapes, many and few levels, batches."""
+    monkeypatch.setenv("ORBX_PATCH_BLUR", "1")
+    monkeypatch.setenv("ORBX_PYR_COLS", pyr_cols)
+    rim = 0
+    for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "natural", {}),
+                                   ((480, 640), 900, "natural", dict(nlevels=12, sf=1.1)), ((241, 322), 300, "sparse", dict(nlevels=2, sf=1.2)),
+                                   ((482, 643), 1500, "noise", {})):
+        nlevels, sf = kw.get("nlevels", 8), kw.get("sf", 1.2)
+        img = synth.frames(variant, 57, 1, *shape)[0]
+        o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
+        ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
+        mono, k, d, lvl = ex(img, None, (0, 0))
+        assert ex.last_forms()[2] == 3
+        check_stages(ex, o, lvl, nlevels)
+        assert_same_result((mono, k, d), want, "patch blur %s %s" % (shape, kw))
+        for l in range(nlevels):      # keypoints within 20 px of a level's edge: their raw tiles reach into the bordered frame (REFLECT_101)
+            w_l, h_l = o.level_size(l)
+            if len(lvl[l]):
+                rim += int(((lvl[l]["x"] <= 20) | (lvl[l]["y"] <= 20) | (lvl[l]["x"] >= w_l - 21) | (lvl[l]["y"] >= h_l - 21)).sum())
+    assert rim >= 20, rim
+    frames = synth.frames("noise", 58, 9, 480, 640)
+    ex = X.ORBextractor(1200, max_batch=9)
+    out = ex.extract_batch(frames, lapping=(0, 0))
+    for f in (0, 4, 8):
+        o, want = oracle_run(frames[f], 1200, (0, 0))
+        assert_same_result(out[f][:3], want, "patch blur batch frame %d" % f)
 
 
 def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):

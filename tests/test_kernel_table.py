@@ -22,7 +22,7 @@ def current():
 
 def test_the_library_holds_the_kernels_of_the_hot_path(current):
     names = set(current)
-    for k in ("k_octree_256", "k_octree_512", "k_octree_1024", "k_octree_256r", "k_octree_512r", "k_octree_1024r", "k_octree_1024g", "k_describe"):
+    for k in ("k_octree_256", "k_octree_512", "k_octree_1024", "k_octree_256r", "k_octree_512r", "k_octree_1024r", "k_octree_1024g", "k_describe<0>", "k_describe<1>"):
         assert k in names, k
     for prefix in ("k_fast<", "k_fast_wide<", "k_pyr_cols<", "k_blur<", "k_resize<", "k_pyr_first<"):
         assert any(n.startswith(prefix) for n in names), prefix
