@@ -41,3 +41,24 @@ def test_cpp_example_matches_oracle(tmp_path):
     for b in d.reshape(-1).tolist():
         s = (s * 1099511628211 + b) & 0xFFFFFFFFFFFFFFFF
     assert s == fnv
+
+
+def _build_latency(tmp_path):
+    exe = str(tmp_path / "orbx_frame_latency")
+    libdir = os.path.dirname(X.library_path())
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "orbx_frame_latency.cpp"),
+                           "-o", exe, "-L" + libdir, "-lorbx", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_frame_latency_example_builds(tmp_path):
+    assert os.path.exists(_build_latency(tmp_path))
+
+
+@pytest.mark.gpu
+def test_frame_latency_example_runs(tmp_path):
+    """examples/orbx_frame_latency.cpp: the drop-in class called frame by frame with pageable images from C++ (the figure DESIGN.md §5 quotes)."""
+    out = subprocess.check_output([_build_latency(tmp_path), "480", "640", "1000", "100"], text=True)
+    m = re.search(r"frame_call_us_median=([\d.]+).*keypoints=(\d+)", out)
+    assert m and 10 < float(m.group(1)) < 2000 and int(m.group(2)) > 900, out
+    (open(os.path.join(ROOT, "gpurun_out", "frame_latency.txt"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else open(os.devnull, "w")).write(out)
