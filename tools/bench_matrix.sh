@@ -28,6 +28,9 @@ run --steps 100 --batch 64
 run --steps 50 --batch 256
 echo "# ORBX_SPLIT=0 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_SPLIT=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_FUSE_SMALL=0 --steps 300 --batch 1" >> gpurun_out/matrix.jsonl; ORBX_FUSE_SMALL=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 300 --batch 1 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd1080" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd1080 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd720" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd720 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_SPLIT=3 --steps 30 --batch 256" >> gpurun_out/matrix.jsonl; ORBX_SPLIT=3 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --batch 256 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 run --steps 30 --handles 2
 timeout -k 10 300 python tools/host_path_rate.py > gpurun_out/host_path.txt 2>&1
 echo done
