@@ -1107,7 +1107,7 @@ int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, pt
     if (rc != ORBX_OK) return rc;
     h->pendingB = 0;
     const double t1 = g_hostTiming ? nowSec() : 0;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // (polling hipStreamQuery instead returns no sooner: 71.7-71.9 against 68.3-72.9 us per call)
     if (g_hostTiming) { const double t2 = nowSec(); g_hostT[0] += t1 - t0; g_hostT[1] += t2 - t1; g_hostN++; }
     const int n = h->host.n[0];
     if (n < 0 || n > h->outCap) return fail(h, ORBX_ERR_CAPACITY, "keypoint count exceeds the handle's capacity (internal bound violated)");
