@@ -132,6 +132,11 @@ struct FrameGeom {
     bool colsPacked = false;
 };
 constexpr int kColPx[] = {40, 56, 80, 112};
+#ifndef ORBX_COL_EDGE_NUM
+#define ORBX_COL_EDGE_NUM 3
+#define ORBX_COL_EDGE_DEN 5
+#endif
+constexpr int kColEdgeNum = ORBX_COL_EDGE_NUM, kColEdgeDen = ORBX_COL_EDGE_DEN;      // an outer region's share of the interior, as a fraction of an inner one's (fine cuts only)
 
 // Returns an empty string on success, else the reason the geometry is unsupported.
 // colPx: side (level-0 pixels) of the regions of the region-major pyramid (0: the sizes of kColPx)
@@ -280,12 +285,13 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         // mirrored by index when they are read.
         // The halo compounds down the chain (level l's rectangle must hold the taps of level l + 1's, halo included: ~ x1.2 per level), so it is
         // carried for the finest `nblur` levels only - most of the pixels, little of the compounding; k_blur keeps the coarse ones.
-        auto buildCols = [&](const int px, const int nblur) {
+        auto buildCols = [&](const int px, const int nblur, const bool evenCut) {
         FrameGeom::ColumnSet cs;
         cs.blurLevels = std::min(nblur, t.nlevels);
         const bool anyBlur = nblur > 0;
         const int RX = std::max(1, (cols + px / 2) / px), RY = std::max(1, (rows + px / 2) / px);
         cs.px = px; cs.RX = RX; cs.RY = RY;
+        const int edgeNum = px <= 56 && !evenCut ? kColEdgeNum : 1, edgeDen = px <= 56 && !evenCut ? kColEdgeDen : 1;
         bool fits = true;
         int maxEven = 0, maxOdd = 0;
         for (int cy = 0; cy < RY; cy++)
@@ -298,8 +304,16 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     const int nd = (kPadL - kEdge + L.w + 2 * kEdge + 3) / 4, wB = L.w + 2 * kEdge;
                     // the INTERIOR is cut evenly (x cuts at multiples of 4: dword boundaries of the bordered rows), so that a region's parts of
                     // successive levels lie above each other; the border frame goes to the outer regions
-                    auto cutX = [&](int i) { return i <= 0 ? 0 : (i >= RX ? nd : (kPadL + (int)(((long long)i * L.w / RX) & ~3LL)) / 4); };
-                    auto cutY = [&](int i) { return i <= 0 ? 0 : (i >= RY ? L.pyrRows : kEdge + (int)((long long)i * L.h / RY)); };
+                    // (the fine cuts - the launch of a few frames is as long as its slowest workgroup - give the OUTER regions less of the interior:
+                    // they also write the 19-px frame and hold its mirrored pixels down to the coarsest level; edgeNum / edgeDen of an inner
+                    // region's share.  One 640x480 frame 37.3 -> 36.6-36.7 us with 3/5; 1/2, 2/5 and 4/5 within 0.3 us of that - the corner regions'
+                    // deep levels are set by the 19 mirrored pixels, not by their share, so this is all the cut can give)
+                    auto frac = [&](int i, int R, long long extent) {
+                        if (R < 3 || edgeNum == edgeDen) return (long long)i * extent / R;
+                        return ((long long)edgeNum + (long long)(i - 1) * edgeDen) * extent / (2LL * edgeNum + (long long)(R - 2) * edgeDen);
+                    };
+                    auto cutX = [&](int i) { return i <= 0 ? 0 : (i >= RX ? nd : (kPadL + (int)(frac(i, RX, L.w) & ~3LL)) / 4); };
+                    auto cutY = [&](int i) { return i <= 0 ? 0 : (i >= RY ? L.pyrRows : kEdge + (int)frac(i, RY, L.h)); };
                     const int dwA = cutX(cx), dwB = cutX(cx + 1), rA = cutY(cy), rB = cutY(cy + 1);
                     c.own[l] = ColOwn{(short)dwA, (short)dwB, (short)rA, (short)rB};
                     int nx0 = 1 << 30, nx1 = -1, ny0 = 1 << 30, ny1 = -1;
@@ -382,8 +396,15 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         cs.fit = fits;
         return cs;
         };
-        if (colPx > 0) { g.colSets.push_back(buildCols(colPx, 0)); g.colSetsBlur.push_back(buildCols(colPx, std::max(blurInLevels, 1))); }
-        else for (int px : kColPx) { g.colSets.push_back(buildCols(px, 0)); g.colSetsBlur.push_back(buildCols(px, std::max(blurInLevels, 1))); }
+        // (a fine cut whose narrower outer regions make an inner region's records outgrow the kernel's staging - many levels at a small scale
+        // factor - is rebuilt evenly)
+        auto buildFit = [&](const int px, const int nblur) {
+            FrameGeom::ColumnSet cs = buildCols(px, nblur, false);
+            if (!cs.fit && px <= 56 && kColEdgeNum != kColEdgeDen) cs = buildCols(px, nblur, true);
+            return cs;
+        };
+        if (colPx > 0) { g.colSets.push_back(buildFit(colPx, 0)); g.colSetsBlur.push_back(buildFit(colPx, std::max(blurInLevels, 1))); }
+        else for (int px : kColPx) { g.colSets.push_back(buildFit(px, 0)); g.colSetsBlur.push_back(buildFit(px, std::max(blurInLevels, 1))); }
         bool packed = true;      // the packed horizontal pass: the 8 taps of any four adjacent columns (region columns start anywhere) within 8 source bytes
         for (int l = 1; l <= top && packed; l++) {
             const std::vector<ResizeX>& X = g.rx[l];
