@@ -1272,6 +1272,7 @@ int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, p
     HIP_TRY(h, hipSetDevice(h->device));
     const LevelGeom& L = h->geom.lv[level];
     if (dst_stride < L.w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "dst_stride too small");
+    if (h->lastBlurForm == 3) return fail(h, ORBX_ERR_UNSUPPORTED, "the last call blurred per keypoint inside k_describe: no blurred level exists (ORBX_PATCH_BLUR=0 keeps k_blur)");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy2D(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
                            L.h, hipMemcpyDeviceToHost));

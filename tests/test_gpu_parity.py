@@ -542,6 +542,8 @@ def test_patch_blur_inside_the_description(pyr_cols, monkeypatch):
         ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
         mono, k, d, lvl = ex(img, None, (0, 0))
         assert ex.last_forms()[2] == 3
+        with pytest.raises(X.OrbxError):
+            ex.debug_blurred(0)            # no blurred level exists in this form, and the library says so
         check_stages(ex, o, lvl, nlevels)
         assert_same_result((mono, k, d), want, "patch blur %s %s" % (shape, kw))
         for l in range(nlevels):      # keypoints within 20 px of a level's edge: their raw tiles reach into the bordered frame (REFLECT_101)
