@@ -728,8 +728,28 @@ def main():
             dth = back_to_back(host_call)
             extras["single_frame_host_us"] = round(dth * 1e6, 1)
             extras["single_frame_host_note"] = ("one pageable 640x480 host image in, host keypoints + descriptors out, every call waited for (orbx_extract_view + the "
-                                                "copy into the caller's arrays; PCIe-inclusive, never `value`): %.0f calls/s" % (1 / dth))
+                                                "copy into the caller's arrays, from Python through ctypes; PCIe-inclusive, never `value`): %.0f calls/s" % (1 / dth))
             del e1
+            # (c'') ... and from C++, without Python in the way: examples/orbx_frame_latency.cpp, the drop-in class's operator() (with allLevelsKeypoints)
+            # called frame by frame on pageable images, compiled here with g++ and run as a CHILD process (its own HIP context on this GPU)
+            try:
+                import re
+                import subprocess
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    exe = os.path.join(td, "orbx_frame_latency")
+                    libdir = os.path.dirname(X.library_path())
+                    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "orbx_frame_latency.cpp"),
+                                           "-o", exe, "-L" + libdir, "-lorbx", "-Wl,-rpath," + libdir], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                    outc = subprocess.check_output([exe, str(w1["rows"]), str(w1["cols"]), str(w1["nfeatures"]), "400"], text=True, timeout=120)
+                mcpp = re.search(r"frame_call_us_median=([\d.]+) frame_call_us_p10=([\d.]+) frame_call_us_p90=([\d.]+)", outc)
+                extras["single_frame_host_cpp_us"] = float(mcpp.group(1))
+                extras["single_frame_host_cpp_note"] = ("examples/orbx_frame_latency.cpp: ORBextractor::operator() of the drop-in class (include/orbx_extractor.hpp) on pageable "
+                                                        "640x480 frames, std::vector<KeyPoint> + descriptors + allLevelsKeypoints out, median of 400 calls (p10 %s, p90 %s): "
+                                                        "%.0f calls/s" % (mcpp.group(2), mcpp.group(3), 1e6 / float(mcpp.group(1))))
+            except Exception as e_cpp:      # (no g++ on the box, or the child could not run: the figure is simply absent)
+                extras["single_frame_host_cpp_us"] = None
+                extras["single_frame_host_cpp_note"] = "not measured: %r" % (e_cpp,)
             # (d) ... and a stereo pair per call (BASELINE.json configs[3]'s call shape: both eyes of one frame, 1200 features per eye)
             ws = WORKLOADS["stereo640"]
             fs = torch.from_numpy(synth.frames("noise", 0, 2, ws["rows"], ws["cols"])).cuda()
