@@ -26,6 +26,8 @@ run --steps 200 --batch 2 --workload mono640_init
 run --steps 200 --batch 8
 run --steps 100 --batch 64
 run --steps 50 --batch 256
+run --steps 15 --batch 1024
+run --steps 10 --batch 2048
 echo "# ORBX_SPLIT=0 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_SPLIT=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_FUSE_SMALL=0 --steps 300 --batch 1" >> gpurun_out/matrix.jsonl; ORBX_FUSE_SMALL=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 300 --batch 1 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd1080" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd1080 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
