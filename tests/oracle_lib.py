@@ -132,7 +132,11 @@ class Oracle:
         if image.size == 0:
             return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
-        cap = self.nfeatures + 3 * self.nlevels + 64
+        # a level keeps at most quota + 3 keypoints - or, when the quota is tiny, what the unconditional first pass leaves: up to four nodes per
+        # root (nIni = round(width / height) roots, ORBextractor.cc:548-599; a 922 x 200 frame with 55 features has five to six roots and quotas
+        # of 5 .. 14 per level: found by the round-4 soak)
+        n_ini = max(1, int(round(image.shape[1] / max(1, image.shape[0])))) + 1
+        cap = self.nfeatures + (3 + 4 * n_ini) * self.nlevels + 64
         kps = np.zeros(cap, KEYPOINT_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         mono = C.c_int(0)

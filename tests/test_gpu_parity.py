@@ -525,6 +525,19 @@ def test_region_major_pyramid_with_the_blur_inside(px, nb, monkeypatch):
                 assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "shape %s frame %d blurred level %d" % (shape_variant, f, l)
 
 
+def test_wide_frame_with_tiny_quotas_keeps_the_first_pass_nodes():
+    """A 922 x 200 frame has five to six quad-tree roots per level (nIni = round(width / height), ORBextractor.cc:548); with 55 features the
+    per-level quotas are 5 .. 14, so what a level keeps is set by the unconditional first pass (up to four nodes per root), not by quota + 3
+    (found by the round-4 soak, where the ORACLE's Python wrapper had sized its output for quota + 3)."""
+    img = synth.frames("textured", 341, 1, 200, 922)[0]
+    o, want = oracle_run(img, 55, (122, 689), 6, 1.2, 24, 24)
+    assert len(want[1]) > 55 + 3 * 6
+    ex = X.ORBextractor(55, 1.2, 6, 24, 24, max_width=922, max_height=200)
+    mono, k, d, lvl = ex(img, None, (122, 689))
+    check_stages(ex, o, lvl, 6)
+    assert_same_result((mono, k, d), want, "wide frame, tiny quotas")
+
+
 @pytest.mark.parametrize("pyr_cols", ["1", "0"])
 def test_patch_blur_inside_the_description(pyr_cols, monkeypatch):
     """k_describe<PB> (the default of large batches of large frames; forced here for every size): no blurred level is made, every keypoint's
