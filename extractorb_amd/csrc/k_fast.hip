@@ -110,45 +110,53 @@ __device__ __forceinline__ unsigned arcExtreme(const unsigned (&r)[17]) {
     return BRIGHT ? pkmax3(pkmax3(g[0], g[1], g[2]), pkmax3(g[3], g[4], g[5]), pkmax3(g[6], g[7], r[16]))
                   : pkmin3(pkmin3(g[0], g[1], g[2]), pkmin3(g[3], g[4], g[5]), pkmin3(g[6], g[7], r[16]));
 }
-// S = max(maxMin - v, v - minMax): the centre took part in both reductions, so neither difference is negative
+// One polarity per pixel (round 4).  A pixel is a corner in at most one polarity, and which one is decided exactly by the opposite ring pairs: a
+// 9-arc holds one pixel of EVERY pair (k, k+8), so a dark corner has min(r_k, r_k+8) < v for all eight pairs; a bright corner's arc k..k+8
+// holds BOTH pixels of pair k, so for it that test fails.  "max over the pairs of the pair minimum < v" therefore selects dark for every
+// dark corner and bright for every bright one; where it picks the wrong side of a non-corner the score comes out as that side's S, which is
+// <= the true S <= minThFAST - and the NMS pass counts everything <= minThFAST alike (thPair).  For a corner the other side's S is 0 (any
+// other arc shares >= 2 pixels with the corner's arc), so the stored score IS S.  A dark pixel's ring and centre are complemented (x ^ 255
+// reverses the order and keeps the halves inside 0..255), after which dark is bright: 12 + 2 + 17 (full-rate v_xor) + 36 + 1 instructions
+// per pixel pair instead of 75.
 __device__ __forceinline__ unsigned pairScore(const unsigned (&r)[17]) {
-    const unsigned maxMin = arcExtreme<true>(r);
+    unsigned m[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = pkmin3(r[k], r[k + 8], r[k + 8]);
+    const unsigned M = pkmax3(pkmax3(m[0], m[1], m[2]), pkmax3(m[3], m[4], m[5]), pkmax3(m[6], m[7], m[7]));
+    unsigned flip;                                   // per half: M < v  <=>  M - v is negative  <=>  its high byte is 0xFF (|M - v| <= 255)
+    asm("v_pk_lshrrev_b16 %0, %2, %1" : "=v"(flip) : "v"(pksub(M, r[16])), "s"(0x00080008u));
+    unsigned x[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) x[i] = r[i] ^ flip;
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned minMax = arcExtreme<false>(r);
-    return pkmax(pksub(maxMin, r[16]), pksub(r[16], minMax));
+    return pksub(arcExtreme<true>(x), x[16]);        // the centre took part in the reduction: never negative
 }
 
+// Byte-per-lane form (prefilter variant): `dark` = the polarity the cheap test let the pixel through on (pairScore has the argument: a pixel
+// that passes the dark test is no bright corner), so one polarity is evaluated, on complemented values when dark.
 template <int TS>
-__device__ __forceinline__ int fastScore(const uint8_t* c) {
+__device__ __forceinline__ int fastScore(const uint8_t* c, bool dark) {
     // ring order of cv::FAST: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),(-3,-1),
     // (-3,0),(-3,1),(-2,2),(-1,3)
+    const unsigned flip = dark ? 255u : 0u;
     unsigned r[16];
     r[0] = c[3 * TS];       r[1] = c[3 * TS + 1];   r[2] = c[2 * TS + 2];   r[3] = c[TS + 3];
     r[4] = c[3];            r[5] = c[-TS + 3];      r[6] = c[-2 * TS + 2];  r[7] = c[-3 * TS + 1];
     r[8] = c[-3 * TS];      r[9] = c[-3 * TS - 1];  r[10] = c[-2 * TS - 2]; r[11] = c[-TS - 3];
     r[12] = c[-3];          r[13] = c[TS - 3];      r[14] = c[2 * TS - 2];  r[15] = c[3 * TS - 1];
-    const unsigned v = c[0];
-    // arc pairs as in arcExtreme: 36 instructions per polarity
-    unsigned lo2[8], hi2[8], lo4[8], hi4[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        lo2[i] = min(r[2 * i + 1], r[(2 * i + 2) & 15]);
-        hi2[i] = max(r[2 * i + 1], r[(2 * i + 2) & 15]);
-    }
+    for (int i = 0; i < 16; i++) r[i] ^= flip;
+    const unsigned v = c[0] ^ flip;
+    // arc pairs as in arcExtreme: 36 instructions
+    unsigned lo2[8], lo4[8], gl[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        lo4[i] = min(lo2[i], lo2[(i + 1) & 7]);
-        hi4[i] = max(hi2[i], hi2[(i + 1) & 7]);
-    }
-    unsigned gl[8], gh[8];
+    for (int i = 0; i < 8; i++) lo2[i] = min(r[2 * i + 1], r[(2 * i + 2) & 15]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        gl[i] = vmin3(lo4[i], lo4[(i + 2) & 7], max(r[2 * i], r[(2 * i + 9) & 15]));
-        gh[i] = vmax3(hi4[i], hi4[(i + 2) & 7], min(r[2 * i], r[(2 * i + 9) & 15]));
-    }
+    for (int i = 0; i < 8; i++) lo4[i] = min(lo2[i], lo2[(i + 1) & 7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) gl[i] = vmin3(lo4[i], lo4[(i + 2) & 7], max(r[2 * i], r[(2 * i + 9) & 15]));
     const unsigned maxMin = vmax3(vmax3(gl[0], gl[1], gl[2]), vmax3(gl[3], gl[4], gl[5]), vmax3(gl[6], gl[7], v));
-    const unsigned minMax = vmin3(vmin3(gh[0], gh[1], gh[2]), vmin3(gh[3], gh[4], gh[5]), vmin3(gh[6], gh[7], v));
-    return (int)max(maxMin - v, v - minMax);
+    return (int)(maxMin - v);
 }
 
 #ifdef ORBX_FAST_CLOCK
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         int nPass = 0;
         int x = x00, y = y00;
         for (int base = 0; base < npix; base += 64) {
-            bool may = false;
+            bool may = false, dark = false;
             if (base + lane < npix) {
                 const uint8_t* c0 = tile + (y + 3) * TS + mis + x + 3;
                 const unsigned v = c0[0];
@@ -312,10 +320,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
                                                 min(max(a6, a14), max(a7, a15)));
                 const unsigned maxOfMin = vmax3(vmax3(min(a0, a8), min(a1, a9), min(a2, a10)), vmax3(min(a3, a11), min(a4, a12), min(a5, a13)),
                                                 max(min(a6, a14), min(a7, a15)));
-                may = minOfMax > v + (unsigned)minTh || maxOfMin + (unsigned)minTh < v;
+                dark = maxOfMin + (unsigned)minTh < v;
+                may = dark || minOfMax > v + (unsigned)minTh;
             }
             const unsigned long long b = __ballot(may);
-            if (may) pass[nPass + __popcll(b & ((1ull << lane) - 1))] = (unsigned short)(x | (y << 6));
+            if (may) pass[nPass + __popcll(b & ((1ull << lane) - 1))] = (unsigned short)(x | (y << 6) | (dark ? 0x1000 : 0));
             nPass += __popcll(b);
             x += qx; y += qy;
             if (x >= cw) { x -= cw; y++; }
@@ -323,8 +332,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         waveLdsSync();
         // 1b. full score of the survivors
         for (int i = lane; i < nPass; i += 64) {
-            const int e = pass[i], px = e & 63, py = e >> 6;
-            const int s = fastScore<TS>(tile + (py + 3) * TS + mis + px + 3);
+            const int e = pass[i], px = e & 63, py = (e >> 6) & 63;
+            const int s = fastScore<TS>(tile + (py + 3) * TS + mis + px + 3, (e & 0x1000) != 0);
             score[(py + 1) * TS + mis + px + 3] = (uint8_t)s;
         }
     } else if (!(ORBX_FAST_SKIP & 1)) {
