@@ -344,7 +344,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         const unsigned maskFirst = 0xFFFFFFFFu << (8 * lo), maskLast = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
         const int sx = 64 % nq, sy = 64 / nq;
         int qi = lane % nq, y = lane / nq;
-        for (int item = lane; item < nItems; item += 64) {
+        // An LDS read is served in two groups of 32 lanes (banks = dword index mod 32).  With 8 items per row a group is four rows of 8 dwords, and
+        // four CONSECUTIVE rows at 12 dwords per row start at banks 0, 12, 24, 4: the fourth collides with the first (every read of the pass
+        // 2-way).  Rows 0, 2, 4, 6 start at 0, 24, 16, 8 (and 1, 3, 5, 7 at 12, 4, 28, 20): disjoint.  The order of the items does not matter here.
+        if (DW == 12 && nq == 8) y = ((y & 3) << 1) | (y >> 2);
+        for (; y < ch;) {
             const uint8_t* base = tile + y * TS + 4 * (q0 + qi);                 // row y = centre row - 3
             unsigned L[7], C[7], R[7];
 #pragma unroll
@@ -403,20 +407,17 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
             unsigned dA, dB;                             // per half: S - max, saturated at 0: nonzero <=> strict maximum above minThFAST
             asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dA) : "v"(sA), "v"(mA));
             asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dB) : "v"(sB), "v"(mB));
-            const bool f0 = act && (dA & 0xFFFFu) != 0, f1 = act && dA > 0xFFFFu, f2 = act && (dB & 0xFFFFu) != 0, f3 = act && dB > 0xFFFFu;
-            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
-            if (b0 | b1 | b2 | b3) {
+            // two horizontal neighbours are never both strict maxima, so a pixel PAIR keeps at most one pixel: one ballot per pair, not per pixel
+            const bool fA = act && dA != 0u, fB = act && dB != 0u;
+            const unsigned long long bA = __ballot(fA), bB = __ballot(fB);
+            if (bA | bB) {
                 int at = nMin;                           // + kept pixels of the lower lanes: one v_mbcnt pair per ballot
-                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, at));
-                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, at));
-                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, at));
-                at = __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, at));
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(bA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bA, at));
+                at = __builtin_amdgcn_mbcnt_hi((unsigned)(bB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bB, at));
                 const unsigned xy = (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6);   // pixel 0 of the dword (x may be "negative": only kept pixels are used)
-                if (f0) list[at++] = xy | ((sA & 0xFFFFu) << 12);
-                if (f1) list[at++] = (xy + 1) | ((sA >> 16) << 12);
-                if (f2) list[at++] = (xy + 2) | ((sB & 0xFFFFu) << 12);
-                if (f3) list[at++] = (xy + 3) | ((sB >> 16) << 12);
-                nMin += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+                if (fA) { const bool hi = dA > 0xFFFFu; list[at++] = (xy + (hi ? 1u : 0u)) | ((hi ? sA >> 16 : sA & 0xFFFFu) << 12); }
+                if (fB) { const bool hi = dB > 0xFFFFu; list[at] = (xy + (hi ? 3u : 2u)) | ((hi ? sB >> 16 : sB & 0xFFFFu) << 12); }
+                nMin += __popcll(bA) + __popcll(bB);
             }
             qi += sx; y += sy;
             if (qi >= nq) { qi -= nq; y++; }
