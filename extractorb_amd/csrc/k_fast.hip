@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
                                                unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
                                                BlurTail tail, LeafTables lt) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
-    constexpr int kScoreBytes = TS * (ROWS - 4);      // score tile: (ch + 2) rows <= ROWS - 4
+    constexpr int kScoreBytes = TS * (ROWS - 3);      // score tile: (ch + 2) rows <= ROWS - 4, and one more zero row for the NMS lanes past the last item
     constexpr int DW = TS / 4;                        // dwords per tile row
     constexpr int LPR = DW <= 16 ? 8 : 16;            // lanes per row while staging: a lane moves TWO dwords (one 8-byte load, one 8-byte LDS store)
     constexpr int RPI = 64 / LPR;                     // rows per staging step
@@ -224,8 +224,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     static_assert(DW % 2 == 0 && TS % 8 == 0, "dword pairs per tile row");
     constexpr int kMaxPix = (ROWS - 6) * (ROWS - 6);  // interior pixels of the largest cell
     constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
-    // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword
-    __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kScoreBytes + kPassBytes)];
+    // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword.  The score tiles are an
+    // array of their own: their base is then one scalar, and the NMS pass's nine reads are immediate offsets of ONE address register (inside
+    // one array they sat 2 KB behind the pixel tile's base, past the reach of ds_read2's offsets: four v_add per trip)
+    __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kPassBytes)];
+    __shared__ __align__(16) uint8_t scoreS[kFastWaves * kScoreBytes];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
     int chunk, fr;
     if (!xcdChunkFrame(nFrames, chunk, fr)) return;   // all cells of a frame on one XCD: the 6-px ROI overlap of neighbouring cells hits its L2
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     FAST_CLOCK_BEGIN
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
-    uint8_t* tile = smem + 16 + wave * (kTileBytes + kScoreBytes + kPassBytes);
-    uint8_t* score = tile + kTileBytes;
+    uint8_t* tile = smem + 16 + wave * (kTileBytes + kPassBytes);
+    uint8_t* score = scoreS + wave * kScoreBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
     // small batches (leaf tables): the x / y path codes of the cell's interior columns and rows are fetched WITH the ROI (lane i: column i and
     // row i) and kept in LDS: read from memory where the emit needs them they were two dependent L2 round trips at the end of every cell
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         //     at threshold t needs min over the 8 pairs of max(r_k, r_k+8) > v + t (max over pairs of min < v - t).
         //     Pixels failing both have S <= minThFAST: they are neither keypoints nor able to suppress one, so their
         //     score stays 0.  Survivors are compacted so the full score runs at full lane occupancy.
-        unsigned short* pass = (unsigned short*)(score + kScoreBytes);
+        unsigned short* pass = (unsigned short*)(tile + kTileBytes);
         int nPass = 0;
         int x = x00, y = y00;
         for (int base = 0; base < npix; base += 64) {
@@ -386,8 +389,9 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         const int sx = 64 % nq, sy = 64 / nq;
         int qi = lane % nq, y = lane / nq;
         for (int item0 = 0; item0 < nItems; item0 += 64) {
-            const bool act = item0 + lane < nItems;
-            const uint8_t* base = score + (act ? y * TS + 4 * (q0 + qi) : 4);     // score row y = the row above the centre row
+            // score row y = the row above the centre row.  Lanes past the last item (y >= ch) take centre row ch + 1, the zero row below the
+            // interior: S = 0 keeps nothing, so the pass needs no "active" predicate
+            const uint8_t* base = score + min(y, ch) * TS + 4 * (q0 + qi);
             unsigned U[3], M[3], D[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
             asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dA) : "v"(sA), "v"(mA));
             asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dB) : "v"(sB), "v"(mB));
             // two horizontal neighbours are never both strict maxima, so a pixel PAIR keeps at most one pixel: one ballot per pair, not per pixel
-            const bool fA = act && dA != 0u, fB = act && dB != 0u;
+            const bool fA = dA != 0u, fB = dB != 0u;
             const unsigned long long bA = __ballot(fA), bB = __ballot(fB);
             if (bA | bB) {
                 int at = nMin;                           // + kept pixels of the lower lanes: one v_mbcnt pair per ballot
