@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     //      items are exactly 4 wave iterations.  Cost: the lane's right neighbour's dword (DPP) and one v_alignbyte. ----
     const int gx1 = kPadL + c.x0 - 1;                   // byte column of tile byte 0 in the bordered row
     const int gsh = gx1 & 3;                            // its offset inside the aligned dword the lanes load
-    constexpr int mis = 1;                              // tile byte of ROI pixel 0 (the passes below are written for any value)
+    constexpr int mis = kFastTileShift;                              // tile byte of ROI pixel 0 (the passes below are written for any value)
     {
         // wave-uniform base + 32-bit lane offsets; rows / dword columns past the ROI are clamped, not predicated (their
         // tile bytes are never read by an interior pixel)
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
         // (first / last dword of a row) are written as 0 = "outside the ROI interior".
         const int lo = mis + 3 - 4 * q0, hi = mis + 3 + cw - 4 * q1;            // first valid byte of dword q0 / valid bytes of q1
         const unsigned maskFirst = 0xFFFFFFFFu << (8 * lo), maskLast = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
-        const int sx = 64 % nq, sy = 64 / nq;
-        int qi = lane % nq, y = lane / nq;
+        const int sy = (64 * c.itemRecip) >> 16, sx = 64 - sy * nq;           // 64 / nq, 64 % nq (exact: CellDesc::itemRecip)
+        int y = (lane * c.itemRecip) >> 16, qi = lane - y * nq;                  // lane / nq, lane % nq
         // An LDS read is served in two groups of 32 lanes (banks = dword index mod 32).  With 8 items per row a group is four rows of 8 dwords, and
         // four CONSECUTIVE rows at 12 dwords per row start at banks 0, 12, 24, 4: the fourth collides with the first (every read of the pass
         // 2-way).  Rows 0, 2, 4, 6 start at 0, 24, 16, 8 (and 1, 3, 5, 7 at 12, 4, 28, 20): disjoint.  The order of the items does not matter here.
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     int nMin = 0;
     {
         const unsigned thPair = (unsigned)minTh | ((unsigned)minTh << 16);
-        const int sx = 64 % nq, sy = 64 / nq;
-        int qi = lane % nq, y = lane / nq;
+        const int sy = (64 * c.itemRecip) >> 16, sx = 64 - sy * nq;
+        int y = (lane * c.itemRecip) >> 16, qi = lane - y * nq;
         for (int item0 = 0; item0 < nItems; item0 += 64) {
             // score row y = the row above the centre row.  Lanes past the last item (y >= ch) take centre row ch + 1, the zero row below the
             // interior: S = 0 keeps nothing, so the pass needs no "active" predicate
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
         myCode = tid < 64 ? lt.xcode[c.level * lt.XT + min(c.shiftX + 3 + tid, g.rectW - 1)] : lt.ycode[c.level * lt.XT + min(c.shiftY + 3 + tid - 64, g.rectH - 1)];
     // ---- stage the ROI, re-aligned (k_fast has the reasons): tile byte k of row r is ROI pixel (k - 1, r) ----
     const int gx1 = kPadL + c.x0 - 1, gsh = gx1 & 3;
-    constexpr int mis = 1;
+    constexpr int mis = kFastTileShift;
     {
         const uint8_t* sp = pyr + c.pyrOff + (long long)f * c.pyrFrameBytes + (long long)(kEdge + c.y0) * c.pyrStride + (gx1 - gsh);
         const int dcol = tid & (LPR - 1), rsub = tid / LPR;
@@ -578,12 +578,13 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
     FAST_MID(0);
     const int q0 = (mis + 3) >> 2, q1 = (mis + 2 + cw) >> 2, nq = q1 - q0 + 1;
     const int nItems = nq * ch;
-    const int sx = 256 % nq, sy = 256 / nq;
+    const int sy = (256 * c.itemRecip) >> 16, sx = 256 - sy * nq;                // 256 / nq, 256 % nq (exact: CellDesc::itemRecip)
+    const int y0w = (tid * c.itemRecip) >> 16, qi0w = tid - y0w * nq;             // tid / nq, tid % nq
     // ---- pass 1: scores (one thread = the four pixels of one tile dword) ----
     {
         const int lo = mis + 3 - 4 * q0, hi = mis + 3 + cw - 4 * q1;
         const unsigned maskFirst = 0xFFFFFFFFu << (8 * lo), maskLast = hi >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * hi));
-        int qi = tid % nq, y = tid / nq;
+        int qi = qi0w, y = y0w;
         for (int item = tid; item < nItems; item += 256) {
             const uint8_t* base = tile + y * TS + 4 * (q0 + qi);
             unsigned L[7], C[7], R[7];
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
     int preMin[kRounds], preIni[kRounds];      // kept pixels of the lower lanes of this wave in this trip
     {
         const unsigned thPair = (unsigned)minTh | ((unsigned)minTh << 16);
-        int qi = tid % nq, y = tid / nq;
+        int qi = qi0w, y = y0w;
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             const bool act = r * 256 + tid < nItems;

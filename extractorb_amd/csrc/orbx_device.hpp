@@ -59,9 +59,13 @@ struct CellDesc {             // one FAST cell == one cv::FAST call of the refer
     int segOff;               // first slot of this cell's candidate segment inside the level's per-frame arena
     // where the cell's level lives in the pyramid arena (copied from LevelGeom by installGeometry): k_fast's staging loads then depend on
     // ONE wave-uniform load (this record), not on a second look-up in the level table — a memory round trip off a single frame's critical path
-    int pyrStride, pad2;
+    int pyrStride;
+    int itemRecip;            // ceil(65536 / fastItemsPerRow(roiW - 6)): k_fast deals lanes to (row, item) with a multiply instead of a division
     long long pyrOff, pyrFrameBytes;
 };
+// k_fast's packed passes: four-pixel items per interior row of a cell cw pixels wide (the interior starts on the tile's dword 1)
+constexpr int kFastTileShift = 1;      // tile byte of ROI pixel 0 (k_fast.hip: mis)
+inline constexpr int fastItemsPerRow(int cw) { return ((kFastTileShift + 2 + cw) >> 2) - ((kFastTileShift + 3) >> 2) + 1; }
 static_assert(sizeof(CellDesc) == 48, "CellDesc layout");
 
 // ---- quad-tree dense phase: leaf grid of a root (k_octree.hip) -------------------------------------------------------------------

@@ -187,7 +187,8 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                 c.roiH = (short)(maxY - iniY);
                 c.x0 = (short)iniX; c.y0 = (short)iniY;
                 c.shiftX = (short)(j * L.wCell); c.shiftY = (short)(i * L.hCell);
-                c.pad = 0; c.pyrStride = 0; c.pad2 = 0; c.pyrOff = 0; c.pyrFrameBytes = 0;      // (set by layoutArenas)
+                c.pad = 0; c.pyrStride = 0; c.pyrOff = 0; c.pyrFrameBytes = 0;      // (set by layoutArenas)
+                { const int nq = fastItemsPerRow(c.roiW - 6); c.itemRecip = nq > 0 ? (65536 + nq - 1) / nq : 0; }
                 c.cellId = i * L.nCols + j;
                 c.segOff = (int)cap;     // cells own consecutive, exactly sized segments in the reference's loop order
                 if (c.roiW < 7 || c.roiH < 7) continue;   // cv::FAST tests nothing on such an ROI
@@ -469,7 +470,7 @@ inline void layoutArenas(FrameGeom& g, int maxBatch) {
     g.blurBytesPerFrame = blur / maxBatch;
     for (CellDesc& c : g.cells) {      // the cells carry their level's place in the pyramid arena (orbx_device.hpp: CellDesc)
         const LevelGeom& L = g.lv[c.level];
-        c.pyrStride = L.pyrStride; c.pad2 = 0; c.pyrOff = L.pyrOff; c.pyrFrameBytes = L.pyrFrameBytes;
+        c.pyrStride = L.pyrStride; c.pyrOff = L.pyrOff; c.pyrFrameBytes = L.pyrFrameBytes;
     }
 }
 
