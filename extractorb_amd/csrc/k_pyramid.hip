@@ -281,10 +281,11 @@ extern "C" int orbx_debug_chain_spans(unsigned long long* out) { return (int)hip
 // v_alignbyte, per pixel one v_perm + one v_dot2) is shared by the destination rows that use it.  Threads are dealt quad-major (thread = row
 // block * quads + quad): every step keeps most of the T threads busy, each with few rows.
 template <int T>
-__device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ResizeX* qrs, const ResizeX* cys,
+__device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const ChainRegion rs, const ChainRegion rd, const ChainDeal dl, const ResizeX* qrs, const ResizeX* cys,
                                           const int ss, const int ds, const int tid) {
-    const int nq = (rd.w + 3) >> 2, nb = T / nq, blk = tid / nq, x4 = 4 * (tid - blk * nq);
-    const int per = (rd.h + nb - 1) / nb, yb = blk * per, ye = min(yb + per, (int)rd.h);
+    static_assert(T == 256 || T == 512, "PyrColumn::deal holds the dealing for 256 and 512 deriving threads");
+    const int nq = (rd.w + 3) >> 2, nb = dl.nb, blk = (int)(((unsigned)tid * dl.recip) >> 20), x4 = 4 * (tid - blk * nq);      // (orbx_device.hpp: ChainDeal)
+    const int per = dl.per, yb = blk * per, ye = min(yb + per, (int)rd.h);
     if (blk < nb && yb < ye) {
         u16x2 wt[4];
         unsigned sel[4];
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
         if (j < top) {
             const ResizeX* cxs = coef + off;                        // the level's quad records, then its y records (PyrColumn's layout)
             const int nqUnits = 6 * ((rd.w + 3) >> 2);
-            if (tid < TD) chainStep<TD>(S, bufOf(j + 1), rs, rd, cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
+            if (tid < TD) chainStep<TD>(S, bufOf(j + 1), rs, rd, pc.deal[TD == 512][j + 1 < kMaxLevels ? j + 1 : j], cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
             off += nqUnits + ((rd.h + 1) & ~1);
         }
         // (the last level has nothing to derive: every thread writes)
@@ -463,8 +464,18 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
                 const int rA = own.r0 + grp * per, rB = min(rA + per, (int)own.r1);
                 const uint8_t* scol = S + (4 * (fa + c) - kPadL - rs.x0);      // the column's first byte in rectangle row 0 (a multiple of 4, as rs.x0 is)
                 uint8_t* ocol = out + 4 * (fa + c);
-                for (int row = rA; row < rB; row++)
-                    *(unsigned*)(ocol + (long long)row * stride) = *(const unsigned*)(scol + __mul24(reflect101(row - kEdge, h) - rs.y0, ss));
+                // bordered rows [0, kEdge) mirror level rows kEdge .. 1, [kEdge, kEdge + h) are rows 0 .. h - 1, the rest mirror h - 2 .. (reflect101):
+                // three runs whose source row moves by one rectangle row per bordered row - an LDS read, a store and two pointer steps per dword
+                // (with the reflection, the row's product and a 64-bit address worked out per dword it was ~14 instructions)
+                auto run = [&](const int r0, const int r1, const int src0, const int sstep) {
+                    const uint8_t* sp = scol + __mul24(src0 - rs.y0, ss);
+                    uint8_t* op = ocol + (long long)r0 * stride;
+                    for (int row = r0; row < r1; row++, op += stride, sp += sstep) *(unsigned*)op = *(const unsigned*)sp;
+                };
+                const int t1 = min(rB, kEdge), m0 = max(rA, kEdge), m1 = min(rB, kEdge + h), b0 = max(rA, kEdge + h);
+                if (rA < t1) run(rA, t1, kEdge - rA, -ss);
+                if (m0 < m1) run(m0, m1, m0 - kEdge, ss);
+                if (b0 < rB) run(b0, rB, 2 * (h - 1) - (b0 - kEdge), -ss);
             }
             // (columns beyond ngrp * ndw threads: a rectangle wider than the role has threads — the regions are at most 64 dwords wide)
         }

@@ -138,7 +138,17 @@ struct ChainRegion { short x0, y0, w, h; };
 // it, the weight pairs.  (Derived in the kernel from four ResizeX records it was ~45 of the ~100 vector instructions of a one-row step.)
 struct QuadRec { unsigned sel[4]; unsigned wt[4]; int baseSh; int pad[3]; };      // baseSh = base | shift << 16;  48 bytes = six 8-byte units
 struct ColOwn { short dw0, dw1, r0, r1; };
-struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; int nCoef, pad; };   // nCoef: coefficient records of all its steps
+// How the deriving role's TD threads are dealt over level l's rectangle (thread = row block * quads + quad), worked out by the host: in the kernel
+// it was two integer divisions per thread and level (~45 vector instructions, a tenth of k_pyr_cols).  recip = ceil(2^20 / quads): tid / quads =
+// tid * recip >> 20 (exact while tid * quads < 2^20); nb = row blocks, per = rows per block.  deal[0] is for TD = 256, deal[1] for TD = 512.
+struct ChainDeal { unsigned recip; short nb, per; };
+inline ChainDeal makeChainDeal(int w, int h, int TD) {
+    const int nq = (w + 3) >> 2;
+    if (nq <= 0 || h <= 0) return ChainDeal{0u, 0, 0};
+    const int nb = TD / nq;
+    return ChainDeal{(unsigned)(((1u << 20) + nq - 1) / nq), (short)nb, (short)(nb > 0 ? (h + nb - 1) / nb : 0)};
+}
+struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; ChainDeal deal[2][kMaxLevels]; int nCoef, pad; };   // nCoef: coefficient records of all its steps
 // (the records - per level the quad records of its rectangle's column quads (QuadRec), then its y records (ResizeX, an even number of
 // slots) - are laid out per region by the host in 8-byte units: the kernel copies region t's list from coef[t * slot ..], one coalesced pass)
 struct ColLevels {      // what the kernel needs of the level tables, by value (kernel argument: scalar loads)

@@ -351,6 +351,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (l == 0) w = (w + 3) & ~3;             // the loaded rectangle: whole dwords (the kernel never reads past an image row)
                     const int hh = ny1 - ny0 + 1, bytes = ((w + 3) & ~3) * hh;
                     c.region[l] = ChainRegion{(short)nx0, (short)ny0, (short)w, (short)hh};
+                    c.deal[0][l] = makeChainDeal(w, hh, 256); c.deal[1][l] = makeChainDeal(w, hh, 512);
                     if (w > kChainMaxW || (l == 0 && bytes > kChainMaxW * kChainMaxH0)) fits = false;
                     if (l & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
                     if (l >= 1) coefs += 6 * ((w + 3) >> 2) + ((hh + 1) & ~1);      // 8-byte units: quad records, y records (even: the next level's quads stay 16-byte aligned)
