@@ -304,29 +304,17 @@ __device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const Ch
             for (int k = 0; k < 4; k++)
                 h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[k])), wt[k], 0u, false) & ~15u;
         };
-        unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
-        int have0 = -(1 << 20), have1 = -(1 << 20);          // source rows held in H0 / H1
+        // two banks of horizontal-pass results; the row records say which source row each bank must hold and the weight it gets (RowRec)
+        unsigned HA[4] = {0, 0, 0, 0}, HB[4] = {0, 0, 0, 0};
+        int haveA = -(1 << 20), haveB = -(1 << 20);
+        const RowRec* rrs = (const RowRec*)cys;
         for (int y = yb; y < ye; y++) {
-            const ResizeX cy = cys[y];
-            const int s0 = cy.sx0, s1 = cy.sx1;            // (per-lane: the lanes of a wave sit in different row blocks)
-            if (s0 != have0) {
-                if (s0 == have1) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) H0[k] = H1[k];
-                } else hrow(s0, H0);
-                have0 = s0;
-            }
-            if (s1 != have1) {
-                if (s1 == have0) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) H1[k] = H0[k];
-                } else hrow(s1, H1);
-                have1 = s1;
-            }
-            const unsigned b0 = (unsigned)cy.a0 << 12, b1 = (unsigned)cy.a1 << 12;
+            const RowRec rr = rrs[y];                      // (per-lane: the lanes of a wave sit in different row blocks)
+            if (rr.sA != haveA) { hrow(rr.sA, HA); haveA = rr.sA; }
+            if (rr.sB != haveB) { hrow(rr.sB, HB); haveB = rr.sB; }
             unsigned t[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) t[k] = mulHi24(b0, H0[k]) + mulHi24(b1, H1[k]) + 2u;
+            for (int k = 0; k < 4; k++) t[k] = mulHi24(rr.bA, HA[k]) + mulHi24(rr.bB, HB[k]) + 2u;
             const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
             *(unsigned*)(D + y * ds + x4) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);      // (columns past the region's width are padding of the 4-aligned stride)
         }
@@ -424,7 +412,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
             const ResizeX* cxs = coef + off;                        // the level's quad records, then its y records (PyrColumn's layout)
             const int nqUnits = 6 * ((rd.w + 3) >> 2);
             if (tid < TD) chainStep<TD>(S, bufOf(j + 1), rs, rd, pc.deal[TD == 512][j + 1 < kMaxLevels ? j + 1 : j], cxs, cxs + nqUnits, ss, (rd.w + 3) & ~3, tid);      // wave-uniform
-            off += nqUnits + ((rd.h + 1) & ~1);
+            off += nqUnits + 2 * rd.h;
         }
         // (the last level has nothing to derive: every thread writes)
         const bool everyone = TD == T || j == top;

@@ -124,7 +124,7 @@ struct TileFoot { short fx0, nDw, fy0, nRows; };
 struct ResizeX { short sx0, sx1, a0, a1; };   // two source columns (or rows) and their 11-bit weights for one output column (row)
 
 // Largest rectangle (any level / the loaded one) and most coefficient records (all steps of one region) k_pyr_cols' LDS staging holds
-constexpr int kChainMaxW = 256, kChainMaxH0 = 96, kChainCoefMax = 1280;
+constexpr int kChainMaxW = 256, kChainMaxH0 = 96, kChainCoefMax = 2048;
 struct ChainRegion { short x0, y0, w, h; };
 
 // Region-major pyramid (k_pyr_cols): the image is cut into RX x RY regions; ONE workgroup builds its region of EVERY level, level after level
@@ -137,6 +137,16 @@ struct ChainRegion { short x0, y0, w, h; };
 // aligned start and the byte shift of the 8-byte tap window inside the region's row, the v_perm selectors that cut each column's two taps out of
 // it, the weight pairs.  (Derived in the kernel from four ResizeX records it was ~45 of the ~100 vector instructions of a one-row step.)
 struct QuadRec { unsigned sel[4]; unsigned wt[4]; int baseSh; int pad[3]; };      // baseSh = base | shift << 16;  48 bytes = six 8-byte units
+// A destination row of the same step: its two source rows dealt to two BANKS of horizontal-pass results (A: the even source row, B: the odd
+// one; a row whose taps coincide or share a parity: tap 0 in A, tap 1 in B), each with its 11-bit weight already shifted for the vertical
+// multiply.  A thread that walks down consecutive destination rows keeps a bank while its source row stays: at scale 1.2 five rows in six
+// re-use one of the two, with no register copies and no search ("does the row I need sit in the other set?").  16 bytes = two 8-byte units.
+struct RowRec { unsigned bA, bB; int sA, sB; };
+inline RowRec makeRowRec(const ResizeX& cy) {
+    const bool swap = ((cy.sx0 ^ cy.sx1) & 1) && (cy.sx0 & 1);      // different parities and tap 0 is the odd row
+    const unsigned b0 = (unsigned)(unsigned short)cy.a0 << 12, b1 = (unsigned)(unsigned short)cy.a1 << 12;
+    return swap ? RowRec{b1, b0, cy.sx1, cy.sx0} : RowRec{b0, b1, cy.sx0, cy.sx1};
+}
 struct ColOwn { short dw0, dw1, r0, r1; };
 // How the deriving role's TD threads are dealt over level l's rectangle (thread = row block * quads + quad), worked out by the host: in the kernel
 // it was two integer divisions per thread and level (~45 vector instructions, a tenth of k_pyr_cols).  recip = ceil(2^20 / quads): tid / quads =
@@ -149,8 +159,8 @@ inline ChainDeal makeChainDeal(int w, int h, int TD) {
     return ChainDeal{(unsigned)(((1u << 20) + nq - 1) / nq), (short)nb, (short)(nb > 0 ? (h + nb - 1) / nb : 0)};
 }
 struct PyrColumn { ChainRegion region[kMaxLevels]; ColOwn own[kMaxLevels]; ChainDeal deal[2][kMaxLevels]; int nCoef, pad; };   // nCoef: coefficient records of all its steps
-// (the records - per level the quad records of its rectangle's column quads (QuadRec), then its y records (ResizeX, an even number of
-// slots) - are laid out per region by the host in 8-byte units: the kernel copies region t's list from coef[t * slot ..], one coalesced pass)
+// (the records - per level the quad records of its rectangle's column quads (QuadRec), then its row records (RowRec) - are laid out per
+// region by the host in 8-byte units: the kernel copies region t's list from coef[t * slot ..], one coalesced pass)
 struct ColLevels {      // what the kernel needs of the level tables, by value (kernel argument: scalar loads)
     int nlevels, pad;
     int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];

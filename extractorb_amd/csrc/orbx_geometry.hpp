@@ -354,7 +354,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     c.deal[0][l] = makeChainDeal(w, hh, 256); c.deal[1][l] = makeChainDeal(w, hh, 512);
                     if (w > kChainMaxW || (l == 0 && bytes > kChainMaxW * kChainMaxH0)) fits = false;
                     if (l & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
-                    if (l >= 1) coefs += 6 * ((w + 3) >> 2) + ((hh + 1) & ~1);      // 8-byte units: quad records, y records (even: the next level's quads stay 16-byte aligned)
+                    if (l >= 1) coefs += 6 * ((w + 3) >> 2) + 2 * hh;      // 8-byte units: quad records (six each), row records (two each)
                     x0 = nx0; x1 = anyBlur ? nx0 + w - 1 : std::min(nx0 + w - 1, L.w - 1); y0 = ny0; y1 = ny1;      // (blur: virtual columns are derived too)
                     if (l == 0) x1 = nx1;
                 }
@@ -388,8 +388,11 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                         std::memcpy(q, &qr, sizeof(qr));
                         q += sizeof(qr) / sizeof(ResizeX);
                     }
-                    for (int y = 0; y < r.h; y++) *q++ = g.ry[l][r.y0 + y];
-                    if (r.h & 1) *q++ = ResizeX{0, 0, 0, 0};
+                    for (int y = 0; y < r.h; y++) {
+                        const RowRec rr = makeRowRec(g.ry[l][r.y0 + y]);
+                        std::memcpy(q, &rr, sizeof(rr));
+                        q += sizeof(rr) / sizeof(ResizeX);
+                    }
                 }
             }
         }

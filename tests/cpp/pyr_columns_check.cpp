@@ -86,8 +86,8 @@ int main(int argc, char** argv) {
         for (size_t ci = 0; ci < cs.columns.size(); ci++) {
             const PyrColumn& c = cs.columns[ci];
             const ResizeX* coef = cs.coef.data() + ci * (size_t)cs.coefSlot;
-            int off = 0, total = 0;      // 8-byte units: per level the quad records (six units each), then the y records (an even number of slots)
-            for (int l = 1; l < nlevels; l++) total += 6 * ((c.region[l].w + 3) / 4) + ((c.region[l].h + 1) & ~1);
+            int off = 0, total = 0;      // 8-byte units: per level the quad records (six units each), then the row records (two units each)
+            for (int l = 1; l < nlevels; l++) total += 6 * ((c.region[l].w + 3) / 4) + 2 * c.region[l].h;
             if (total != c.nCoef || total > kChainCoefMax || total > cs.coefSlot) FAIL("px %d region %zu: %d coefficient records, nCoef %d, slot %d", cs.px, ci, total, c.nCoef, cs.coefSlot);
             std::vector<uint8_t> cur, nxt;
             for (int l = 0; l < nlevels; l++) {
@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
                     nxt.assign((size_t)ds * d.h, 0xEE);
                     const int nq = (d.w + 3) / 4;
                     const QuadRec* qrs = (const QuadRec*)(coef + off);
-                    const ResizeX* cys = coef + off + 6 * nq;
+                    const RowRec* rrs = (const RowRec*)(coef + off + 6 * nq);
                     for (int y = 0; y < d.h; y++)
                         for (int x = 0; x < d.w; x++) {
                             // the column's taps and weights as the kernel reads them out of its quad record: tap = row start + base + shift + selector byte
@@ -169,7 +169,17 @@ int main(int argc, char** argv) {
                             ResizeX cx;
                             cx.sx0 = (short)(r.x0 + base + sh + t0); cx.sx1 = (short)(r.x0 + base + sh + t1);
                             cx.a0 = (short)(qr.wt[k] & 0xffff); cx.a1 = (short)(qr.wt[k] >> 16);
-                            const ResizeX cy = cys[y];
+                            // the row's taps back out of its bank record: bank A holds the even source row when the parities differ (either order is
+                            // the same sum; the kernel adds the two products and the rounding constant as integers)
+                            const RowRec rr = rrs[y];
+                            ResizeX cy;
+                            {
+                                const ResizeX want = g.ry[l + 1][d.y0 + y];
+                                const bool swapped = rr.sA != want.sx0 || (unsigned)(unsigned short)want.a0 << 12 != rr.bA;
+                                cy.sx0 = (short)(swapped ? rr.sB : rr.sA); cy.sx1 = (short)(swapped ? rr.sA : rr.sB);
+                                cy.a0 = (short)((swapped ? rr.bB : rr.bA) >> 12); cy.a1 = (short)((swapped ? rr.bA : rr.bB) >> 12);
+                                if (((rr.sA ^ rr.sB) & 1) && (rr.sA & 1)) FAIL("px %d region %zu level %d row %d: bank A holds an odd source row although the parities differ", cs.px, ci, l + 1, y);
+                            }
                             const ResizeX gx = g.rx[l + 1][refl(d.x0 + x, g.lv[l + 1].w)], gy = g.ry[l + 1][d.y0 + y];      // (a virtual column is derived with the taps of the column it mirrors)
                             if (cx.sx0 != gx.sx0 || cx.sx1 != gx.sx1 || cx.a0 != gx.a0 || cx.a1 != gx.a1 || cy.sx0 != gy.sx0 || cy.sx1 != gy.sx1 || cy.a0 != gy.a0 || cy.a1 != gy.a1)
                                 FAIL("px %d region %zu level %d: coefficient list differs from the level tables at (%d, %d)", cs.px, ci, l + 1, x, y);
@@ -184,7 +194,7 @@ int main(int argc, char** argv) {
                                 }
                             nxt[(size_t)y * ds + x] = (uint8_t)resizePx(p[0][0], p[0][1], p[1][0], p[1][1], cx, cy);
                         }
-                    off += 6 * nq + ((d.h + 1) & ~1);
+                    off += 6 * nq + 2 * d.h;
                     cur.swap(nxt);
                 }
             }
