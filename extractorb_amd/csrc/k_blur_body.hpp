@@ -10,10 +10,26 @@
 
 namespace orbx {
 
-__device__ __forceinline__ unsigned hsum4(unsigned lo, unsigned hi) {
-    // lo = pixels x-3..x, hi = pixels x+1..x+4 (the last one weighted 0)
-    const unsigned KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
-    return __builtin_amdgcn_udot4(lo, KLO, __builtin_amdgcn_udot4(hi, KHI, 0u, false), false);
+// The horizontal 7-tap sums of the four pixels x0 .. x0 + 3 out of the three aligned dwords d0 | d1 | d2 = pixels x0 - 4 .. x0 + 7: pixel j reads
+// bytes j + 1 .. j + 7 of that 12-byte string, so its taps are a v_dot4_u32_u8 per dword it touches against the kernel shifted to the pixel's
+// place (2 + 3 + 3 + 2 multiply-adds; shifting the string to each pixel first - three v_alignbyte pairs and 2 x 4 multiply-adds - was 14).
+// The sums are the same integers whatever the order.
+__device__ __forceinline__ void hsums4(unsigned d0, unsigned d1, unsigned d2, unsigned (&hn)[4]) {
+    constexpr unsigned K0 = 18, K1 = 34, K2 = 49, K3 = 55, K4 = 49, K5 = 34, K6 = 18;      // getGaussianKernel(7, 2) x 256, rounded as cv::GaussianBlur's fixed point does
+    auto w4 = [](unsigned b0, unsigned b1, unsigned b2, unsigned b3) constexpr { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); };
+    hn[0] = __builtin_amdgcn_udot4(d0, w4(0, K0, K1, K2), __builtin_amdgcn_udot4(d1, w4(K3, K4, K5, K6), 0u, false), false);
+    hn[1] = __builtin_amdgcn_udot4(d0, w4(0, 0, K0, K1), __builtin_amdgcn_udot4(d1, w4(K2, K3, K4, K5), __builtin_amdgcn_udot4(d2, w4(K6, 0, 0, 0), 0u, false), false), false);
+    hn[2] = __builtin_amdgcn_udot4(d0, w4(0, 0, 0, K0), __builtin_amdgcn_udot4(d1, w4(K1, K2, K3, K4), __builtin_amdgcn_udot4(d2, w4(K5, K6, 0, 0), 0u, false), false), false);
+    hn[3] = __builtin_amdgcn_udot4(d1, w4(K0, K1, K2, K3), __builtin_amdgcn_udot4(d2, w4(K4, K5, K6, 0), 0u, false), false);
+}
+// (s + 32768) >> 16 saturated to 255 for four sums (a white patch reaches 257): the high halves of two sums side by side (v_perm), v_sat_pk_u8_i16
+// on each pair, the two byte pairs joined (v_perm: nothing depends on what the saturating pack leaves in its upper half) - five instructions
+// where a v_min_u32 per sum and the byte gather were seven.
+__device__ __forceinline__ unsigned satPack4(const unsigned (&t)[4]) {
+    unsigned p01, p23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p01) : "v"(__builtin_amdgcn_perm(t[1], t[0], 0x07060302u)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p23) : "v"(__builtin_amdgcn_perm(t[3], t[2], 0x07060302u)));
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
 }
 
 // One block of kBlurRows output rows x 4 columns.  load(i, d0, d1, d2): the three aligned dwords (pixels x0-4 .. x0+7) of input row i,
@@ -34,10 +50,7 @@ __device__ __forceinline__ void blurBlock(Load load, Store store) {
         unsigned d0, d1, d2;
         load(i, d0, d1, d2);
         unsigned hn[4];
-        hn[0] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1));
-        hn[1] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2));
-        hn[2] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3));
-        hn[3] = hsum4(d1, d2);
+        hsums4(d0, d1, d2, hn);
         if (i & 1) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -57,10 +70,9 @@ __device__ __forceinline__ void blurBlock(Load load, Store store) {
                     sacc = dot2(P[3][j], 34, 18, dot2(P[2][j], 55, 49, dot2(P[1][j], 34, 49, dot2(P[0][j], 0, 18, 32768u))));
                 else            // rows i-6 .. i = P[1], P[2], P[3], the waiting even row
                     sacc = dot2(lo[j], 18, 0, dot2(P[3][j], 49, 34, dot2(P[2][j], 49, 55, dot2(P[1][j], 18, 34, 32768u))));
-                t[j] = min(sacc, 0x00FFFFFFu);      // (s + 32768) >> 16 clamped to 255 is byte 2 of this
+                t[j] = sacc;
             }
-            const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(t[3], t[2], 0x0C0C0602u);
-            store(i - 6, (p23 << 16) | p01);
+            store(i - 6, satPack4(t));
         }
     }
 }
@@ -79,15 +91,9 @@ __device__ __forceinline__ void blurRun(const int nOut, Load load, Store store) 
     auto hsums = [&](int i, unsigned (&hn)[4]) {
         unsigned d0, d1, d2;
         load(i, d0, d1, d2);
-        hn[0] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1));
-        hn[1] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2));
-        hn[2] = hsum4(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3));
-        hn[3] = hsum4(d1, d2);
+        hsums4(d0, d1, d2, hn);
     };
-    auto pack = [](const unsigned (&t)[4]) {
-        const unsigned p01 = __builtin_amdgcn_perm(t[1], t[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(t[3], t[2], 0x0C0C0602u);
-        return (p23 << 16) | p01;
-    };
+    auto pack = [](const unsigned (&t)[4]) { return satPack4(t); };
     auto even = [&](int i) {          // row i (even) arrives: it waits for its partner
         unsigned hn[4];
         hsums(i, hn);
@@ -110,12 +116,12 @@ __device__ __forceinline__ void blurRun(const int nOut, Load load, Store store) 
         even(i);                      // rows i-6 .. i = P[1], P[2], P[3], the waiting even row
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            t[j] = min(dot2(lo[j], 18, 0, dot2(P[3][j], 49, 34, dot2(P[2][j], 49, 55, dot2(P[1][j], 18, 34, 32768u)))), 0x00FFFFFFu);
+            t[j] = dot2(lo[j], 18, 0, dot2(P[3][j], 49, 34, dot2(P[2][j], 49, 55, dot2(P[1][j], 18, 34, 32768u))));
         store(i - 6, pack(t));
         odd(i + 1);                   // rows i-5 .. i+1 = high half of P[0], P[1], P[2], P[3]
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            t[j] = min(dot2(P[3][j], 34, 18, dot2(P[2][j], 55, 49, dot2(P[1][j], 34, 49, dot2(P[0][j], 0, 18, 32768u)))), 0x00FFFFFFu);
+            t[j] = dot2(P[3][j], 34, 18, dot2(P[2][j], 55, 49, dot2(P[1][j], 34, 49, dot2(P[0][j], 0, 18, 32768u))));
         if (i - 5 < nOut) store(i - 5, pack(t));
     }
 }
