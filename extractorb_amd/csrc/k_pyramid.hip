@@ -61,7 +61,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // (the tap pair as two u16) and one v_dot2_u32_u16 against the packed weight pair; the vertical pass uses
 // (b << 12) * (h & ~15) >> 32 == (b * (h >> 4)) >> 16 in one v_mul_hi_u32_u24.
 template <bool PACKED>
-__device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d, const ResizeX* __restrict__ xt,
+__device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d, const ResizeX* __restrict__ xt, const QuadRec* __restrict__ xq,
                                            const ResizeX* __restrict__ yt, const TileFoot ft, uint8_t* __restrict__ pyr,
                                            int tileX, int tileY, int f, uint8_t* tile, int ldsStride) {
     const int tid = threadIdx.x, col = tid & (kTileCols - 1), rgrp = tid / kTileCols;
@@ -75,17 +75,25 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
     // ---- this thread's 4 columns: LDS byte offsets of the two taps and their 11-bit weights (loads issued first,
     //      so their latency overlaps the staging loads') ----
     int c0[4], c1[4], a0[4], a1[4];
+    uint4 q0{}, q1{};
+    int qlo = 0;
+    if constexpr (PACKED) {      // the host's record of this dword column (orbx_geometry.hpp: xq): selectors, weight pairs, the window's first source byte
+        const uint4* qr = (const uint4*)(xq + (valid ? dw : nd - 1));
+        q0 = qr[0]; q1 = qr[1];
+        qlo = ((const int*)qr)[9] - fx0;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int bx = bc0 + j - (kPadL - kEdge);               // bordered x of this byte
-        bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);    // bytes of the dword outside the bordered row are padding
-        const ResizeX cx = xt[reflect101(bx - kEdge, d.w)];
-        c0[j] = cx.sx0 - fx0; c1[j] = cx.sx1 - fx0; a0[j] = cx.a0; a1[j] = cx.a1;
+        for (int j = 0; j < 4; j++) {
+            int bx = bc0 + j - (kPadL - kEdge);               // bordered x of this byte
+            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);    // bytes of the dword outside the bordered row are padding
+            const ResizeX cx = xt[reflect101(bx - kEdge, d.w)];
+            c0[j] = cx.sx0 - fx0; c1[j] = cx.sx1 - fx0; a0[j] = cx.a0; a1[j] = cx.a1;
+        }
     }
-    // the 32 rows' vertical coefficients go through LDS (a runtime-indexed register array would live in scratch)
-    __shared__ ResizeX ycoef[kTileRows];
-    ResizeX myY{};
-    if (tid < kTileRows) myY = yt[reflect101(min(tileY * kTileRows + tid, d.pyrRows - 1) - kEdge, d.h)];
+    // the 32 rows' vertical coefficients go through LDS (a runtime-indexed register array would live in scratch), as bank records (RowRec)
+    __shared__ __align__(16) RowRec ycoef[kTileRows];
+    RowRec myY{};
+    if (tid < kTileRows) myY = makeRowRec(yt[reflect101(min(tileY * kTileRows + tid, d.pyrRows - 1) - kEdge, d.h)]);
 
     // ---- stage the footprint: 128 dword columns x 2 rows per step, kStageRows loads in flight per thread (a
     //      load -> store loop would pay one memory latency per row pair) ----
@@ -119,19 +127,13 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
     if (tid < kTileRows) ycoef[tid] = myY;
     __syncthreads();
     const int by0 = tileY * kTileRows + rgrp * kPyrRows;
-    const ResizeX* cy = ycoef + rgrp * kPyrRows;
+    const RowRec* cy = ycoef + rgrp * kPyrRows;
     uint8_t* dst = pyr + d.pyrOff + (long long)f * d.pyrFrameBytes + (long long)by0 * d.pyrStride + bc0;
     if constexpr (PACKED) {
-        int lo = min(min(min(c0[0], c1[0]), min(c0[1], c1[1])), min(min(c0[2], c1[2]), min(c0[3], c1[3])));
-        const int base = lo & ~3;
-        const unsigned sh = (unsigned)(lo & 3);
-        unsigned sel[4];
-        u16x2 wt[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sel[j] = 0x0C000C00u | (unsigned)(c0[j] - lo) | ((unsigned)(c1[j] - lo) << 16);
-            wt[j] = u16x2{(unsigned short)a0[j], (unsigned short)a1[j]};
-        }
+        const int base = qlo & ~3;
+        const unsigned sh = (unsigned)(qlo & 3);
+        const unsigned sel[4] = {q0.x, q0.y, q0.z, q0.w};
+        const u16x2 wt[4] = {__builtin_bit_cast(u16x2, q1.x), __builtin_bit_cast(u16x2, q1.y), __builtin_bit_cast(u16x2, q1.z), __builtin_bit_cast(u16x2, q1.w)};
         // Horizontal pass of ONE source row for the thread's four pixels (masked for the vertical pass's >> 4).  Consecutive destination
         // rows share source rows (at scale 1.2 eight destination rows use ten distinct source rows, not sixteen), and the rows a
         // destination row uses are the same for the whole wave (a wave = one row group), so the choice "reuse / compute" is a scalar
@@ -144,29 +146,18 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
             for (int j = 0; j < 4; j++)
                 h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(P1, P0, sel[j])), wt[j], 0u, false) & ~15u;
         };
-        unsigned H0[4] = {0, 0, 0, 0}, H1[4] = {0, 0, 0, 0};
-        int have0 = -(1 << 20), have1 = -(1 << 20);             // source rows held in H0 / H1
+        // two banks of horizontal-pass results (RowRec: the host-side rule that deals a row's two source rows to them, weights pre-shifted)
+        unsigned HA[4] = {0, 0, 0, 0}, HB[4] = {0, 0, 0, 0};
+        int haveA = -(1 << 20), haveB = -(1 << 20);
 #pragma unroll
         for (int r = 0; r < kPyrRows; r++) {
-            const int s0 = __builtin_amdgcn_readfirstlane((int)cy[r].sx0), s1 = __builtin_amdgcn_readfirstlane((int)cy[r].sx1);
-            if (s0 != have0) {
-                if (s0 == have1) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) H0[j] = H1[j];
-                } else hrow(s0, H0);
-                have0 = s0;
-            }
-            if (s1 != have1) {
-                if (s1 == have0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) H1[j] = H0[j];
-                } else hrow(s1, H1);
-                have1 = s1;
-            }
-            const unsigned b0 = (unsigned)cy[r].a0 << 12, b1 = (unsigned)cy[r].a1 << 12;
+            const RowRec rr = cy[r];
+            const int sA = __builtin_amdgcn_readfirstlane(rr.sA), sB = __builtin_amdgcn_readfirstlane(rr.sB);
+            if (sA != haveA) { hrow(sA, HA); haveA = sA; }
+            if (sB != haveB) { hrow(sB, HB); haveB = sB; }
             unsigned t[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) t[j] = mulHi24(b0, H0[j]) + mulHi24(b1, H1[j]) + 2u;
+            for (int j = 0; j < 4; j++) t[j] = mulHi24(rr.bA, HA[j]) + mulHi24(rr.bB, HB[j]) + 2u;
             const unsigned u01 = pkLshr2(t[0] | (t[1] << 16)), u23 = pkLshr2(t[2] | (t[3] << 16));
             if (valid && by0 + r < d.pyrRows) *(unsigned*)(dst + r * d.pyrStride) = __builtin_amdgcn_perm(u23, u01, 0x06040200u);
         }
@@ -174,9 +165,9 @@ __device__ __forceinline__ void resizeTile(const SrcView& sv, const LevelGeom& d
     // two rows per trip: enough LDS reads in flight without holding all 128 taps of the thread in registers
 #pragma unroll 2
     for (int r = 0; r < kPyrRows; r++) {
-        const uint8_t* r0 = tile + __mul24(cy[r].sx0 - fy0, ldsStride);
-        const uint8_t* r1 = tile + __mul24(cy[r].sx1 - fy0, ldsStride);
-        const int b0 = cy[r].a0, b1 = cy[r].a1;
+        const uint8_t* r0 = tile + __mul24(cy[r].sA - fy0, ldsStride);      // (bank A / bank B: either order is the same sum)
+        const uint8_t* r1 = tile + __mul24(cy[r].sB - fy0, ldsStride);
+        const int b0 = (int)(cy[r].bA >> 12), b1 = (int)(cy[r].bB >> 12);
         unsigned o = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -225,7 +216,7 @@ __device__ __forceinline__ void copyTile(const SrcView& sv, const LevelGeom& g0,
 // bordered level 1 from the caller's image (== level 0's interior).
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, LevelGeom g1, int tilesX0, int nTiles0,
-                                                    int tilesX1, const ResizeX* __restrict__ xt, const ResizeX* __restrict__ yt,
+                                                    int tilesX1, const ResizeX* __restrict__ xt, const QuadRec* __restrict__ xq, const ResizeX* __restrict__ yt,
                                                     const TileFoot* __restrict__ foot, uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
     int t, fr;
@@ -236,13 +227,13 @@ __global__ __launch_bounds__(256) void k_pyr_first(SrcView img, LevelGeom g0, Le
     } else {
         t -= nTiles0;
         const int tileY = t / tilesX1;
-        resizeTile<PACKED>(img, g1, xt, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride);
+        resizeTile<PACKED>(img, g1, xt, xq, yt, foot[t], pyr, t - tileY * tilesX1, tileY, f0 + fr, tile, ldsStride);
     }
 }
 
 // grid (tilesX*tilesY, B): level d from level s of the pyramid.
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt,
+__global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int tilesX, const ResizeX* __restrict__ xt, const QuadRec* __restrict__ xq,
                                                  const ResizeX* __restrict__ yt, const TileFoot* __restrict__ foot,
                                                  uint8_t* __restrict__ pyr, int ldsStride, int f0, int nFrames) {
     extern __shared__ __align__(16) uint8_t tile[];
@@ -252,7 +243,7 @@ __global__ __launch_bounds__(256) void k_resize(LevelGeom s, LevelGeom d, int ti
     int t, fr;
     if (!xcdChunkFrame(nFrames, t, fr)) return;   // neighbouring tiles of a frame (overlapping source footprints) on one XCD
     const int tileY = t / tilesX;
-    resizeTile<PACKED>(sv, d, xt, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
+    resizeTile<PACKED>(sv, d, xt, xq, yt, foot[t], pyr, t - tileY * tilesX, tileY, f0 + fr, tile, ldsStride);
 }
 
 // ---- stamped builds (-DORBX_CHAIN_STAMPS, tools/cols_stamps.py): s_memrealtime ticks of one region's stages and every region's span ----
@@ -553,7 +544,7 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
 }
 
 void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, const LevelGeom& g0,
-                    const LevelGeom* g1, int tilesX0, int tilesY0, int tilesX1, int tilesY1, const ResizeX* xt,
+                    const LevelGeom* g1, int tilesX0, int tilesY0, int tilesX1, int tilesY1, const ResizeX* xt, const QuadRec* xq,
                     const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = g0.w;
@@ -561,16 +552,16 @@ void launchPyrFirst(hipStream_t st, const uint8_t* img, long long stride, long l
     const int n0 = tilesX0 * tilesY0, n1 = g1 ? tilesX1 * tilesY1 : 0;
     // + 16: the packed path reads three dwords from the first tap's dword, i.e. up to 8 bytes past a row's footprint
     if (packed) hipLaunchKernelGGL(k_pyr_first<true>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
-                                   g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
+                                   g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, xq, yt, foot, pyr, ldsStride, f0, B);
     else hipLaunchKernelGGL(k_pyr_first<false>, xcdGrid(n0 + n1, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, sv, g0,
-                            g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, yt, foot, pyr, ldsStride, f0, B);
+                            g1 ? *g1 : g0, tilesX0, n0, g1 ? tilesX1 : 1, xt, xq, yt, foot, pyr, ldsStride, f0, B);
 }
-void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt,
+void launchResize(hipStream_t st, const LevelGeom& s, const LevelGeom& d, int tilesX, int tilesY, const ResizeX* xt, const QuadRec* xq,
                   const ResizeX* yt, const TileFoot* foot, uint8_t* pyr, int ldsStride, int ldsRows, bool packed, int f0, int B) {
     if (packed) hipLaunchKernelGGL(k_resize<true>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                                   tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
+                                   tilesX, xt, xq, yt, foot, pyr, ldsStride, f0, B);
     else hipLaunchKernelGGL(k_resize<false>, xcdGrid(tilesX * tilesY, B), dim3(256), (size_t)ldsStride * ldsRows + 16, st, s, d,
-                            tilesX, xt, yt, foot, pyr, ldsStride, f0, B);
+                            tilesX, xt, xq, yt, foot, pyr, ldsStride, f0, B);
 }
 
 }  // namespace orbx

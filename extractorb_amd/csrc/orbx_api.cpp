@@ -19,8 +19,8 @@
 namespace orbx {
 // launch wrappers, defined in the k_*.hip files
 void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
-                    const ResizeX*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
-void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const ResizeX*, const TileFoot*,
+                    const ResizeX*, const QuadRec*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
+void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const QuadRec*, const ResizeX*, const TileFoot*,
                   uint8_t*, int, int, bool, int, int);
 struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
@@ -131,6 +131,8 @@ struct orbx_handle {
     LevelGeom* d_lv = nullptr;
     CellDesc* d_cells = nullptr;
     ResizeX *d_rx = nullptr, *d_ry = nullptr;
+    QuadRec* d_xq = nullptr;            // per level: the tile resize's dword-column records (FrameGeom::xq)
+    size_t xqCap = 0, xqOff[kMaxLevels] = {};
     PyrColumn* d_cols = nullptr;        // regions of the region-major pyramid (k_pyr_cols)
     size_t colsCap = 0, colsOff[8] = {};   // first column of each cut of the geometry in d_cols
     ResizeX* d_colCoef = nullptr;       // the regions' coefficient lists, cut after cut
@@ -274,7 +276,7 @@ orbx_handle::OutView outView(uint8_t* base, const OutLayout& o) {
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
-                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
+                   h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_xq, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -315,6 +317,16 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
         xo += g.rx[l].size(); yo += g.ry[l].size();
+    }
+    {
+        size_t qo = 0;
+        for (int l = 1; l < g.nlevels; l++) {
+            h->xqOff[l] = qo;
+            if (g.xq[l].empty()) continue;      // (taps not packed: the byte-gather form reads the plain tables)
+            if (qo + g.xq[l].size() > h->xqCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "resize column records do not fit");
+            HIP_TRY(h, hipMemcpy(h->d_xq + qo, g.xq[l].data(), sizeof(QuadRec) * g.xq[l].size(), hipMemcpyHostToDevice));
+            qo += g.xq[l].size();
+        }
     }
     if (h->leafFrames) {      // x / y path codes of every level the quad-tree's dense phase covers (k_octree_body.inc: `dense`)
         std::vector<uint8_t> code((size_t)2 * g.nlevels * h->octXT, 0);
@@ -528,13 +540,13 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                 Prof p(h, S_LEVEL0, st);
                 pollute(st);
                 launchPyrFirst(st, d_imgs, stride, frameStride, g.lv[0], g.nlevels > 1 ? &g.lv[1] : nullptr, g.tilesX[0], g.tilesY[0],
-                               g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
+                               g.tilesX[1], g.tilesY[1], h->d_rx + h->rxOff[1], h->d_xq + h->xqOff[1], h->d_ry + h->ryOff[1], h->d_foot + h->footOff[1], h->d_pyr,
                                g.tileLdsStride, g.tileLdsRows, g.packedTaps[1] && !h->resizeBytewise, f0, Bn);
             }
             for (int l = 2; l < g.nlevels; l++) {      // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above)
                 Prof p(h, S_RESIZE, st);
                 pollute(st);
-                launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_ry + h->ryOff[l],
+                launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_xq + h->xqOff[l], h->d_ry + h->ryOff[l],
                              h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
             }
         }
@@ -878,6 +890,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_cells, sizeof(CellDesc) * h->cellCap);
     CREATE_ALLOC(h->d_rx, sizeof(ResizeX) * h->rxCap);
     CREATE_ALLOC(h->d_ry, sizeof(ResizeX) * h->rxCap);
+    h->xqCap = ((size_t)(max_width + 2 * kEdge + kPadL) / 4 + 2) * nlevels;
+    CREATE_ALLOC(h->d_xq, sizeof(QuadRec) * h->xqCap);
     CREATE_ALLOC(h->d_tiles, sizeof(BlurItem) * h->tileCap);
     CREATE_ALLOC(h->d_laneItem, sizeof(unsigned short) * h->laneCap);
     h->pyrCols = getenv("ORBX_PYR_COLS") ? atoi(getenv("ORBX_PYR_COLS")) : -1;

@@ -142,7 +142,7 @@ struct QuadRec { unsigned sel[4]; unsigned wt[4]; int baseSh; int pad[3]; };    
 // multiply.  A thread that walks down consecutive destination rows keeps a bank while its source row stays: at scale 1.2 five rows in six
 // re-use one of the two, with no register copies and no search ("does the row I need sit in the other set?").  16 bytes = two 8-byte units.
 struct RowRec { unsigned bA, bB; int sA, sB; };
-inline RowRec makeRowRec(const ResizeX& cy) {
+ORBX_HD inline RowRec makeRowRec(const ResizeX& cy) {
     const bool swap = ((cy.sx0 ^ cy.sx1) & 1) && (cy.sx0 & 1);      // different parities and tap 0 is the odd row
     const unsigned b0 = (unsigned)(unsigned short)cy.a0 << 12, b1 = (unsigned)(unsigned short)cy.a1 << 12;
     return swap ? RowRec{b1, b0, cy.sx1, cy.sx0} : RowRec{b0, b1, cy.sx0, cy.sx1};

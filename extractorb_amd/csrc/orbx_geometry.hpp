@@ -109,6 +109,7 @@ struct FrameGeom {
     int tilesX[kMaxLevels] = {}, tilesY[kMaxLevels] = {};
     int tileLdsStride = 16, tileLdsRows = 1; // LDS tile able to hold the largest footprint
     bool packedTaps[kMaxLevels] = {};        // level l: the 8 source taps of every aligned 4-pixel group span <= 8 bytes
+    std::vector<QuadRec> xq[kMaxLevels];     // level l, packed taps: what a thread of the tile resize needs of its dword column (k_resize / k_pyr_first)
     long long pyrBytesPerFrame = 0, blurBytesPerFrame = 0;
     long long candPerFrame = 0;              // sum of candCap
     int selPerFrame = 0;                     // sum of selCap
@@ -231,6 +232,27 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (hi - lo > 7) packed = false;
                 }
                 g.packedTaps[l] = packed;
+                // the tile resize's per-thread setup, once per level instead of once per thread and tile (four table look-ups with their clamps
+                // and reflections, the window's start, selectors and weight pairs: ~50 of a thread's ~800 vector instructions): QuadRec of the
+                // bordered level's dword column dw, the window's first byte kept as an ABSOLUTE source column in pad[0] (tiles subtract their own
+                // footprint origin, a multiple of 4)
+                g.xq[l].clear();
+                if (packed)
+                    for (int dw = 0; dw < nd; dw++) {
+                        QuadRec q{};
+                        int c0[4], c1[4], lo = 1 << 30;
+                        for (int j = 0; j < 4; j++) {
+                            int bx = 4 * dw + j - (kPadL - kEdge);
+                            bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                            const ResizeX& c = g.rx[l][refl(bx - kEdge, L.w)];
+                            c0[j] = c.sx0; c1[j] = c.sx1;
+                            q.wt[j] = (unsigned)(unsigned short)c.a0 | ((unsigned)(unsigned short)c.a1 << 16);
+                            lo = std::min(lo, std::min(c0[j], c1[j]));
+                        }
+                        for (int j = 0; j < 4; j++) q.sel[j] = 0x0C000C00u | (unsigned)(c0[j] - lo) | ((unsigned)(c1[j] - lo) << 16);
+                        q.pad[0] = lo;
+                        g.xq[l].push_back(q);
+                    }
                 // tap footprints per tile column / tile row (they factor: x taps depend on tx only, y taps on ty only)
                 std::vector<int> fx0(g.tilesX[l]), fx1(g.tilesX[l]), fy0(g.tilesY[l]), fy1(g.tilesY[l]);
                 for (int tx = 0; tx < g.tilesX[l]; tx++) {
