@@ -11,8 +11,9 @@
 // Packed form (the variant used on dense content): one lane = the four pixels of one tile dword, as two pixel PAIRS held
 // as 2 x u16 per register.  The bit patterns 0..255 are non-negative binary16 denormals, whose order is the integer
 // order, so gfx950's packed v_pk_minimum3_f16 / v_pk_maximum3_f16 are exact integer min3 / max3 on both pixels; ring
-// pairs are cut out of the tile's dwords with v_perm_b32.  The byte-per-lane form (fastScore) serves the prefilter
-// variant, which scores only the few pixels that pass a cheap exact test.
+// pairs are cut out of the tile's dwords with v_perm_b32.  (Rounds 1-3 also kept a byte-per-lane variant that first rejected pixels with
+// a cheap exact test and scored the survivors, for natural / sparse content; once the packed pass evaluated one polarity per pixel it was
+// the faster one on every content measured - noise, textured, natural, sparse, 640x480 and 1920x1080 - and the variant was removed.)
 //
 // NMS is a strict 3x3 maximum of S with everything outside the cell interior counted as 0; a surviving centre has
 // S > t, so neighbours below t can never suppress it: NMS is threshold independent and runs once (also four pixels
@@ -29,17 +30,6 @@
 #include "k_blur_body.hpp"
 
 namespace orbx {
-
-__device__ __forceinline__ unsigned vmin3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ unsigned vmax3(unsigned a, unsigned b, unsigned c) {
-    unsigned r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 
 // Two pixels per register: u16 halves holding 0..255.  As IEEE binary16 bit patterns those are non-negative
 // denormals, whose order is the integer order, and minimum/maximum return one operand unchanged (the kernel runs
@@ -132,33 +122,6 @@ __device__ __forceinline__ unsigned pairScore(const unsigned (&r)[17]) {
     return pksub(arcExtreme<true>(x), x[16]);        // the centre took part in the reduction: never negative
 }
 
-// Byte-per-lane form (prefilter variant): `dark` = the polarity the cheap test let the pixel through on (pairScore has the argument: a pixel
-// that passes the dark test is no bright corner), so one polarity is evaluated, on complemented values when dark.
-template <int TS>
-__device__ __forceinline__ int fastScore(const uint8_t* c, bool dark) {
-    // ring order of cv::FAST: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),(-3,-1),
-    // (-3,0),(-3,1),(-2,2),(-1,3)
-    const unsigned flip = dark ? 255u : 0u;
-    unsigned r[16];
-    r[0] = c[3 * TS];       r[1] = c[3 * TS + 1];   r[2] = c[2 * TS + 2];   r[3] = c[TS + 3];
-    r[4] = c[3];            r[5] = c[-TS + 3];      r[6] = c[-2 * TS + 2];  r[7] = c[-3 * TS + 1];
-    r[8] = c[-3 * TS];      r[9] = c[-3 * TS - 1];  r[10] = c[-2 * TS - 2]; r[11] = c[-TS - 3];
-    r[12] = c[-3];          r[13] = c[TS - 3];      r[14] = c[2 * TS - 2];  r[15] = c[3 * TS - 1];
-#pragma unroll
-    for (int i = 0; i < 16; i++) r[i] ^= flip;
-    const unsigned v = c[0] ^ flip;
-    // arc pairs as in arcExtreme: 36 instructions
-    unsigned lo2[8], lo4[8], gl[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) lo2[i] = min(r[2 * i + 1], r[(2 * i + 2) & 15]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) lo4[i] = min(lo2[i], lo2[(i + 1) & 7]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) gl[i] = vmin3(lo4[i], lo4[(i + 2) & 7], max(r[2 * i], r[(2 * i + 9) & 15]));
-    const unsigned maxMin = vmax3(vmax3(gl[0], gl[1], gl[2]), vmax3(gl[3], gl[4], gl[5]), vmax3(gl[6], gl[7], v));
-    return (int)(maxMin - v);
-}
-
 #ifdef ORBX_FAST_CLOCK
 // diagnostic build only (tools/fast_clock.py): the clock k_fast's waves actually run at = sum of delta s_memtime / sum of delta s_memrealtime
 // x 100 MHz over every cell-wave (MI355X_MICROARCH.md, DVFS give-back (6)); the stamps go to a buffer nothing else reads
@@ -188,7 +151,7 @@ extern "C" int orbx_debug_fast_mid(unsigned long long* out) { return (int)hipMem
 #endif
 constexpr int kFastWaves = 4;
 #ifndef ORBX_FAST_WAVES
-#define ORBX_FAST_WAVES 4   // waves per SIMD the packed (non-prefilter) variant is compiled for
+#define ORBX_FAST_WAVES 4   // waves per SIMD the kernel is compiled for
 #endif
 #ifndef ORBX_FAST_SKIP
 #define ORBX_FAST_SKIP 0   // diagnostic builds (tools/fast_breakdown.py): 1 = no score pass, 2 = stop after the score pass, 4 = no staging loads
@@ -209,8 +172,8 @@ struct BlurTail { const BlurItem* items; const unsigned short* laneItem; int nLa
 
 // TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.  FUSE_BLUR: chunks past tail.fastChunks run
 // blur lanes (short-chain form) instead of FAST cells.
-template <int TS, int ROWS, bool PREFILTER, bool FUSE_BLUR = false>
-__global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
+template <int TS, int ROWS, bool FUSE_BLUR = false>
+__global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
@@ -222,12 +185,10 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     constexpr int RPI = 64 / LPR;                     // rows per staging step
     constexpr int STEPS = (ROWS + RPI - 1) / RPI;
     static_assert(DW % 2 == 0 && TS % 8 == 0, "dword pairs per tile row");
-    constexpr int kMaxPix = (ROWS - 6) * (ROWS - 6);  // interior pixels of the largest cell
-    constexpr int kPassBytes = PREFILTER ? ((kMaxPix * 2 + 15) & ~15) : 0;   // list of pixels that may be corners
     // 16 bytes of padding in front: the packed score pass reads the dword left of every row's first interior dword.  The score tiles are an
     // array of their own: their base is then one scalar, and the NMS pass's nine reads are immediate offsets of ONE address register (inside
     // one array they sat 2 KB behind the pixel tile's base, past the reach of ds_read2's offsets: four v_add per trip)
-    __shared__ __align__(16) uint8_t smem[16 + kFastWaves * (kTileBytes + kPassBytes)];
+    __shared__ __align__(16) uint8_t smem[16 + kFastWaves * kTileBytes];
     __shared__ __align__(16) uint8_t scoreS[kFastWaves * kScoreBytes];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: the cell and its geometry load through the scalar unit
     int chunk, fr;
@@ -245,7 +206,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     FAST_CLOCK_BEGIN
     const CellDesc c = cells[ci];
     const LevelGeom g = lv[c.level];
-    uint8_t* tile = smem + 16 + wave * (kTileBytes + kPassBytes);
+    uint8_t* tile = smem + 16 + wave * kTileBytes;
     uint8_t* score = scoreS + wave * kScoreBytes;
     const int roiW = c.roiW, roiH = c.roiH, cw = roiW - 6, ch = roiH - 6;
     // small batches (leaf tables): the x / y path codes of the cell's interior columns and rows are fetched WITH the ROI (lane i: column i and
@@ -295,51 +256,11 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
     waveLdsSync();
     FAST_MID(0);
 
-    const int npix = cw * ch;
-    const int qx = 64 % cw, qy = 64 / cw;               // how (x, y) advance when the pixel index advances by 64
-    const int x00 = lane % cw, y00 = lane / cw;
     // "items" of the packed passes: one tile dword (4 pixels) of an interior row; q0..q1 are the dwords that touch it
     const int q0 = (mis + 3) >> 2, q1 = (mis + 2 + cw) >> 2, nq = q1 - q0 + 1;
     const int nItems = nq * ch;
     // ---- pass 1: scores ----
-    if (PREFILTER) {
-        // 1a. cheap exact rejection: a 9-arc contains one pixel of every opposite ring pair, so a bright (dark) corner
-        //     at threshold t needs min over the 8 pairs of max(r_k, r_k+8) > v + t (max over pairs of min < v - t).
-        //     Pixels failing both have S <= minThFAST: they are neither keypoints nor able to suppress one, so their
-        //     score stays 0.  Survivors are compacted so the full score runs at full lane occupancy.
-        unsigned short* pass = (unsigned short*)(tile + kTileBytes);
-        int nPass = 0;
-        int x = x00, y = y00;
-        for (int base = 0; base < npix; base += 64) {
-            bool may = false, dark = false;
-            if (base + lane < npix) {
-                const uint8_t* c0 = tile + (y + 3) * TS + mis + x + 3;
-                const unsigned v = c0[0];
-                const unsigned a0 = c0[3 * TS], a8 = c0[-3 * TS], a1 = c0[3 * TS + 1], a9 = c0[-3 * TS - 1];
-                const unsigned a2 = c0[2 * TS + 2], a10 = c0[-2 * TS - 2], a3 = c0[TS + 3], a11 = c0[-TS - 3];
-                const unsigned a4 = c0[3], a12 = c0[-3], a5 = c0[-TS + 3], a13 = c0[TS - 3];
-                const unsigned a6 = c0[-2 * TS + 2], a14 = c0[2 * TS - 2], a7 = c0[-3 * TS + 1], a15 = c0[3 * TS - 1];
-                const unsigned minOfMax = vmin3(vmin3(max(a0, a8), max(a1, a9), max(a2, a10)), vmin3(max(a3, a11), max(a4, a12), max(a5, a13)),
-                                                min(max(a6, a14), max(a7, a15)));
-                const unsigned maxOfMin = vmax3(vmax3(min(a0, a8), min(a1, a9), min(a2, a10)), vmax3(min(a3, a11), min(a4, a12), min(a5, a13)),
-                                                max(min(a6, a14), min(a7, a15)));
-                dark = maxOfMin + (unsigned)minTh < v;
-                may = dark || minOfMax > v + (unsigned)minTh;
-            }
-            const unsigned long long b = __ballot(may);
-            if (may) pass[nPass + __popcll(b & ((1ull << lane) - 1))] = (unsigned short)(x | (y << 6) | (dark ? 0x1000 : 0));
-            nPass += __popcll(b);
-            x += qx; y += qy;
-            if (x >= cw) { x -= cw; y++; }
-        }
-        waveLdsSync();
-        // 1b. full score of the survivors
-        for (int i = lane; i < nPass; i += 64) {
-            const int e = pass[i], px = e & 63, py = (e >> 6) & 63;
-            const int s = fastScore<TS>(tile + (py + 3) * TS + mis + px + 3, (e & 0x1000) != 0);
-            score[(py + 1) * TS + mis + px + 3] = (uint8_t)s;
-        }
-    } else if (!(ORBX_FAST_SKIP & 1)) {
+    if (!(ORBX_FAST_SKIP & 1)) {
         // one lane = the four pixels of one tile dword (two packed pairs); 21 dword reads feed 4 scores.  Score row y+1
         // keeps the tile's column alignment, so the four scores are one dword store; bytes outside the interior
         // (first / last dword of a row) are written as 0 = "outside the ROI interior".
@@ -513,7 +434,7 @@ __global__ __launch_bounds__(256, PREFILTER ? 8 : ORBX_FAST_WAVES) void k_fast(c
 //      Here the four waves share the cell's dword items (256 per trip instead of 64); the raster order of the candidates (cv::FAST's output
 //      order, ORBextractor.cc:797-864) comes from per-wave counts and ONE exchange of wave totals: every kept pixel learns its place in the
 //      minThFAST list and its place among the iniThFAST ones, the retry rule (:835-838) picks one of the two, and the candidates go straight
-//      from registers to the segment (no list in LDS).  Four barriers.  Same arithmetic as k_fast's packed path (no prefilter form). ----
+//      from registers to the segment (no list in LDS).  Four barriers.  Same arithmetic as k_fast. ----
 template <int TS, int ROWS, bool FUSE_BLUR>
 __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ cells, int nCells,
                                                     const LevelGeom* __restrict__ lv, int nlevels,
@@ -737,13 +658,13 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
-                bool prefilter, int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur,
+                int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur,
                 LeafTables lt, bool wide) {
     const int fastChunks = (nCells + kFastWaves - 1) / kFastWaves;
     const dim3 block(256);
     BlurTail tail{blurItems, blurLaneItem, blurLanes, blur, fastChunks};
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
-    if (wide && !prefilter && maxRoiW <= 45 && maxRoiH <= 45) {      // few cells: a workgroup per cell
+    if (wide && maxRoiW <= 45 && maxRoiH <= 45) {      // few cells: a workgroup per cell
         if (blurItems) hipLaunchKernelGGL((k_fast_wide<48, 45, true>), xcdGrid(nCells + (blurLanes + 255) / 256, B), block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
         else hipLaunchKernelGGL((k_fast_wide<48, 45, false>), xcdGrid(nCells, B), block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
         return;
@@ -751,17 +672,14 @@ void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGe
     if (maxRoiW <= 45 && maxRoiH <= 45) {
         if (blurItems) {      // small batch: the blur's lanes ride in the same launch
             const dim3 grid = xcdGrid(fastChunks + (blurLanes + 255) / 256, B);
-            if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
-            else hipLaunchKernelGGL((k_fast<48, 45, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+            hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
             return;
         }
         const dim3 grid = xcdGrid(fastChunks, B);
-        if (prefilter) hipLaunchKernelGGL((k_fast<48, 45, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
-        else hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+        hipLaunchKernelGGL((k_fast<48, 45, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
     } else {   // cells up to 63 px (the geometry code rejects larger ones)
         const dim3 grid = xcdGrid(fastChunks, B);
-        if (prefilter) hipLaunchKernelGGL((k_fast<72, 69, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
-        else hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+        hipLaunchKernelGGL((k_fast<72, 69, false>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
     }
 }
 bool fastCanCarryBlur(int maxRoiW, int maxRoiH) { return maxRoiW <= 45 && maxRoiH <= 45; }

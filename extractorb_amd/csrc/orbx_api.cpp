@@ -29,7 +29,7 @@ void launchLdsPollute(hipStream_t, int, int, unsigned*);
 void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, uint8_t*, int, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, bool, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
+                int, int, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
 bool fastCanCarryBlur(int, int);
 size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
@@ -95,7 +95,6 @@ static const bool g_hostTiming = getenv("ORBX_HOST_TIMING") && atoi(getenv("ORBX
 static inline double nowSec() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 namespace {
-constexpr float kPrefilterDensity = 0.02f;   // candidates per pixel below which the prefilter variant of k_fast is faster
 enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_FRAME };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
@@ -190,11 +189,6 @@ struct orbx_handle {
     int lastHostB = 0;           // frames whose results the handle itself holds (the result slab: h->dev / h->host): set by the host-buffer path only
     int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
     bool pendingLevels = false;
-    // FAST kernel choice.  Both variants give identical results; the one that first rejects pixels with a cheap exact
-    // test and scores only the survivors wins when few pixels can be corners (natural images: 2-18 %), the direct one
-    // when most can (noise: 55 %).  Chosen from the candidate density of the previous batch of the stream, read back
-    // asynchronously (never waited for); ORBX_FAST_PREFILTER=0/1 forces a variant.
-    int fastMode = -1;              // -1 auto, 0 direct, 1 prefilter
     int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
                                        // chosen by the image area — separate launches per size measured slower)
     int octThreadsForced = 0;          // ORBX_OCT_THREADS
@@ -202,9 +196,6 @@ struct orbx_handle {
     bool octRoomyForced = false;       // ORBX_OCT_ROOMY: the 128-VGPR variants whatever the batch (tests reach every variant with it)
     int numCUs = 256;
     bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
-    float candDensity = -1.f;       // FAST candidates per pyramid pixel of the last batch whose statistics arrived
-    unsigned* h_candStat = nullptr; // pinned copy of d_candCount
-    hipEvent_t statEvent = nullptr;
     // the internal stream and the events of the two-half overlap (enqueueBatch)
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -214,9 +205,6 @@ struct orbx_handle {
                                        // their tails: enqueueBatch); 0 = no overlap of any kind; 3 = staggered tails for every large batch
     bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
     long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
-    bool statPending = false;
-    unsigned statCalls = 0;
-    int statB = 0;
     // ComputeBoW scratch (allocated on first use): per-feature word id / weight / node
     size_t bowEntries = 0;
     uint32_t *d_bowWord = nullptr, *d_bowNode = nullptr;
@@ -280,13 +268,12 @@ void freeAll(orbx_handle* h) {
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
                    h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
     for (void* p : dev) if (p) (void)hipFree(p);
-    if (h->statEvent) (void)hipEventDestroy(h->statEvent);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->aux2) (void)hipStreamDestroy(h->aux2);
     for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); }
-    void* host[] = {h->h_candStat, h->h_lap, h->h_out, h->h_in, h->h_pyr};
+    void* host[] = {h->h_lap, h->h_out, h->h_in, h->h_pyr};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -463,13 +450,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             h->lapCached = want;
         }
     }
-    if (h->statPending && hipEventQuery(h->statEvent) == hipSuccess) {
-        long long total = 0;
-        for (int i = 0; i < h->statB * g.nlevels; i++) total += h->h_candStat[i];
-        h->candDensity = (float)((double)total / ((double)h->statB * (double)g.sumPixels));
-        h->statPending = false;
-    }
-    const bool prefilter = h->fastMode == 1 || (h->fastMode < 0 && h->candDensity >= 0.f && h->candDensity < kPrefilterDensity);
     // the launch sequence of frames [f0, f0 + Bn) on stream st, in two parts: front = pyramid + blur (HBM / latency bound),
     // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
@@ -601,7 +581,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             if (lt.hist) h->leafDirty = true;
             if (h->testFailAfterFast && lt.hist) { injected = true; h->testFailAfterFast = false; }      // (test aid: a call that dies between k_fast and k_octree)
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
-                       h->d_cellCount, g.maxRoiW, g.maxRoiH, prefilter, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
+                       h->d_cellCount, g.maxRoiW, g.maxRoiH, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
                        h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
                        h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs));
         }
@@ -676,14 +656,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     } else {
         if (doFront) front(st, 0, B);
         if (doBack) back(st, 0, B);
-    }
-    // statistics for the next batches' kernel choice; nobody waits for this copy.  Once a density is known the stream is sampled every 32nd
-    // call only: the copy is a 4-us blit kernel on the stream, 7 % of a single-frame call
-    if (doBack && !injected && h->fastMode < 0 && !h->statPending && (h->candDensity < 0.f || (h->statCalls++ & 31) == 0)) {
-        HIP_TRY(h, hipMemcpyAsync(h->h_candStat, h->d_candCount, sizeof(unsigned) * B * g.nlevels, hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipEventRecord(h->statEvent, st));
-        h->statPending = true;
-        h->statB = B;
     }
     if (injected) return fail(h, ORBX_ERR_HIP, "ORBX_TEST_FAIL_AFTER_FAST: returned between k_fast and k_octree");
     HIP_TRY(h, hipGetLastError());
@@ -914,8 +886,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->testFailAfterFast = getenv("ORBX_TEST_FAIL_AFTER_FAST") && atoi(getenv("ORBX_TEST_FAIL_AFTER_FAST")) != 0;
     h->zeroCopy = !(getenv("ORBX_ZERO_COPY") && atoi(getenv("ORBX_ZERO_COPY")) == 0);
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
-    CREATE_TRY(hipHostMalloc(&h->h_candStat, sizeof(unsigned) * max_batch * nlevels));
-    CREATE_TRY(hipEventCreateWithFlags(&h->statEvent, hipEventDisableTiming));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));      // (default priority: a low-priority blur only starts when everything else is done - 1928 -> 2022 us; high = default)
     for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming)); }
@@ -924,7 +894,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->splitMode = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 1;
     h->fuseSmall = !(getenv("ORBX_FUSE_SMALL") && atoi(getenv("ORBX_FUSE_SMALL")) == 0);
     h->splitMinPixels = (long long)((getenv("ORBX_SPLIT_MIN_MPX") ? atof(getenv("ORBX_SPLIT_MIN_MPX")) : 120.0) * 1e6);
-    if (const char* e = getenv("ORBX_FAST_PREFILTER")) h->fastMode = atoi(e) != 0 ? 1 : 0;
     h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
     if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
     h->octRoomyForced = getenv("ORBX_OCT_ROOMY") != nullptr;

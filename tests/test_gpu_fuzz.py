@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 # (environment switches, cases, seed): the switches are read by orbx_create
 CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THREADS": "512"}, 8, 103),
-           ({"ORBX_OCT_THREADS": "1024"}, 8, 104), ({"ORBX_FAST_PREFILTER": "0"}, 8, 105), ({"ORBX_FAST_PREFILTER": "1"}, 8, 106),
+           ({"ORBX_OCT_THREADS": "1024"}, 8, 104), ({}, 8, 105), ({}, 8, 106),
            # FAST with a workgroup per cell (the form of calls with few cells, round 3) whatever the size, and never
-           ({"ORBX_FAST_WIDE": "1", "ORBX_FAST_PREFILTER": "0"}, 8, 121), ({"ORBX_FAST_WIDE": "0"}, 8, 122), ({"ORBX_FAST_WIDE": "1", "ORBX_LEAF_FRAMES": "0", "ORBX_LDS_POLLUTE": "77"}, 8, 123),
+           ({"ORBX_FAST_WIDE": "1"}, 8, 121), ({"ORBX_FAST_WIDE": "0"}, 8, 122), ({"ORBX_FAST_WIDE": "1", "ORBX_LEAF_FRAMES": "0", "ORBX_LDS_POLLUTE": "77"}, 8, 123),
            ({"ORBX_RESIZE_BYTEWISE": "1"}, 8, 107),
            # the 128-VGPR quad-tree variants (short phase-2 passes) at every workgroup size; seed 103 draws sparse levels
            ({"ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 103), ({"ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),

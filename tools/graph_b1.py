@@ -3,7 +3,6 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("ORBX_FAST_PREFILTER", "0")      # no density statistics: nothing but kernel launches in the call
 import numpy as np, torch
 import extractorb_amd as X
 from extractorb_amd import sharding, synth

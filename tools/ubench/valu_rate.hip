@@ -13,7 +13,7 @@
 // and "ghz", the clock each cell actually ran at: delta s_memtime / delta s_memrealtime x 100 MHz inside the same waves
 // (MI355X_MICROARCH.md, DVFS give-back (6)).  ev x ghz / 2.4 must then equal mt: if it does, the ev / mt gap is the chip
 // holding its clock down under a VALU-dense load, not an accounting error.
-//   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate [csv]
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate [csv [first instruction index]]
 #include <hip/hip_runtime.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
@@ -28,7 +28,7 @@ enum Op {
     OP_FMA_F32, OP_ADD_F32, OP_MAX3_F32, OP_PK_FMA_F32, OP_CVT_F32_UBYTE0, OP_PK_ADD_F16, OP_MOV_B32,
     OP_SAT_PK_U8_I16, OP_MIN_U32_SDWA, OP_LSHL_OR_B32, OP_ADD3_U32, OP_MUL_U32_U24, OP_OR_B32, OP_CNDMASK, OP_DOT2_U32_U16, OP_MUL_HI_U32_U24,
     OP_MUL_F32, OP_RNDNE_F32, OP_CVT_I32_F32, OP_FMA_F64, OP_ADD_F64, OP_MBCNT_LO, OP_MOV_DPP, OP_MAX_F32, OP_SUB_U32, OP_LSHL_ADD_U32,
-    OP_MAD_U64_U32, OP_LSHL_ADD_U64, OP_MUL_F64, OP_LSHRREV_B64, OP_MUL_I32_I24, OP_RCP_F32, OP_CVT_F64_F32, OP_CVT_F32_F64, OP_DIV_FIXUP_F32, OP_BCNT, OP_CMP_CNDMASK, OP_COUNT
+    OP_MAD_U64_U32, OP_LSHL_ADD_U64, OP_MUL_F64, OP_LSHRREV_B64, OP_MUL_I32_I24, OP_RCP_F32, OP_CVT_F64_F32, OP_CVT_F32_F64, OP_DIV_FIXUP_F32, OP_BCNT, OP_CMP_CNDMASK, OP_XOR_B32, OP_PK_LSHRREV_B16, OP_COUNT
 };
 static const char* kNames[OP_COUNT] = {
     "v_min3_u32", "v_pk_minimum3_f16", "v_pk_min_u16", "v_perm_b32", "v_min_u32", "v_pk_sub_u16", "v_bfe_u32", "v_alignbyte_b32",
@@ -36,7 +36,7 @@ static const char* kNames[OP_COUNT] = {
     "v_fma_f32", "v_add_f32", "v_max3_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_pk_add_f16", "v_mov_b32",
     "v_sat_pk_u8_i16", "v_min_u32_sdwa(WORD_1)", "v_lshl_or_b32", "v_add3_u32", "v_mul_u32_u24", "v_or_b32", "v_cndmask_b32", "v_dot2_u32_u16", "v_mul_hi_u32_u24",
     "v_mul_f32", "v_rndne_f32", "v_cvt_i32_f32", "v_fma_f64", "v_add_f64", "v_mbcnt_lo_u32_b32", "v_mov_b32_dpp(quad_perm)", "v_max_f32", "v_sub_u32", "v_lshl_add_u32",
-    "v_mad_u64_u32", "v_lshl_add_u64", "v_mul_f64", "v_lshrrev_b64", "v_mul_i32_i24", "v_rcp_f32", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_div_fixup_f32", "v_bcnt_u32_b32", "v_cmp_lt_u32+v_cndmask_b32 (pair)"};
+    "v_mad_u64_u32", "v_lshl_add_u64", "v_mul_f64", "v_lshrrev_b64", "v_mul_i32_i24", "v_rcp_f32", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_div_fixup_f32", "v_bcnt_u32_b32", "v_cmp_lt_u32+v_cndmask_b32 (pair)", "v_xor_b32", "v_pk_lshrrev_b16"};
 
 // DEP: 1 = the instruction reads its own destination (accumulator chain), 0 = destination is write-only
 template <int OP, int DEP>
@@ -101,6 +101,8 @@ __device__ __forceinline__ void one(unsigned& a, unsigned long long& a2, unsigne
     else if constexpr (OP == OP_ADD3_U32) { I3("v_add3_u32") }
     else if constexpr (OP == OP_MUL_U32_U24) { I2("v_mul_u32_u24") }
     else if constexpr (OP == OP_OR_B32) { I2("v_or_b32") }
+    else if constexpr (OP == OP_XOR_B32) { I2("v_xor_b32") }
+    else if constexpr (OP == OP_PK_LSHRREV_B16) { I2("v_pk_lshrrev_b16") }
     else if constexpr (OP == OP_CNDMASK) {
         if (DEP) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b)); else asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a) : "v"(b), "v"(c));
     }
@@ -245,8 +247,8 @@ void runOp(unsigned* d, unsigned long long* dT, bool csv) {
 }
 
 template <int OP>
-void runAll(unsigned* d, unsigned long long* dT, bool csv) {
-    if constexpr (OP < OP_COUNT) { runOp<OP>(d, dT, csv); runAll<OP + 1>(d, dT, csv); }
+void runAll(unsigned* d, unsigned long long* dT, bool csv, int first) {
+    if constexpr (OP < OP_COUNT) { if (OP >= first) runOp<OP>(d, dT, csv); runAll<OP + 1>(d, dT, csv, first); }
 }
 
 int main(int argc, char** argv) {
@@ -255,6 +257,7 @@ int main(int argc, char** argv) {
     hipMalloc(&d, 4096);
     hipMalloc(&dT, 256 * 8 * 4 * 4 * sizeof(unsigned long long));
     if (csv) printf("instruction,waves_per_simd,acc8_ev,acc8_mt,acc16_ev,acc16_mt,indep_ev,indep_mt,acc8_ghz,acc16_ghz,indep_ghz,acc8_resident,acc16_resident,indep_resident\n");
-    runAll<0>(d, dT, csv);
+    const int first = argc > 2 ? atoi(argv[2]) : 0;      // (./valu_rate csv N: only the instructions from index N on - additions to the table)
+    runAll<0>(d, dT, csv, first);
     return 0;
 }

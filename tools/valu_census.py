@@ -11,7 +11,7 @@ usage: valu_census.py [--json]      -> table (or JSON {kernel: {valu, full_rate,
 import json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "extractorb_amd", "csrc")
-FULL = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_mov_b32"}
+FULL = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32"}      # (v_xor_b32: profiles/r04_valu_issue_rate_additions.md)
 # kernel (as bench.py / rocprof name it) -> (source file, mangled-name fragment of the variant the default workload runs)
 KERNELS = {"k_fast": ("k_fast.hip", "k_fastILi48ELi45ELb0E"), "k_blur": ("k_blur.hip", "k_blur"), "k_describe": ("k_describe.hip", "k_describeILb0E"),
            "k_pyr_first": ("k_pyramid.hip", "k_pyr_firstILb1E"), "k_resize": ("k_pyramid.hip", "k_resizeILb1E"),
