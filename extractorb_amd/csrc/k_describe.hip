@@ -78,7 +78,7 @@ __device__ __forceinline__ void sincosGlibc(float y, float* s_out, float* c_out)
 constexpr int kDescWaves = 4;                         // waves per workgroup; each half-wave (32 lanes) owns one keypoint
 constexpr int kBriefReach = 18;                       // |rounded rotated pattern coordinate| <= 18 (max radius 18.385)
 constexpr int kRawRows = 2 * kHalfPatch + 1;          // 31
-constexpr int kRawStride = 36;                        // 3 + 31 bytes -> 9 dwords
+constexpr int kRawStride = 40;                        // 3 + 31 bytes -> 9 dwords, staged as five 8-byte pairs
 constexpr int kBlurRows = 2 * kBriefReach + 1;        // 37
 constexpr int kBlurStride = 40;                       // 3 + 37 bytes -> 10 dwords
 constexpr int kPatchLds = kRawRows * kRawStride + kBlurRows * kBlurStride;   // 2596 bytes per keypoint (dword multiple)
@@ -247,31 +247,37 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     const int blurCol0 = kx - kBriefReach;
     blurMis = blurCol0 & 3;
     {
-        constexpr int kRawDw = kRawStride / 4, kBlurDw = kBlurStride / 4;            // 9, 10 dwords per tile row
-        constexpr int kRawSteps = (kRawRows + 2) / 3, kBlurSteps = (kBlurRows + 2) / 3;   // 11, 13
-        static_assert(kRawDw == 9 && kBlurDw == 10, "the multiply-shift divisions below are for 9 and 10");
-        const int rr = (hl * 57) >> 9, rc = hl - rr * kRawDw;     // hl / 9 for hl < 32: lanes 0..26: row (mod 3) and dword column of the raw tile
-        const int br = (hl * 52) >> 9, bcw = hl - br * kBlurDw;   // hl / 10 for hl < 32: lanes 0..29: the same for the blurred tile
-        const bool rawLane = hl < 3 * kRawDw;
-        // the last dword of a blurred row can start past the row's padded end when the patch touches the right edge
-        const bool blurLane = hl < 3 * kBlurDw && blurCol0 - blurMis + 4 * bcw < blurStride;
-        const int rOff = __mul24(kEdge + ky - kHalfPatch + rr, pyrStride) + (rawCol0 - rawMis) + 4 * rc;   // 24-bit: full-rate multiplies
-        const int bOff = __mul24(ky - kBriefReach + br, blurStride) + (blurCol0 - blurMis) + 4 * bcw;
-        unsigned wr[kRawSteps], wb[kBlurSteps];
+        // 8-byte loads (4-byte aligned: one global_load_dwordx2 each): a half-wave covers SIX tile rows per step (lane = (row % 6, dword pair)), 6 + 7
+        // load instructions per wave instead of 11 + 13 with dword loads - the patch gather is bound by the L1's rate of line look-ups (0.9 per cycle
+        // and CU in this kernel: profiles/r04_l1_l2_counters.md), and a wave instruction's look-ups go with its 16-lane groups x the lines each touches
+        constexpr int kPairs = 5, kRowsPerStep = 6;
+        static_assert(kRawStride == 8 * kPairs && kBlurStride == 8 * kPairs, "tile rows are five 8-byte pairs");
+        constexpr int kRawSteps = (kRawRows + kRowsPerStep - 1) / kRowsPerStep, kBlurSteps = (kBlurRows + kRowsPerStep - 1) / kRowsPerStep;   // 6, 7
+        const int rr = (hl * 52) >> 8, rc = hl - rr * kPairs;     // hl / 5 for hl < 32: lanes 0..29: row (mod 6) and dword pair of both tiles
+        const bool stLane = hl < kRowsPerStep * kPairs;
+        // (every aligned dword that starts inside a level's padded row lies inside it: strides are multiples of 64; the pairs reach at most 9 bytes
+        //  past the raw patch - inside the 19-px border - and 3 + 3 bytes past the blurred one - inside the row, kx <= w - 20)
+        const int rOff = __mul24(kEdge + ky - kHalfPatch + rr, pyrStride) + (rawCol0 - rawMis) + 8 * rc;   // 24-bit: full-rate multiplies
+        const int bOff = __mul24(ky - kBriefReach + rr, blurStride) + (blurCol0 - blurMis) + 8 * rc;
+        uint2 wr[kRawSteps], wb[kBlurSteps];
+#pragma unroll
+        for (int s = 0; s < kRawSteps; s++) {
+            wr[s] = uint2{0u, 0u};
+            if (stLane && rr + kRowsPerStep * s < kRawRows) __builtin_memcpy(&wr[s], pyrL + ((unsigned)rOff + (unsigned)(kRowsPerStep * s * pyrStride)), 8);   // uniform base + u32 offset
+        }
+#pragma unroll
+        for (int s = 0; s < kBlurSteps; s++) {
+            wb[s] = uint2{0u, 0u};
+            if (stLane && rr + kRowsPerStep * s < kBlurRows) __builtin_memcpy(&wb[s], blurL + ((unsigned)bOff + (unsigned)(kRowsPerStep * s * blurStride)), 8);
+        }
+        uint8_t* rdst = rawT + rr * kRawStride + 8 * rc;
+        uint8_t* bdst = blurT + rr * kBlurStride + 8 * rc;
 #pragma unroll
         for (int s = 0; s < kRawSteps; s++)
-            wr[s] = (rawLane && rr + 3 * s < kRawRows) ? *(const unsigned*)(pyrL + ((unsigned)rOff + (unsigned)(3 * s * pyrStride))) : 0u;   // uniform base + u32 offset
+            if (stLane && rr + kRowsPerStep * s < kRawRows) *(uint2*)(rdst + kRowsPerStep * s * kRawStride) = wr[s];
 #pragma unroll
         for (int s = 0; s < kBlurSteps; s++)
-            wb[s] = (blurLane && br + 3 * s < kBlurRows) ? *(const unsigned*)(blurL + ((unsigned)bOff + (unsigned)(3 * s * blurStride))) : 0u;
-        uint8_t* rdst = rawT + rr * kRawStride + 4 * rc;
-        uint8_t* bdst = blurT + br * kBlurStride + 4 * bcw;
-#pragma unroll
-        for (int s = 0; s < kRawSteps; s++)
-            if (rawLane && rr + 3 * s < kRawRows) *(unsigned*)(rdst + 3 * s * kRawStride) = wr[s];
-#pragma unroll
-        for (int s = 0; s < kBlurSteps; s++)
-            if (hl < 3 * kBlurDw && br + 3 * s < kBlurRows) *(unsigned*)(bdst + 3 * s * kBlurStride) = wb[s];
+            if (stLane && rr + kRowsPerStep * s < kBlurRows) *(uint2*)(bdst + kRowsPerStep * s * kBlurStride) = wb[s];
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
