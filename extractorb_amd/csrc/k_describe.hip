@@ -184,24 +184,31 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
     uint8_t* blurT;
     int blurMis;
     if constexpr (PB) {
-        // ---- stage the raw 43 x 44 tile, re-aligned: 16 lanes per tile row (12 load a source dword, 11 store a re-aligned one), two rows per step ----
+        // ---- stage the raw 43 x 44 tile, re-aligned: 8 lanes per tile row (6 load an 8-byte pair of source dwords - 4-byte aligned: one
+        //      global_load_dwordx2 -, 11 re-aligned dwords stored), four rows per step: 11 load instructions per wave (dword loads: 22; the gather is bound
+        //      by the L1's look-up rate: profiles/r04_l1_l2_counters.md) ----
         uint8_t* rawT = smem + (wave * 2 + half) * kPbLds;
         blurT = rawT + kPbRawBytes;
         blurMis = 0;
-        constexpr int kSteps = (kPbRows + 1) / 2;            // 22
-        const int l16 = hl & 15, rsub = hl >> 4;
+        constexpr int kSteps = (kPbRows + 3) / 4;            // 11
+        const int l8 = hl & 7, rsub = hl >> 3;
         const int col0 = kPadL + kx - (kBriefReach + 4), mis = col0 & 3;
-        const int rOff = __mul24(kEdge + ky - (kBriefReach + 3) + rsub, pyrStride) + (col0 - mis) + 4 * l16;
-        unsigned wr[kSteps];
-#pragma unroll
-        for (int s = 0; s < kSteps; s++)
-            wr[s] = (l16 < 12 && rsub + 2 * s < kPbRows) ? *(const unsigned*)(pyrL + ((unsigned)rOff + (unsigned)(2 * s * pyrStride))) : 0u;
-        uint8_t* rdst = rawT + rsub * kPbStride + 4 * l16;
+        const int rOff = __mul24(kEdge + ky - (kBriefReach + 3) + rsub, pyrStride) + (col0 - mis) + 8 * l8;
+        uint2 wr[kSteps];
 #pragma unroll
         for (int s = 0; s < kSteps; s++) {
-            const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wr[s], 0x101, 0xF, 0xF, false);      // row_shl:1: the next dword of the same tile row
-            const unsigned v = __builtin_amdgcn_alignbyte(nxt, wr[s], (unsigned)mis);
-            if (l16 < 11 && rsub + 2 * s < kPbRows) *(unsigned*)(rdst + 2 * s * kPbStride) = v;
+            wr[s] = uint2{0u, 0u};
+            if (l8 < 6 && rsub + 4 * s < kPbRows) __builtin_memcpy(&wr[s], pyrL + ((unsigned)rOff + (unsigned)(4 * s * pyrStride)), 8);
+        }
+        uint8_t* rdst = rawT + rsub * kPbStride + 8 * l8;
+#pragma unroll
+        for (int s = 0; s < kSteps; s++) {
+            const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wr[s].x, 0x101, 0xF, 0xF, false);      // row_shl:1: the next pair's first dword (same tile row for l8 < 5)
+            const unsigned v0 = __builtin_amdgcn_alignbyte(wr[s].y, wr[s].x, (unsigned)mis), v1 = __builtin_amdgcn_alignbyte(nxt, wr[s].y, (unsigned)mis);
+            if (l8 < 6 && rsub + 4 * s < kPbRows) {
+                *(unsigned*)(rdst + 4 * s * kPbStride) = v0;
+                if (l8 < 5) *(unsigned*)(rdst + 4 * s * kPbStride + 4) = v1;      // (a tile row is 11 dwords: the sixth pair stores its first only)
+            }
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
