@@ -609,7 +609,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                 int need = q + 4 <= 256 ? 256 : (q + 4 <= 512 ? 512 : residentT);
                 if (need < residentT) residentT = need;
             }
-            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : h->octThreads[l];
+            // queued launches whose first sweep k_fast has done: the same chain of barriers, and the 256-thread workgroup wins at every frame size
+            // (128 x 1080p: 87 us with 1024 threads, 57 with 512, 50 with 256; 64 x 1080p: 49 / 34 / 28; 128 x 720p: 87 / 57 / 46) - the sizes by
+            // image area were measured with the sweep inside the kernel, where a level-0 workgroup reads ~60 k candidates
+            const int queuedT = lt.hist && !h->octThreadsForced ? 256 : 0;
+            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : (queuedT ? queuedT : h->octThreads[l]);
             pollute(st);
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
