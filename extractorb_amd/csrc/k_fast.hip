@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
                         atomicAdd(&tHist[li], 1u);
                         atomicMax(&tBest[li], val);
                     } else {
-                        const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                        const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
                         atomicAdd(lt.hist + cellOfRoot, 1);
                         atomicMax(lt.best + cellOfRoot, val);
                     }
@@ -418,8 +418,9 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
         for (int e = lane; e < nLeafLocal; e += 64) {
             const unsigned n = tHist[e];
             if (n) {
-                const int xc = xc0 + e % nxl, yc = yc0 + e / nxl;
-                const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                const int er = (int)(((float)e + 0.5f) * __frcp_rn((float)nxl));      // e / nxl (exact: e < 1024, the quotient is >= 0.5 / nxl away from an integer)
+                const int xc = xc0 + (e - er * nxl), yc = yc0 + er;
+                const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
                 atomicAdd(lt.hist + cellOfRoot, (int)n);
                 atomicMax(lt.best + cellOfRoot, tBest[e]);
             }
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
                             atomicAdd(&tHist[li], 1u);
                             atomicMax(&tBest[li], val);
                         } else {
-                            const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                            const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
                             atomicAdd(lt.hist + cellOfRoot, 1);
                             atomicMax(lt.best + cellOfRoot, val);
                         }
@@ -646,8 +647,9 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
         for (int e = tid; e < nLeafLocal; e += 256) {
             const unsigned n = tHist[e];
             if (n) {
-                const int xc = xc0 + e % nxl, yc = yc0 + e / nxl;
-                const long long cellOfRoot = ((long long)(f * lt.nlevels + c.level) * lt.R + (xc >> kOctDepth)) * kOctLeaves + ((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+                const int er = (int)(((float)e + 0.5f) * __frcp_rn((float)nxl));      // e / nxl (exact: e < 1024, the quotient is >= 0.5 / nxl away from an integer)
+                const int xc = xc0 + (e - er * nxl), yc = yc0 + er;
+                const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
                 atomicAdd(lt.hist + cellOfRoot, (int)n);
                 atomicMax(lt.best + cellOfRoot, tBest[e]);
             }

@@ -851,6 +851,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 128;
     if (h->leafFrames > max_batch) h->leafFrames = max_batch;
     if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree
+    // (k_fast indexes the tables with 32 bits: cap the frames so that frames x levels x roots x 1024 stays below 2^30 entries)
+    if (h->leafFrames && (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves >= ((size_t)1 << 30)) h->leafFrames = (int)((((size_t)1 << 30) - 1) / ((size_t)nlevels * h->octR * kOctLeaves));
     if (h->leafFrames) {
         const size_t n = (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves;
         CREATE_ALLOC(h->d_leafHist, n * sizeof(int));
