@@ -115,9 +115,16 @@ def _descriptors(v, rng, n):
     return d
 
 
+def _seed(cfg):
+    """a seed per configuration that is the same in every process (the built-in hash of a str is salted per interpreter run: with it one run in
+    eleven drew a ragged vocabulary that missed the sanity thresholds below - the equalities held on every draw)"""
+    import zlib
+    return zlib.crc32(str(sorted(cfg.items())).encode()) % 2 ** 31
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
 def test_oracle_bow_equals_independent_statement(cfg):
-    rng = np.random.default_rng(hash(str(cfg)) % 2 ** 31)
+    rng = np.random.default_rng(_seed(cfg))
     v = _vocab_for(cfg, rng)
     d = _descriptors(v, rng, 400)
     lu = cfg.get("levelsup", min(4, v["L"] - 1))
@@ -143,7 +150,7 @@ def test_bow_of_real_descriptors_groups_features_by_node():
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
 def test_gpu_bow_equals_oracle(cfg, tmp_path):
     import torch
-    rng = np.random.default_rng(hash(str(cfg)) % 2 ** 31 + 1)
+    rng = np.random.default_rng(_seed(cfg) + 1)
     v = _vocab_for(cfg, rng)
     lu = cfg.get("levelsup", min(4, v["L"] - 1))
     path = tmp_path / "voc.txt"
