@@ -388,6 +388,11 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         if (h->octThreadsForced == 256 || h->octThreadsForced == 512 || h->octThreadsForced == 1024) T = h->octThreadsForced;
         for (int l = 0; l < g.nlevels; l++) h->octThreads[l] = T;
     }
+    // The tables above went up with hipMemcpy from pageable host vectors; the kernels that read them run on h->stream, a NON-BLOCKING stream that does
+    // not order itself behind the null stream.  Wait for the device here, once per geometry, so that no first call can start before a staged copy
+    // has landed (a seeded fuzz run saw ONE frame in ~8000 first calls with wrong border bytes in level 0 and every other stage right; it did not
+    // reproduce, with or without poisoned memory - this closes the one ordering the code did not state).
+    HIP_TRY(h, hipDeviceSynchronize());
     h->geom = g;
     return ORBX_OK;
 }
@@ -926,6 +931,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
             return bail(ORBX_ERR_UNSUPPORTED);
         }
     }
+    // hipMemset is asynchronous to the host: the arenas' zero fill (and the poison) must be over before a first call's kernels - on a non-blocking
+    // stream, which does not wait for the null stream - write into them
+    CREATE_TRY(hipDeviceSynchronize());
 #undef CREATE_TRY
     h->geom = FrameGeom();   // installed on first use
     *out = h;
@@ -1600,6 +1608,7 @@ int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int
         orbx_vocabulary_destroy(v);
         return ORBX_ERR_HIP;
     }
+    if (hipDeviceSynchronize() != hipSuccess) { orbx_vocabulary_destroy(v); return ORBX_ERR_HIP; }      // (the tables have landed before any handle's stream reads them: installGeometry has the reason)
     *out = v;
     return ORBX_OK;
 }

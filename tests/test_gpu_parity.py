@@ -26,7 +26,7 @@ def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
         for l in range(nlevels):
             both["gpu_candidates_%d" % l], both["oracle_candidates_%d" % l] = ex.debug_candidates(l, frame), o.candidates(l)
             both["gpu_level_keys_%d" % l], both["oracle_level_keys_%d" % l] = lvl_gpu[l], o.level_keypoints(l)
-            both["gpu_pyramid_%d" % l], both["oracle_pyramid_%d" % l] = ex.image_pyramid_level(l, frame), o.level(l)
+            both["gpu_pyramid_%d" % l], both["oracle_pyramid_%d" % l] = ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)      # (bordered: the interior is inside)
         fail_with_dump(msg, frame=frame, quotas=o.features_per_level, **both)
 
     for l in range(nlevels):
