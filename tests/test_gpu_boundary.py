@@ -187,3 +187,20 @@ def test_the_benchmarks_own_batch_shapes(shape, nf, B):
     assert ex.last_forms()[2] == (3 if shape[0] == 1080 else 0), ex.last_forms()      # 1080p x 2000: the blur per keypoint inside k_describe; 640x480 x 1000: k_blur (beside FAST)
     out2 = ex.extract_batch(frames[::-1].copy())          # the same handle again: what the timed steps of bench.py do
     assert_same_result(out2[B - 1][:3], out[0][:3], "second call")
+
+
+def test_first_call_on_fresh_handles_has_every_border_byte():
+    """The first call of a NEW handle follows the geometry tables' upload and the arenas' zero fill, which go through the null stream while the
+    kernels run on a non-blocking stream (orbx_create / installGeometry end with a device synchronisation: DESIGN.md section 4j).  Thirty fresh handles,
+    three sizes, first call each: every bordered level (interior + its BORDER_REFLECT_101 frame) against the oracle."""
+    import test_gpu_parity as P
+    for rows, cols, nl, sf in ((432, 1014, 2, 1.5), (480, 640, 8, 1.2), (333, 517, 4, 1.3)):
+        img = synth.frames("natural", 3, 1, rows, cols)[0]
+        o, _ = P.oracle_run(img, 600, (0, 1000), nl, sf, 20, 7)
+        want = [o.level(l, bordered=True) for l in range(nl)]
+        for rep in range(10):
+            ex = X.ORBextractor(600, sf, nl, 20, 7, max_width=cols, max_height=rows)
+            ex(img)
+            for l in range(nl):
+                got = ex.image_pyramid_level(l, 0, bordered=True)
+                assert np.array_equal(got, want[l]), "handle %d, %dx%d level %d: %d bytes of the bordered level differ" % (rep, cols, rows, l, int((got != want[l]).sum()))
