@@ -272,8 +272,7 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
         // four CONSECUTIVE rows at 12 dwords per row start at banks 0, 12, 24, 4: the fourth collides with the first (every read of the pass
         // 2-way).  Rows 0, 2, 4, 6 start at 0, 24, 16, 8 (and 1, 3, 5, 7 at 12, 4, 28, 20): disjoint.  The order of the items does not matter here.
         if (DW == 12 && nq == 8) y = ((y & 3) << 1) | (y >> 2);
-        for (; y < ch;) {
-            const uint8_t* base = tile + y * TS + 4 * (q0 + qi);                 // row y = centre row - 3
+        auto scoreItem = [&](const uint8_t* base, uint8_t* dst, const unsigned m) {      // base: the item's dword in tile row y (= centre row - 3); dst: in score row y + 1
             unsigned L[7], C[7], R[7];
 #pragma unroll
             for (int d = 0; d < 7; d++) {
@@ -288,11 +287,23 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
             const unsigned sA = pairScore(rA);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned sB = pairScore(rB);
-            unsigned m = qi == 0 ? maskFirst : 0xFFFFFFFFu;
-            m = qi == nq - 1 ? (m & maskLast) : m;
-            *(unsigned*)(score + (y + 1) * TS + 4 * (q0 + qi)) = __builtin_amdgcn_perm(sB, sA, 0x06040200u) & m;
-            qi += sx; y += sy;
-            if (qi >= nq) { qi -= nq; y++; }
+            *(unsigned*)dst = __builtin_amdgcn_perm(sB, sA, 0x06040200u) & m;
+        };
+        if (sx == 0) {
+            // the items of a row divide the wave (8 items: the usual 29..32-px cells; 1, 2, 4, 16): a lane keeps its item column, so its edge mask is
+            // fixed and a trip is "sy rows further": two pointer steps and a compare instead of re-deriving (item, row), the masks and the address
+            const unsigned m = (qi == 0 ? maskFirst : 0xFFFFFFFFu) & (qi == nq - 1 ? maskLast : 0xFFFFFFFFu);
+            const uint8_t* base = tile + y * TS + 4 * (q0 + qi);
+            uint8_t* dst = score + (y + 1) * TS + 4 * (q0 + qi);
+            for (; y < ch; y += sy, base += sy * TS, dst += sy * TS) scoreItem(base, dst, m);
+        } else {
+            for (; y < ch;) {
+                unsigned m = qi == 0 ? maskFirst : 0xFFFFFFFFu;
+                m = qi == nq - 1 ? (m & maskLast) : m;
+                scoreItem(tile + y * TS + 4 * (q0 + qi), score + (y + 1) * TS + 4 * (q0 + qi), m);
+                qi += sx; y += sy;
+                if (qi >= nq) { qi -= nq; y++; }
+            }
         }
     }
     waveLdsSync();
@@ -309,10 +320,10 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
         const unsigned thPair = (unsigned)minTh | ((unsigned)minTh << 16);
         const int sy = (64 * c.itemRecip) >> 16, sx = 64 - sy * nq;
         int y = (lane * c.itemRecip) >> 16, qi = lane - y * nq;
-        for (int item0 = 0; item0 < nItems; item0 += 64) {
-            // score row y = the row above the centre row.  Lanes past the last item (y >= ch) take centre row ch + 1, the zero row below the
-            // interior: S = 0 keeps nothing, so the pass needs no "active" predicate
-            const uint8_t* base = score + min(y, ch) * TS + 4 * (q0 + qi);
+        // one trip of 64 items: base = the item's dword in score row y (the row above the centre row), xy = x | y << 6 of its pixel 0 (x may be
+        // "negative": only kept pixels are used).  Lanes past the last item (y >= ch) take centre row ch + 1, the zero row below the interior: S = 0
+        // keeps nothing, so the pass needs no "active" predicate
+        auto nmsTrip = [&](const uint8_t* base, const unsigned xy) {
             unsigned U[3], M[3], D[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -339,13 +350,23 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
                 int at = nMin;                           // + kept pixels of the lower lanes: one v_mbcnt pair per ballot
                 at = __builtin_amdgcn_mbcnt_hi((unsigned)(bA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bA, at));
                 at = __builtin_amdgcn_mbcnt_hi((unsigned)(bB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bB, at));
-                const unsigned xy = (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6);   // pixel 0 of the dword (x may be "negative": only kept pixels are used)
                 if (fA) { const bool hi = dA > 0xFFFFu; list[at++] = (xy + (hi ? 1u : 0u)) | ((hi ? sA >> 16 : sA & 0xFFFFu) << 12); }
                 if (fB) { const bool hi = dB > 0xFFFFu; list[at] = (xy + (hi ? 3u : 2u)) | ((hi ? sB >> 16 : sB & 0xFFFFu) << 12); }
                 nMin += __popcll(bA) + __popcll(bB);
             }
-            qi += sx; y += sy;
-            if (qi >= nq) { qi -= nq; y++; }
+        };
+        const int trips = (nItems + 63) >> 6;
+        if (sx == 0) {      // a lane keeps its item column (scoreItem has the reason): a trip is sy rows further
+            const uint8_t* base = score + y * TS + 4 * (q0 + qi);
+            const uint8_t* const baseEnd = score + ch * TS + 4 * (q0 + qi);
+            unsigned xy = (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6);
+            for (int t = 0; t < trips; t++, base += sy * TS, xy += (unsigned)sy << 6) nmsTrip(base < baseEnd ? base : baseEnd, xy);
+        } else {
+            for (int t = 0; t < trips; t++) {
+                nmsTrip(score + min(y, ch) * TS + 4 * (q0 + qi), (unsigned)(4 * (q0 + qi) - (mis + 3)) + ((unsigned)y << 6));
+                qi += sx; y += sy;
+                if (qi >= nq) { qi -= nq; y++; }
+            }
         }
     }
     waveLdsSync();
