@@ -640,9 +640,10 @@ def main():
             for a in pin:
                 X.pinned_free(a)
             del hx
-            # (b) BASELINE.json configs[2] as a secondary figure: 1920x1080, 2000 features, device-resident, 64 frames per call
+            # (b) BASELINE.json configs[2] as a secondary figure: 1920x1080, 2000 features, device-resident, the workload's own frames per call
+            #     (128: what `--workload hd1080` times; rounds 1-4 quoted this figure at 64 frames per call)
             w2 = WORKLOADS["hd1080"]
-            B2 = 64
+            B2 = w2["batch"]
             f2 = torch.from_numpy(synth.frames("noise", 0, 16, w2["rows"], w2["cols"])).cuda().repeat(B2 // 16, 1, 1).contiguous()
             e2 = X.ORBextractor(w2["nfeatures"], 1.2, 8, 20, 7, max_width=w2["cols"], max_height=w2["rows"], max_batch=B2, device=local_rank)
             e2.set_stream(stream.cuda_stream)
