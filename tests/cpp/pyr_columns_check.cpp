@@ -63,6 +63,30 @@ int main(int argc, char** argv) {
                 lvl[l][(size_t)y * w + x] = (uint8_t)resizePx(s[(size_t)cy.sx0 * sw + cx.sx0], s[(size_t)cy.sx0 * sw + cx.sx1], s[(size_t)cy.sx1 * sw + cx.sx0], s[(size_t)cy.sx1 * sw + cx.sx1], cx, cy);
             }
     }
+    // the FAST cells' item reciprocal (CellDesc::itemRecip): k_fast deals lanes, k_fast_wide threads, to (row, item) with it
+    for (const CellDesc& c : g.cells) {
+        const int nq = fastItemsPerRow(c.roiW - 6);
+        if (nq < 1 || nq > 16) FAIL("cell %d of level %d: %d items per row", c.cellId, c.level, nq);
+        for (int x = 0; x <= 256; x++)
+            if ((x * c.itemRecip) >> 16 != x / nq) FAIL("cell %d of level %d: itemRecip %d gives %d / %d wrong", c.cellId, c.level, c.itemRecip, x, nq);
+    }
+    // the tile resize's dword-column records (FrameGeom::xq): taps and weights of the four bytes as the level tables have them
+    for (int l = 1; l < nlevels; l++) {
+        if (!g.packedTaps[l]) { if (!g.xq[l].empty()) FAIL("level %d: column records without packed taps", l); continue; }
+        const int nd = (kPadL - kEdge + g.lv[l].w + 2 * kEdge + 3) / 4, wB = g.lv[l].w + 2 * kEdge;
+        if ((int)g.xq[l].size() != nd) FAIL("level %d: %zu column records for %d dword columns", l, g.xq[l].size(), nd);
+        for (int dw = 0; dw < nd; dw++)
+            for (int j = 0; j < 4; j++) {
+                int bx = 4 * dw + j - (kPadL - kEdge);
+                bx = bx < 0 ? 0 : (bx > wB - 1 ? wB - 1 : bx);
+                const ResizeX want = g.rx[l][refl(bx - kEdge, g.lv[l].w)];
+                const QuadRec& q = g.xq[l][dw];
+                const int t0 = (int)(q.sel[j] & 0xff), t1 = (int)((q.sel[j] >> 16) & 0xff);
+                if ((q.sel[j] & 0xff00ff00u) != 0x0C000C00u || t0 > 7 || t1 > 7 || q.pad[0] + t0 != want.sx0 || q.pad[0] + t1 != want.sx1 ||
+                    (short)(q.wt[j] & 0xffff) != want.a0 || (short)(q.wt[j] >> 16) != want.a1)
+                    FAIL("level %d dword column %d byte %d: column record differs from the level table", l, dw, j);
+            }
+    }
     int checked = 0;
     for (const std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
     for (const FrameGeom::ColumnSet& cs : *sets) {
@@ -89,6 +113,17 @@ int main(int argc, char** argv) {
             int off = 0, total = 0;      // 8-byte units: per level the quad records (six units each), then the row records (two units each)
             for (int l = 1; l < nlevels; l++) total += 6 * ((c.region[l].w + 3) / 4) + 2 * c.region[l].h;
             if (total != c.nCoef || total > kChainCoefMax || total > cs.coefSlot) FAIL("px %d region %zu: %d coefficient records, nCoef %d, slot %d", cs.px, ci, total, c.nCoef, cs.coefSlot);
+            // the host-made dealing of the deriving threads (ChainDeal): the reciprocal gives tid / quads exactly for every thread of the largest
+            // workgroup, the row blocks times the quads fit the role's threads, and the blocks cover the rectangle's rows
+            for (int l = 1; l < nlevels; l++)
+                for (int v = 0; v < 2; v++) {
+                    const ChainDeal d = c.deal[v][l];
+                    const int TD = v ? 512 : 256, nq = (c.region[l].w + 3) / 4;
+                    if (d.nb != TD / nq || d.nb < 1 || d.nb * nq > TD || (int)d.per * d.nb < c.region[l].h || ((int)d.per - 1) * d.nb >= c.region[l].h)
+                        FAIL("px %d region %zu level %d: dealing for %d threads: %d blocks of %d rows over %d quads x %d rows", cs.px, ci, l, TD, d.nb, d.per, nq, c.region[l].h);
+                    for (int tid = 0; tid < 1024; tid++)
+                        if ((int)(((unsigned)tid * d.recip) >> 20) != tid / nq) FAIL("px %d region %zu level %d: reciprocal %u gives tid %d / %d wrong", cs.px, ci, l, d.recip, tid, nq);
+                }
             std::vector<uint8_t> cur, nxt;
             for (int l = 0; l < nlevels; l++) {
                 const ChainRegion r = c.region[l];
