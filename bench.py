@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even at N = 1 (what --gpus N > 1 does "
                     "by itself when no launcher set RANK)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed slab")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0, help="N = 1: length of the sustained-load window behind the timed steps "
+                    "(secondary.sustained; 0 = skip; --no-extras skips it too)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --stub-extractor)")
     ap.add_argument("--stub-extractor", action="store_true", help="REHEARSAL, not a measurement: CPU tensors, the result slabs written by the "
                     "oracle instead of the HIP path, so that the N > 1 control flow of this file (double-buffered slabs, the asynchronous gather, "
@@ -326,6 +328,9 @@ def main():
         gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(len(slabs))]
     pending = [None] * len(slabs)      # the gather that last read slab k (and last wrote gathered[k])
     counter = [0]
+    # what the gather costs the step (SCALE diagnostics): the time `pending[k].wait()` holds up the slab's next writer - on the host (gloo
+    # blocks the caller) and on the handle's stream (RCCL's wait is a stream dependency: measured between two events around it)
+    exposed = dict(on=False, host_s=0.0, events=[])
     corrupt_rank = int(os.environ.get("ORBX_BENCH_TEST_CORRUPT_RANK", "-1"))      # tests/test_bench_world2.py: a wrong slab must fail the run
 
     def step():
@@ -338,7 +343,16 @@ def main():
             # slab k is about to be overwritten by handle j on ITS stream: that stream, not torch's current one, has to wait
             # for the gather that is still reading the slab
             with on_stream(streams[j]):
+                if exposed["on"]:
+                    ta = time.perf_counter()
+                    if not stub:
+                        ea = torch.cuda.Event(enable_timing=True); ea.record()
                 pending[k].wait()
+                if exposed["on"]:
+                    exposed["host_s"] += time.perf_counter() - ta
+                    if not stub:
+                        eb = torch.cuda.Event(enable_timing=True); eb.record()
+                        exposed["events"].append((ea, eb))
             pending[k] = None
         if color:
             e_.gray_from_color_device(B, d_color, rows, cols, color, False, d_img)     # Tracking.cc:991-993 (mbRGB = 0: BGR)
@@ -382,15 +396,34 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    exposed["on"] = gather
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    exposed["on"] = False
+    kl_timed = (counter[0] - 1) % len(slabs)      # the slab the LAST TIMED step wrote (what `verified` checks)
+    multi = None
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # every rank's own clock and exposed gather time in ONE all-reduce: slot r / world + r are written by rank r only, MAX collects them
+        # (and the first `world` slots' maximum is the step time the line reports: the slowest rank)
+        stall_ms = sum(a.elapsed_time(b) for a, b in exposed["events"]) if exposed["events"] else 0.0
+        t = torch.zeros(3 * world, dtype=torch.float64, device=dev)
+        t[rank] = elapsed
+        t[world + rank] = exposed["host_s"] * 1e3
+        t[2 * world + rank] = stall_ms
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        th = t.cpu().numpy()
+        elapsed = float(th[:world].max())
+        K_ = max(args.steps, 1)
+        multi = dict(per_rank_ms_per_step=[round(float(v) / K_ * 1e3, 4) for v in th[:world]],
+                     gather_exposed_ms=dict(host_blocked_ms_per_step=[round(float(v) / K_, 4) for v in th[world:2 * world]],
+                                            stream_stalled_ms_per_step=[round(float(v) / K_, 4) for v in th[2 * world:]],
+                                            note="per rank: time the wait for the previous gather of a slab held up that slab's next step - on the host "
+                                                 "(the caller blocked in wait(): gloo) and on the handle's stream (between two events around the wait: "
+                                                 "RCCL's wait is a stream dependency); 0 = the gather was over before the slab was needed again")
+                     if gather else None)
     base = slabs[0].data_ptr()
     n_host = slabs[0][off_n:off_n + 4 * B].cpu().numpy().view(np.int32)
     fps = N * B * args.steps / elapsed
@@ -451,7 +484,7 @@ def main():
     if rank == 0 and not args.no_verify and args.steps > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O      # the checker; never the product path
-        kl = (counter[0] - 1) % len(slabs)
+        kl = kl_timed
         orc = O.Oracle(nf, 1.2, 8, 20, 7)
 
         def check(slab_t, r, picks_):
@@ -492,6 +525,31 @@ def main():
         if bad:
             print("bench.py: TIMED RESULTS DIFFER FROM THE ORACLE on (rank, frame) %s" % bad, file=sys.stderr, flush=True)
 
+    # ---- rank 0's kernels WITH the gather running (N > 1 diagnostics): RCCL's receive kernels take CUs on rank 0 while its own k_fast wants
+    #      every issue slot; the event profile of the same steps shows it as a number next to roofline.kernel_ms_per_step (no gather).
+    #      Every rank runs the same steps (the gather is a collective); only rank 0 brackets its kernels with events. ----
+    if multi is not None and gather and not stub:
+        psteps_g = max(3, min(args.steps, 10))
+        if rank == 0:
+            ex.profile(True)
+        step()
+        fence()
+        if rank == 0:
+            ex.profile(True)      # (resets the slots)
+        for _ in range(psteps_g):
+            step()
+        fence()
+        if rank == 0:
+            pg = ex.profile_read()
+            ex.profile(False)
+            multi["rank0_kernel_ms_per_step"] = {k: round(v[0] / psteps_g, 4) for k, v in sorted(pg.items()) if k.startswith("k_") and v[1] > 0}
+            multi["rank0_kernel_ms_note"] = ("HIP-event profile of %d steps on rank 0 with the asynchronous gather of the previous step's slab running beside "
+                                             "them (event profiling serialises the handle's own launches: compare with roofline.kernel_ms_per_step, the same "
+                                             "profile without a gather)" % psteps_g)
+    elif multi is not None:
+        multi["rank0_kernel_ms_per_step"] = None
+        multi["rank0_kernel_ms_note"] = "not measured: " + ("--stub-extractor rehearsal (no HIP kernels)" if stub else "gather disabled")
+
     result = None
     if rank == 0 and stub:
         result = {"metric": "REHEARSAL of bench.py's control flow (--stub-extractor): not a measurement", "value": None, "unit": "frames/s", "n_gpus": N,
@@ -499,7 +557,8 @@ def main():
                   "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "stub": True, "backend": args.backend,
                   "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "variant": variant, "frames_per_gpu_per_step": B,
                              "global_frames_per_step": N * B, "extractor": "oracle (CPU restatement) writing the slabs"},
-                  "verified": verified, "roofline": None, "cpu_baseline": None, "secondary": ({"configs4_64_per_gpu": cfg5} if cfg5 else None)}
+                  "verified": verified, "roofline": None, "cpu_baseline": None, "multi_gpu": multi,
+                  "secondary": ({"configs4_64_per_gpu": cfg5} if cfg5 else None)}
         print(json.dumps(result), flush=True)
     if rank == 0 and not stub:
         # ---- per-kernel durations, HIP events on the handle's stream (separate, untimed pass) ----
@@ -614,6 +673,70 @@ def main():
                               "host cores visible to the box, cgroup_cpu_share = CPUs the box's cgroup grants, threads = oracle threads of the best run"
                               % (bestrun["frames"], variant, cols, rows, bestrun["threads"], bestrun["seconds"], n1, sec1))
         extras = {}
+        value_basis = "the %d timed steps" % args.steps
+        if N == 1 and not args.no_extras and not distributed and args.sustained_seconds > 0:
+            # ---- (0) the headline under SUSTAINED load: the same step looped for >= 5 s, the rate over the whole
+            #      window and over its last second (GPU timestamps: an event every 32 steps), and the shader clock the chip ran at meanwhile
+            #      (orbx_debug_clock_probe: a sleeping wave per CU stamps s_memtime against the 100-MHz s_memrealtime, every 256 steps, on
+            #      a side stream beside k_fast - not a poll of the SMI).  The timed window above is tens of milliseconds; a kernel at 0.99
+            #      of the issue ceiling is the worst case for power, so this is where a clock that sags shows. ----
+            ex.clock_probe(0)
+            ex.clock_read(1)                     # (first use allocates: keep that out of the window)
+            chunk, marks, nst, nprobe = 32, [], 0, 0
+            e0 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            ts0 = time.perf_counter()
+            while True:
+                for _ in range(chunk):
+                    step()
+                nst += chunk
+                em = torch.cuda.Event(enable_timing=True); em.record()
+                marks.append((nst, em))
+                if nst % (8 * chunk) == 0 and nprobe < 64:
+                    ex.clock_probe(nprobe); nprobe += 1
+                if len(marks) > 3:
+                    marks[-4][1].synchronize()      # the host stays three marks ahead of the GPU: the window ends close to the asked time
+                if time.perf_counter() - ts0 >= args.sustained_seconds:
+                    break
+            torch.cuda.synchronize()
+            tms = [e0.elapsed_time(m[1]) for m in marks]
+            total_ms = tms[-1]
+            i_last = max(i for i, v in enumerate(tms) if v <= max(total_ms - 1000.0, 0.0)) if tms[0] <= total_ms - 1000.0 else None
+            fps_all = B * nst / total_ms * 1e3
+            if i_last is not None:
+                fps_last = B * (nst - marks[i_last][0]) / (total_ms - tms[i_last]) * 1e3
+            else:
+                fps_last = fps_all
+            i_first = min(i for i, v in enumerate(tms) if v >= min(1000.0, total_ms))
+            fps_first = B * marks[i_first][0] / tms[i_first] * 1e3
+            ghz = [round(float(v), 4) for v in ex.clock_read(nprobe)] if nprobe else []
+            ghz_ok = [v for v in ghz if v > 0]
+            within = abs(fps_last - fps) <= 0.02 * fps
+            extras["sustained"] = dict(
+                seconds=round(total_ms / 1e3, 3), steps=nst, frames_per_step=B, fps=round(fps_all, 1), fps_first_second=round(fps_first, 1),
+                fps_last_second=round(fps_last, 1), ms_per_step=round(total_ms / nst, 4), ms_per_step_last_second=round(B / fps_last * 1e3, 4),
+                last_second_vs_value=round(fps_last / fps, 4), within_2_percent_of_value=bool(within),
+                shader_clock_ghz=dict(samples=ghz, first=ghz_ok[0] if ghz_ok else None, last=ghz_ok[-1] if ghz_ok else None,
+                                      min=min(ghz_ok) if ghz_ok else None, mean=round(sum(ghz_ok) / len(ghz_ok), 4) if ghz_ok else None),
+                note="the timed step looped back to back for >= %.0f s after the timed region, same slabs, same launch policy; rates from GPU "
+                     "timestamps (an event every %d steps); shader clock = delta s_memtime / delta s_memrealtime x 100 MHz over 50 us on one "
+                     "sleeping wave per CU (k_clock_probe on a side stream, every %d steps, beside the extraction kernels)" % (args.sustained_seconds, chunk, 8 * chunk))
+            if not within:
+                # the short window does not stand for the steady state: the line's value is the sustained one
+                value_basis = "secondary.sustained (the %d timed steps gave %.1f frames/s, %.4f ms per step: more than 2 %% from the last second of %.1f s of load)" % (
+                    args.steps, fps, elapsed / args.steps * 1e3, total_ms / 1e3)
+                fps = fps_all
+                elapsed = args.steps * total_ms / nst / 1e3
+                roofline["path_achieved"] = round(fps / N * b_alg / 1e9, 2)
+                roofline["path_frac"] = round(fps / N * b_alg / 1e9 / HBM_PEAK_GBS, 5)
+            clk = (sum(ghz_ok) / len(ghz_ok)) if ghz_ok else None
+            if valu is not None and clk:
+                # the issue ceiling priced at the clock the chip actually held under this load (the 4-cycle class: 1024 SIMDs x clock / 4)
+                valu["shader_clock_ghz_measured"] = round(clk, 4)
+                valu["peak_ginstr_s_at_measured_clock"] = round(1024 * clk / 4.0, 1)
+                valu["frac_at_measured_clock"] = round(valu["achieved_ginstr_s"] / (1024 * clk / 4.0), 4)
+                valu["frac_of_measured_ceiling_at_measured_clock"] = round(valu["achieved_ginstr_s"] / (1024 * clk / 4.14), 4)
         if N == 1 and args.workload == "mono640" and not args.no_extras and not distributed:
             if not args.no_verify:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -784,9 +907,10 @@ def main():
                            "projection_search_rounds_pair0": _search_rounds()} if track else {}),
                        **({"mean_words_per_frame": round(float(d_nw.float().mean().item()), 1)} if bow else {}),
                        **({"mean_bow_matches_per_pair": round(float(d_nmb.float().mean().item()), 1)} if refkf else {}),
-                       "handles_per_gpu": nH,
+                       "handles_per_gpu": nH, "policy": ex.policy(),
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
-            "verified": verified, "roofline": roofline, "cpu_baseline": cpu,
+            "value_basis": value_basis,
+            "verified": verified, "roofline": roofline, "cpu_baseline": cpu, "multi_gpu": multi,
             "secondary": ({**extras, **({"configs4_64_per_gpu": cfg5} if cfg5 else {})}) or None,
         }
         print(json.dumps(result), flush=True)

@@ -9,8 +9,10 @@ extractor without the built library or without a HIP device raises.
 """
 from .orbextractor import (KEYPOINT_DTYPE, ORBextractor, OrbxError, build_library, library_path, load_library,
                            compute_tables, compute_level_sizes, compute_cell_grid, header_symbols, camera,
-                           compute_image_bounds, pinned_empty, pinned_free, source_hash, Vocabulary)
+                           compute_image_bounds, pinned_empty, pinned_free, source_hash, Vocabulary, debug_set_option,
+                           debug_reset_options)
 
 __all__ = ["KEYPOINT_DTYPE", "ORBextractor", "OrbxError", "build_library", "library_path", "load_library",
-           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols", "camera", "compute_image_bounds", "pinned_empty", "pinned_free", "source_hash", "Vocabulary"]
+           "compute_tables", "compute_level_sizes", "compute_cell_grid", "header_symbols", "camera", "compute_image_bounds", "pinned_empty", "pinned_free", "source_hash", "Vocabulary",
+           "debug_set_option", "debug_reset_options"]
 __version__ = "0.1.0"

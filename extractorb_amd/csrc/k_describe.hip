@@ -10,8 +10,14 @@ namespace orbx {
 // ================================================================================================
 // IC_Angle + rotated BRIEF + final placement.  One wave64 per kept keypoint.
 // ================================================================================================
-__constant__ int c_umax[16];
-__constant__ __attribute__((aligned(16))) float c_patternF[1024];   // the same pattern as floats (filled by uploadUmax)
+// Both tables are the same for every extractor (HALF_PATCH_SIZE = 15 and the learned pattern are compile-time constants of the reference,
+// ORBextractor.cc:71, 148-406), so they are initialised statically: no upload, nothing for a second handle's creation to overwrite while a
+// first handle's kernels read them.  checkUmax compares the static c_umax with the table the host derives by the reference's formula (:459-474).
+constexpr int kUmaxStatic[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ __attribute__((aligned(16))) float c_patternF[1024] = {   // the rBRIEF pattern as floats
+#include "orbx_brief_pattern.inc"
+};
 
 // cv::fastAtan2: every operation rounded separately in binary32.
 __device__ __forceinline__ float fastAtan2Deg(float y, float x) {
@@ -407,15 +413,9 @@ void launchDescribe(hipStream_t st, const LevelGeom* lv, int nlevels, const uint
                            pyr, blur, sel, selPerFrame, levelCount, levelLap, outK, outD, capacity, nOut, monoOut, outLevelK,
                            outLevelCounts, f0, B, fewWaves);
 }
-static const int8_t kHostPattern[1024] = {
-#include "orbx_brief_pattern.inc"
-};
-hipError_t uploadUmax(const int* umax16) {
-    float pf[1024];
-    for (int i = 0; i < 1024; i++) pf[i] = (float)kHostPattern[i];
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_patternF), pf, sizeof(pf));
-    if (e != hipSuccess) return e;
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+bool checkUmax(const int* umax16) {      // the static device table is the one the reference's constructor computes
+    for (int i = 0; i < 16; i++) if (umax16[i] != kUmaxStatic[i]) return false;
+    return true;
 }
 
 

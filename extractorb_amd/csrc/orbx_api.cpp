@@ -36,7 +36,7 @@ void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, cons
                   unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*, LeafTables);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
                     const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, bool, int, int);
-hipError_t uploadUmax(const int* umax16);
+bool checkUmax(const int* umax16);
 hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
 struct StereoParams {
     float scale[kMaxLevels], invScale[kMaxLevels];
@@ -82,6 +82,7 @@ struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, fr
 void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
+void launchClockProbe(hipStream_t, unsigned long long*, int, int, unsigned);
 }  // namespace orbx
 
 using namespace orbx;
@@ -95,6 +96,14 @@ static const bool g_hostTiming = getenv("ORBX_HOST_TIMING") && atoi(getenv("ORBX
 static inline double nowSec() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 namespace {
+// Test aids (tests/ only).  They are NOT reachable from the environment: a test sets them through orbx_debug_set_option() before orbx_create,
+// so nothing in a deployed process's environment can poison an extractor's memory or make a call fail.
+struct TestAids {
+    int poison = -1;          // "poison": byte every device allocation of orbx_create is filled with (no kernel may depend on what hipMalloc returns)
+    int ldsPollute = -1;      // "lds_pollute": byte every CU's LDS is filled with in front of every kernel
+    int failAfterFast = 0;    // "fail_after_fast": the next handle's first call with leaf tables returns between k_fast and k_octree (one shot)
+};
+TestAids g_aids;
 enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_FRAME };
 const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
@@ -177,14 +186,17 @@ struct orbx_handle {
     size_t hInBytes = 0;
     uint8_t* h_pyr = nullptr;          // orbx_fetch_pyramid: one frame's bordered levels (allocated on first use)
     size_t hPyrBytes = 0;
+    uint8_t* h_tab = nullptr;          // installGeometry: the geometry's tables, packed, copied to the device arenas on the handle's stream
+    size_t hTabBytes = 0;
     // where the results of the last host-buffer batch are: as the kernels see them (dev: d_out, or h_out when written zero-copy) and on the host
     struct OutView { Keypoint* k = nullptr; uint8_t* d = nullptr; int* n = nullptr; int* mono = nullptr; Keypoint* lk = nullptr; int* lc = nullptr; };
     OutView dev, host;
     bool pyramidOnly = false;          // the last call was orbx_compute_pyramid: the handle holds a pyramid (and blurred levels) but no results
     bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
-    bool testFailAfterFast = false;    // ORBX_TEST_FAIL_AFTER_FAST (test aid)
+    bool testFailAfterFast = false;    // test aid "fail_after_fast" (orbx_debug_set_option)
     bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
     int lastPyrForm = -1, lastPyrCut = 0, lastBlurForm = -1;      // orbx_debug_last_forms
+    std::string lastKernel[ORBX_NUM_KERNELS];                      // the kernel (rocprofv3's name, without template arguments) that last ran in each profile slot
     int lastB = 0;
     int lastHostB = 0;           // frames whose results the handle itself holds (the result slab: h->dev / h->host): set by the host-buffer path only
     int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
@@ -192,7 +204,8 @@ struct orbx_handle {
     int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
                                        // chosen by the image area — separate launches per size measured slower)
     int octThreadsForced = 0;          // ORBX_OCT_THREADS
-    int ldsPollute = -1;               // ORBX_LDS_POLLUTE=<byte>: every CU's LDS is filled with the byte in front of every kernel (test aid)
+    int ldsPollute = -1;               // test aid "lds_pollute" (orbx_debug_set_option): every CU's LDS is filled with the byte in front of every kernel
+    std::string policy;                // the launch-policy switches as read at orbx_create (orbx_debug_policy)
     bool octRoomyForced = false;       // ORBX_OCT_ROOMY: the 128-VGPR variants whatever the batch (tests reach every variant with it)
     int numCUs = 256;
     bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
@@ -214,6 +227,9 @@ struct orbx_handle {
     int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
     unsigned short* d_rowList = nullptr;
     float *d_uRight = nullptr, *d_depth = nullptr;
+    // clock probe (orbx_debug_clock_probe: bench.py's sustained-load figure), allocated on first use
+    hipStream_t probeStream = nullptr;
+    unsigned long long* d_clock = nullptr;
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -266,20 +282,27 @@ void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_xq, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
-                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
+                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth, h->d_clock};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->aux2) (void)hipStreamDestroy(h->aux2);
+    if (h->probeStream) { (void)hipStreamSynchronize(h->probeStream); (void)hipStreamDestroy(h->probeStream); }
     for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); }
-    void* host[] = {h->h_lap, h->h_out, h->h_in, h->h_pyr};
+    void* host[] = {h->h_lap, h->h_out, h->h_in, h->h_pyr, h->h_tab};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
 }
 
-// Uploads the tables of h->geom (already laid out) and checks they fit the arenas.
+// Installs the geometry of a rows x cols image: builds its tables, checks that they fit the arenas, and uploads them.
+//
+// Ordering: every table is packed into ONE pinned staging block and copied to its device arena with hipMemcpyAsync ON THE
+// HANDLE'S STREAM, the stream every kernel of the handle is launched on (the internal side streams only ever start behind an event recorded on
+// it).  So "the tables have landed before the first kernel reads them" is stream order - stated, not assumed - and no call in this path waits
+// for the device as a whole: another handle's work on the same device is not stalled by this handle meeting a new image size.  The staging
+// block is reused by the next geometry change, which starts by waiting for this stream.
 int installGeometry(orbx_handle* h, int rows, int cols) {
     FrameGeom g;
     std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->colPx, h->blurInLevels);
@@ -291,27 +314,35 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         (size_t)(last.candOff + (long long)last.candCap * h->maxB) > h->candEntries ||
         (size_t)g.selPerFrame * h->maxB > h->selEntries || g.cells.size() > h->cellCap || g.maxNodes > h->octM)
         return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "image geometry does not fit the arenas sized at orbx_create");
-    HIP_TRY(h, hipStreamSynchronize(h->stream));   // tables may still be in use by queued work
-    h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
-    h->lastB = 0;
-    h->lastHostB = 0;
+    // ---- pass 1 (host only): pack every table, note where it goes.  A table that does not fit returns before anything is uploaded. ----
+    struct Upload { void* dst; size_t at, bytes; };
+    std::vector<uint8_t> image;
+    std::vector<Upload> ups;
+    auto stage = [&](void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        const size_t at = (image.size() + 15) & ~(size_t)15;
+        image.resize(at + bytes);
+        std::memcpy(image.data() + at, src, bytes);
+        ups.push_back(Upload{dst, at, bytes});
+    };
+    size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {}, xqOff[kMaxLevels] = {}, footOff[kMaxLevels] = {}, colsOff[8] = {}, colCoefOff[8] = {};
     size_t xo = 0, yo = 0;
     for (int l = 1; l < g.nlevels; l++) {
-        h->rxOff[l] = xo; h->ryOff[l] = yo;
+        rxOff[l] = xo; ryOff[l] = yo;
         g.lv[l].rxOff = (int)xo; g.lv[l].ryOff = (int)yo;
         if (xo + g.rx[l].size() > h->rxCap || yo + g.ry[l].size() > h->rxCap)
             return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "resize tables do not fit");
-        HIP_TRY(h, hipMemcpy(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size(), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size(), hipMemcpyHostToDevice));
+        stage(h->d_rx + xo, g.rx[l].data(), sizeof(ResizeX) * g.rx[l].size());
+        stage(h->d_ry + yo, g.ry[l].data(), sizeof(ResizeX) * g.ry[l].size());
         xo += g.rx[l].size(); yo += g.ry[l].size();
     }
     {
         size_t qo = 0;
         for (int l = 1; l < g.nlevels; l++) {
-            h->xqOff[l] = qo;
+            xqOff[l] = qo;
             if (g.xq[l].empty()) continue;      // (taps not packed: the byte-gather form reads the plain tables)
             if (qo + g.xq[l].size() > h->xqCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "resize column records do not fit");
-            HIP_TRY(h, hipMemcpy(h->d_xq + qo, g.xq[l].data(), sizeof(QuadRec) * g.xq[l].size(), hipMemcpyHostToDevice));
+            stage(h->d_xq + qo, g.xq[l].data(), sizeof(QuadRec) * g.xq[l].size());
             qo += g.xq[l].size();
         }
     }
@@ -324,15 +355,15 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
             for (int x = 0; x < L.rectW; x++) code[(size_t)l * h->octXT + x] = (uint8_t)octXCode(x, L.hX, L.nIni);
             for (int y = 0; y < L.rectH; y++) code[(size_t)(g.nlevels + l) * h->octXT + y] = (uint8_t)octAxisPath(y, 0, L.rectH);
         }
-        HIP_TRY(h, hipMemcpy(h->d_leafCode, code.data(), code.size(), hipMemcpyHostToDevice));
+        stage(h->d_leafCode, code.data(), code.size());
     }
-    HIP_TRY(h, hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size(), hipMemcpyHostToDevice));
+    stage(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels);
+    stage(h->d_cells, g.cells.data(), sizeof(CellDesc) * g.cells.size());
     size_t fo = 0;
     for (int l = 1; l < g.nlevels; l++) {
-        h->footOff[l] = fo;
+        footOff[l] = fo;
         if (fo + g.foot[l].size() > h->footCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "tile footprint table does not fit");
-        HIP_TRY(h, hipMemcpy(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size(), hipMemcpyHostToDevice));
+        stage(h->d_foot + fo, g.foot[l].data(), sizeof(TileFoot) * g.foot[l].size());
         fo += g.foot[l].size();
     }
     {
@@ -341,11 +372,11 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         for (FrameGeom::ColumnSet& cs : *sets) {
             if (n + cs.columns.size() > h->colsCap || nc + cs.coef.size() > h->colCoefCap) cs.fit = false;      // (a region size far below the default ones: the other forms serve)
             if (!cs.fit) continue;
-            HIP_TRY(h, hipMemcpy(h->d_cols + n, cs.columns.data(), sizeof(PyrColumn) * cs.columns.size(), hipMemcpyHostToDevice));
-            HIP_TRY(h, hipMemcpy(h->d_colCoef + nc, cs.coef.data(), sizeof(ResizeX) * cs.coef.size(), hipMemcpyHostToDevice));
+            stage(h->d_cols + n, cs.columns.data(), sizeof(PyrColumn) * cs.columns.size());
+            stage(h->d_colCoef + nc, cs.coef.data(), sizeof(ResizeX) * cs.coef.size());
             const size_t slot = (&cs - sets->data()) + (sets == &g.colSetsBlur ? 4 : 0);      // (at most four cuts per geometry: kColPx)
-            h->colsOff[slot] = n;
-            h->colCoefOff[slot] = nc;
+            colsOff[slot] = n;
+            colCoefOff[slot] = nc;
             n += cs.columns.size();
             nc += cs.coef.size();
         }
@@ -356,8 +387,10 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
             c.pyrOff[l] = g.lv[l].pyrOff; c.pyrFrameBytes[l] = g.lv[l].pyrFrameBytes;
             c.blurStride[l] = g.lv[l].blurStride; c.blurOff[l] = g.lv[l].blurOff; c.blurFrameBytes[l] = g.lv[l].blurFrameBytes;
         }
-        HIP_TRY(h, hipMemcpy(h->d_colLevels, &c, sizeof(c), hipMemcpyHostToDevice));
+        stage(h->d_colLevels, &c, sizeof(c));
     }
+    int nBlurLanes[3] = {0, 0, 0};
+    size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
     {   // blur tables for both row-block sizes
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
@@ -365,7 +398,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         for (int v = 0; v < 3; v++) {
             const size_t t0 = tiles.size(), l0 = laneItem.size();
             int lanes = 0;
-            if (v == 2 && h->blurInLevels >= g.nlevels) { h->nBlurLanes[v] = 0; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
+            if (v == 2 && h->blurInLevels >= g.nlevels) { nBlurLanes[v] = 0; blurItemOff[v] = t0; blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
             for (int l = 0; l < g.nlevels; l++) {
                 if (v == 2 && l < h->blurInLevels) continue;               // the region-major pyramid blurs the finest levels itself
                 for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
@@ -376,23 +409,35 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
             }
             tiles[t0].count = (int)(tiles.size() - t0);
             if (tiles.size() - t0 > 65535) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
-            h->nBlurLanes[v] = lanes; h->blurItemOff[v] = t0; h->blurLaneOff[v] = l0;
+            nBlurLanes[v] = lanes; blurItemOff[v] = t0; blurLaneOff[v] = l0;
         }
         if (tiles.size() > h->tileCap || laneItem.size() > h->laneCap) return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "blur item table does not fit");
-        HIP_TRY(h, hipMemcpy(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size(), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size(), hipMemcpyHostToDevice));
+        stage(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size());
+        stage(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size());
     }
+    // ---- pass 2: the uploads, in stream order ----
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // the device tables and the staging block may still be in use by queued work
+    h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
+    h->lastB = 0;
+    h->lastHostB = 0;
+    if (image.size() > h->hTabBytes) {
+        if (h->h_tab) (void)hipHostFree(h->h_tab);
+        h->h_tab = nullptr; h->hTabBytes = 0;
+        const size_t want = image.size() + image.size() / 4 + 4096;
+        HIP_TRY(h, hipHostMalloc(&h->h_tab, want));
+        h->hTabBytes = want;
+    }
+    std::memcpy(h->h_tab, image.data(), image.size());
+    for (const Upload& u : ups) HIP_TRY(h, hipMemcpyAsync(u.dst, h->h_tab + u.at, u.bytes, hipMemcpyHostToDevice, h->stream));
+    for (int l = 0; l < kMaxLevels; l++) { h->rxOff[l] = rxOff[l]; h->ryOff[l] = ryOff[l]; h->xqOff[l] = xqOff[l]; h->footOff[l] = footOff[l]; }
+    for (int i = 0; i < 8; i++) { h->colsOff[i] = colsOff[i]; h->colCoefOff[i] = colCoefOff[i]; }
+    for (int v = 0; v < 3; v++) { h->nBlurLanes[v] = nBlurLanes[v]; h->blurItemOff[v] = blurItemOff[v]; h->blurLaneOff[v] = blurLaneOff[v]; }
     {
         const long long px = (long long)g.lv[0].w * g.lv[0].h;
         int T = px <= 500000 ? 256 : (px <= 1200000 ? 512 : 1024);   // measured: 640x480 -> 256, 1280x720 -> 512, 1920x1080 -> 1024 (512 equal)
         if (h->octThreadsForced == 256 || h->octThreadsForced == 512 || h->octThreadsForced == 1024) T = h->octThreadsForced;
         for (int l = 0; l < g.nlevels; l++) h->octThreads[l] = T;
     }
-    // The tables above went up with hipMemcpy from pageable host vectors; the kernels that read them run on h->stream, a NON-BLOCKING stream that does
-    // not order itself behind the null stream.  Wait for the device here, once per geometry, so that no first call can start before a staged copy
-    // has landed (a seeded fuzz run saw ONE frame in ~8000 first calls with wrong border bytes in level 0 and every other stage right; it did not
-    // reproduce, with or without poisoned memory - this closes the one ordering the code did not state).
-    HIP_TRY(h, hipDeviceSynchronize());
     h->geom = g;
     return ORBX_OK;
 }
@@ -465,7 +510,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // patch reads at large frames, and the one raw tile is fewer bytes than a raw + a blurred one.  Measured (us per step, k_blur beside FAST ->
     // patch blur): 128 x 1920x1080 x 2000 (ratio 0.50) 3041-3052 -> 2717-2723; 128 x 1280x720 x 1500 (0.84) 1448-1455 -> 1358-1364; 512 x 640x480 x
     // 1000 (1.67) 1929-1937 -> 1993-2000: taken up to a ratio of 1.25.  ORBX_PATCH_BLUR=1 / 0 forces / forbids it.
-    const bool patchBlur = h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (long long)h->nfeatures * 43 * 37 * 4 <= 5LL * g.sumPixels);
+    // A back-only pass (orbx_compute_keypoints_octree) describes from what the front part of the EARLIER call left: if that call blurred per
+    // keypoint (form 3) no blurred level exists and this pass must do the same, whatever its own frame count would choose; otherwise the blurred
+    // levels exist (or are owed to the FAST launch: blurOwed) and are used.
+    const bool patchBlur = !(stages & kStageFront) ? h->lastBlurForm == 3
+                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (long long)h->nfeatures * 43 * 37 * 4 <= 5LL * g.sumPixels));
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     // Overlap inside one call (round 4): the blurred levels are read by k_description only, the LAST launch, so the blur of a large batch runs on
     // a side stream beside FAST and the quad-tree: pyramid -> {blur | FAST -> quad-tree} -> description.  k_blur is the one HBM-bound kernel of the
@@ -514,6 +563,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // One frame 40.9 -> 39.8 us, two 45.8 -> 44.6, four 58.3 -> 55.7, eight 71.5 -> 67.1; from 32 frames on the small shape wins
             const int colsShape = (long long)cs->columns.size() * Bn <= h->numCUs ? (cs->px <= 56 ? 6 : 4) : 1;
             Prof p(h, S_RESIZE, st);
+            h->lastKernel[S_RESIZE] = "k_pyr_cols";
             pollute(st);
             const size_t slot = cs->blurLevels ? 4 + (cs - g.colSetsBlur.data()) : (cs - g.colSets.data());
             launchPyrCols(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_cols + h->colsOff[slot], (int)cs->columns.size(), h->d_colLevels, g.nlevels,
@@ -530,6 +580,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             }
             for (int l = 2; l < g.nlevels; l++) {      // levels 2..: one launch per level (each level is resized from the rounded pixels of the one above)
                 Prof p(h, S_RESIZE, st);
+                h->lastKernel[S_RESIZE] = "k_resize";
                 pollute(st);
                 launchResize(st, g.lv[l - 1], g.lv[l], g.tilesX[l], g.tilesY[l], h->d_rx + h->rxOff[l], h->d_xq + h->xqOff[l], h->d_ry + h->ryOff[l],
                              h->d_foot + h->footOff[l], h->d_pyr, g.tileLdsStride, g.tileLdsRows, g.packedTaps[l] && !h->resizeBytewise, f0, Bn);
@@ -585,10 +636,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             if (lt.hist) h->leafDirty = true;
             if (h->testFailAfterFast && lt.hist) { injected = true; h->testFailAfterFast = false; }      // (test aid: a call that dies between k_fast and k_octree)
+            const bool wide = h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs);
+            h->lastKernel[S_FAST] = wide && g.maxRoiW <= 45 && g.maxRoiH <= 45 ? "k_fast_wide" : "k_fast";
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
-                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt,
-                       h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs));
+                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt, wide);
         }
     };
     auto backTail = [&](hipStream_t st, int f0, int Bn) {
@@ -620,6 +672,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             const int queuedT = lt.hist && !h->octThreadsForced ? 256 : 0;
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : (queuedT ? queuedT : h->octThreads[l]);
             pollute(st);
+            h->lastKernel[S_OCTREE] = h->d_octArena ? "k_octree_1024g" : "k_octree_" + std::to_string(octT[0]) + (residentT != 0 || h->octRoomyForced ? "r" : "");
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
@@ -666,9 +719,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         if (doFront) front(st, 0, B);
         if (doBack) back(st, 0, B);
     }
-    if (injected) return fail(h, ORBX_ERR_HIP, "ORBX_TEST_FAIL_AFTER_FAST: returned between k_fast and k_octree");
+    if (injected) return fail(h, ORBX_ERR_HIP, "injected failure (test aid fail_after_fast): returned between k_fast and k_octree");
     HIP_TRY(h, hipGetLastError());
-    h->lastB = B;
+    if (doFront) h->lastB = B;   // (a back-only pass leaves the pyramid of the earlier call, all its frames, in place)
     h->lastHostB = 0;            // the caller's buffers hold this batch; orbx_extract_batch_begin sets it again for its own
     h->pyramidOnly = !doBack;
     return ORBX_OK;
@@ -797,7 +850,15 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = ini_th; h->minTh = min_th; h->scaleFactor = scale_factor;
     h->maxW = max_width; h->maxH = max_height; h->maxB = max_batch;
     h->tabs = makeScaleTables(nfeatures, scale_factor, nlevels);
-    if (const char* e = getenv("ORBX_BLUR_IN_LEVELS")) h->blurInLevels = std::max(1, std::min(atoi(e), (int)kMaxLevels));
+    // Launch-policy switches: read ONCE, here, and kept as a string (orbx_debug_policy; bench.py prints it as config.policy).  They choose between
+    // result-identical launch forms (tests run every one); none of them can change a result or make a call fail.
+    auto envInt = [&](const char* name, int dflt) {
+        const char* e = getenv(name);
+        const int v = e ? atoi(e) : dflt;
+        h->policy += std::string(h->policy.empty() ? "" : " ") + (name + 5) + "=" + std::to_string(v) + (e ? "(env)" : "");
+        return v;
+    };
+    h->blurInLevels = std::max(1, std::min(envInt("ORBX_BLUR_IN_LEVELS", 5), (int)kMaxLevels));
     std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom);
     if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
     layoutArenas(h->maxGeom, max_batch);
@@ -827,16 +888,17 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     }
     h->outCap = mg.selPerFrame + 8 * nlevels;
 
-// device allocation of orbx_create; ORBX_POISON=<byte> fills it (tests run with it: no kernel may depend on what hipMalloc returns,
-// which is zeroed pages in a fresh process and another test's leftovers later)
+// device allocation of orbx_create; the test aid "poison" fills it (tests run with it: no kernel may depend on what hipMalloc returns,
+// which is zeroed pages in a fresh process and another test's leftovers later).  Every fill of this function is enqueued on the handle's OWN
+// stream - the stream the kernels run on - so "filled before first use" is stream order, not an assumption about the null stream.
 #define CREATE_ALLOC(ptr, bytes)                                                         \
     do {                                                                                 \
         const size_t n_ = (size_t)(bytes);                                               \
         CREATE_TRY(hipMalloc(&(ptr), n_));                                               \
-        if (poison >= 0) CREATE_TRY(hipMemset((ptr), poison, n_));                       \
+        if (poison >= 0) CREATE_TRY(hipMemsetAsync((ptr), poison, n_, h->stream));       \
     } while (0)
 
-    const int poison = getenv("ORBX_POISON") ? atoi(getenv("ORBX_POISON")) & 255 : -1;
+    const int poison = g_aids.poison >= 0 ? g_aids.poison & 255 : -1;
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->ownStream = true;
     CREATE_ALLOC(h->d_input, (size_t)max_width * max_height * max_batch);
@@ -853,7 +915,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     if (h->octArenaSlice) CREATE_ALLOC(h->d_octArena, h->octArenaSlice * max_batch * nlevels);
     // (k_fast pays ~6 % for the tables, k_octree loses its first sweep: 640x480, us per call without -> with: 12 frames 110 -> 101, 32: 169 -> 163,
     // 64: 306 -> 296, 128: 562 -> 556, 256: 1040 -> 1046, 512: 2040 -> 2053; 1920x1080: 16 frames 519 -> 431, 32: 904 -> 827, 128: 3108 -> 3092)
-    h->leafFrames = getenv("ORBX_LEAF_FRAMES") ? atoi(getenv("ORBX_LEAF_FRAMES")) : 128;
+    h->leafFrames = envInt("ORBX_LEAF_FRAMES", 128);
     if (h->leafFrames > max_batch) h->leafFrames = max_batch;
     if (h->octR < 1 || h->octArenaSlice || h->leafFrames < 0) h->leafFrames = 0;      // no dense phase, or node arrays in HBM: the first sweep stays in k_octree
     // (k_fast indexes the tables with 32 bits: cap the frames so that frames x levels x roots x 1024 stays below 2^30 entries)
@@ -862,8 +924,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
         const size_t n = (size_t)h->leafFrames * nlevels * h->octR * kOctLeaves;
         CREATE_ALLOC(h->d_leafHist, n * sizeof(int));
         CREATE_ALLOC(h->d_leafBest, n * sizeof(unsigned));
-        CREATE_TRY(hipMemset(h->d_leafHist, 0, n * sizeof(int)));          // the tables are zero between calls (also under ORBX_POISON)
-        CREATE_TRY(hipMemset(h->d_leafBest, 0, n * sizeof(unsigned)));
+        CREATE_TRY(hipMemsetAsync(h->d_leafHist, 0, n * sizeof(int), h->stream));          // the tables are zero between calls (also under the poison aid)
+        CREATE_TRY(hipMemsetAsync(h->d_leafBest, 0, n * sizeof(unsigned), h->stream));
         CREATE_ALLOC(h->d_leafCode, (size_t)2 * nlevels * h->octXT);
     }
     CREATE_ALLOC(h->d_levelCount, sizeof(int) * max_batch * nlevels);
@@ -877,12 +939,12 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_xq, sizeof(QuadRec) * h->xqCap);
     CREATE_ALLOC(h->d_tiles, sizeof(BlurItem) * h->tileCap);
     CREATE_ALLOC(h->d_laneItem, sizeof(unsigned short) * h->laneCap);
-    h->pyrCols = getenv("ORBX_PYR_COLS") ? atoi(getenv("ORBX_PYR_COLS")) : -1;
-    h->colPx = getenv("ORBX_PYR_COL_PX") ? atoi(getenv("ORBX_PYR_COL_PX")) : 0;
-    h->fastWide = getenv("ORBX_FAST_WIDE") ? atoi(getenv("ORBX_FAST_WIDE")) : -1;
-    h->colsVariant = getenv("ORBX_PYR_COLS_VARIANT") ? atoi(getenv("ORBX_PYR_COLS_VARIANT")) : -1;
-    h->blurInCols = getenv("ORBX_BLUR_IN_COLS") ? atoi(getenv("ORBX_BLUR_IN_COLS")) : 0;
-    h->patchBlur = getenv("ORBX_PATCH_BLUR") ? atoi(getenv("ORBX_PATCH_BLUR")) : -1;
+    h->pyrCols = envInt("ORBX_PYR_COLS", -1);
+    h->colPx = envInt("ORBX_PYR_COL_PX", 0);
+    h->fastWide = envInt("ORBX_FAST_WIDE", -1);
+    h->colsVariant = envInt("ORBX_PYR_COLS_VARIANT", -1);
+    h->blurInCols = envInt("ORBX_BLUR_IN_COLS", 0);
+    h->patchBlur = envInt("ORBX_PATCH_BLUR", -1);
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += 2 * (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);      // (every cut with and without the blur's halo)
     h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)
@@ -894,25 +956,33 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_foot, sizeof(TileFoot) * h->footCap);
     h->outBytes = outLayout(max_batch, h->outCap, nlevels).all;
     CREATE_ALLOC(h->d_out, h->outBytes);
-    h->testFailAfterFast = getenv("ORBX_TEST_FAIL_AFTER_FAST") && atoi(getenv("ORBX_TEST_FAIL_AFTER_FAST")) != 0;
-    h->zeroCopy = !(getenv("ORBX_ZERO_COPY") && atoi(getenv("ORBX_ZERO_COPY")) == 0);
+    h->testFailAfterFast = g_aids.failAfterFast != 0;
+    g_aids.failAfterFast = 0;      // one shot: this handle's first call with leaf tables
+    h->zeroCopy = envInt("ORBX_ZERO_COPY", 1) != 0;
     CREATE_TRY(hipHostMalloc(&h->h_lap, sizeof(int) * 2 * max_batch));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));      // (default priority: a low-priority blur only starts when everything else is done - 1928 -> 2022 us; high = default)
     for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming)); }
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
-    h->splitMode = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 1;
-    h->fuseSmall = !(getenv("ORBX_FUSE_SMALL") && atoi(getenv("ORBX_FUSE_SMALL")) == 0);
-    h->splitMinPixels = (long long)((getenv("ORBX_SPLIT_MIN_MPX") ? atof(getenv("ORBX_SPLIT_MIN_MPX")) : 120.0) * 1e6);
-    h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;
-    if (const char* e = getenv("ORBX_OCT_THREADS")) h->octThreadsForced = atoi(e);   // tuning switch: 256, 512 or 1024
+    h->splitMode = envInt("ORBX_SPLIT", 1);
+    h->fuseSmall = envInt("ORBX_FUSE_SMALL", 1) != 0;
+    {
+        const char* e = getenv("ORBX_SPLIT_MIN_MPX");
+        h->splitMinPixels = (long long)((e ? atof(e) : 120.0) * 1e6);
+        h->policy += std::string(" SPLIT_MIN_MPX=") + (e ? e : "120") + (e ? "(env)" : "");
+    }
+    h->resizeBytewise = getenv("ORBX_RESIZE_BYTEWISE") != nullptr;      // diagnostic: the byte-gather form of k_resize
     h->octRoomyForced = getenv("ORBX_OCT_ROOMY") != nullptr;
-    if (const char* e = getenv("ORBX_LDS_POLLUTE")) h->ldsPollute = atoi(e) & 255;
+    h->policy += std::string(" RESIZE_BYTEWISE=") + (h->resizeBytewise ? "1(env)" : "0") + " OCT_ROOMY=" + (h->octRoomyForced ? "1(env)" : "0");
+    h->octThreadsForced = envInt("ORBX_OCT_THREADS", 0);   // tuning switch: 256, 512 or 1024
+    if (g_aids.ldsPollute >= 0) h->ldsPollute = g_aids.ldsPollute & 255;
+    if (poison >= 0 || h->ldsPollute >= 0 || h->testFailAfterFast)
+        h->policy += " test_aids=poison:" + std::to_string(poison) + ",lds_pollute:" + std::to_string(h->ldsPollute) + ",fail_after_fast:" + std::to_string((int)h->testFailAfterFast);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;
-    }   // diagnostic: the byte-gather form of k_resize
+    }
     CREATE_TRY(hipHostMalloc(&h->h_out, h->outBytes));
     std::memset(h->h_out, 0, h->outBytes);
     // pageable input up to this size is gathered in pinned memory first (a hipMemcpyAsync from pageable memory stages and waits inside the call)
@@ -920,9 +990,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipHostMalloc(&h->h_in, h->hInBytes));
     // the border of the pyramid arena is only ever written by the kernels, but the padding bytes between
     // rows are never written: clear once so introspection copies are deterministic
-    CREATE_TRY(hipMemset(h->d_pyr, 0, h->pyrBytes));
-    CREATE_TRY(hipMemset(h->d_blur, 0, h->blurBytes));
-    CREATE_TRY(uploadUmax(h->tabs.umax));
+    CREATE_TRY(hipMemsetAsync(h->d_pyr, 0, h->pyrBytes, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_blur, 0, h->blurBytes, h->stream));
+    if (!checkUmax(h->tabs.umax)) { h->err = "orbx_create: the patch-radius table differs from the device's static copy (internal)"; return bail(ORBX_ERR_UNSUPPORTED); }
     {   // k_fast's packed passes assume the 3-input packed f16 min/max act as integer min/max on u16 halves 0..255
         unsigned bad = 1;
         CREATE_TRY(runPackedSelfTest(h->stream, (unsigned*)h->d_candCount, &bad));
@@ -931,9 +1001,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
             return bail(ORBX_ERR_UNSUPPORTED);
         }
     }
-    // hipMemset is asynchronous to the host: the arenas' zero fill (and the poison) must be over before a first call's kernels - on a non-blocking
-    // stream, which does not wait for the null stream - write into them
-    CREATE_TRY(hipDeviceSynchronize());
+    // (runPackedSelfTest ended with a wait for h->stream: the fills above, enqueued on that stream before it, are over as well.  orbx_set_stream
+    // waits for the old stream before it adopts the caller's.)
 #undef CREATE_TRY
     h->geom = FrameGeom();   // installed on first use
     *out = h;
@@ -1192,6 +1261,47 @@ int orbx_fetch_pyramid(orbx_handle* h, int frame, const uint8_t** base, size_t* 
     return ORBX_OK;
 }
 
+int orbx_debug_set_option(const char* name, int value) {
+    if (!name) return ORBX_ERR_BAD_ARGUMENT;
+    const std::string n(name);
+    if (n == "poison") g_aids.poison = value;
+    else if (n == "lds_pollute") g_aids.ldsPollute = value;
+    else if (n == "fail_after_fast") g_aids.failAfterFast = value;
+    else return ORBX_ERR_BAD_ARGUMENT;
+    return ORBX_OK;
+}
+
+const char* orbx_debug_policy(const orbx_handle* h) { return h ? h->policy.c_str() : ""; }
+
+// The shader clock while the handle's work is running: one sleeping wave per CU on a stream of its own (k_clock.hip), asynchronous.
+enum { kClockSlots = 64, kClockTicks = 5000 };      // 5000 ticks of 100 MHz = 50 us per probe
+int orbx_debug_clock_probe(orbx_handle* h, int slot) {
+    if (!h || slot < 0 || slot >= kClockSlots) return ORBX_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->probeStream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->probeStream, hipStreamNonBlocking));
+        HIP_TRY(h, hipMalloc(&h->d_clock, sizeof(unsigned long long) * 2 * kClockSlots * h->numCUs));
+        HIP_TRY(h, hipMemsetAsync(h->d_clock, 0, sizeof(unsigned long long) * 2 * kClockSlots * h->numCUs, h->probeStream));
+    }
+    launchClockProbe(h->probeStream, h->d_clock, slot, h->numCUs, kClockTicks);
+    HIP_TRY(h, hipGetLastError());
+    return ORBX_OK;
+}
+int orbx_debug_clock_read(orbx_handle* h, int n_slots, double* ghz) {
+    if (!h || !ghz || n_slots < 1 || n_slots > kClockSlots) return ORBX_ERR_BAD_ARGUMENT;
+    if (!h->probeStream) return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_debug_clock_read: no probe was launched");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<unsigned long long> v((size_t)2 * n_slots * h->numCUs);
+    HIP_TRY(h, hipMemcpyAsync(v.data(), h->d_clock, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->probeStream));
+    HIP_TRY(h, hipStreamSynchronize(h->probeStream));
+    for (int s = 0; s < n_slots; s++) {
+        double dt = 0, dr = 0;
+        for (int w = 0; w < h->numCUs; w++) { dt += (double)v[2 * ((size_t)s * h->numCUs + w)]; dr += (double)v[2 * ((size_t)s * h->numCUs + w) + 1]; }
+        ghz[s] = dr > 0 ? 0.1 * dt / dr : 0.0;      // cycles per 10-ns tick -> GHz
+    }
+    return ORBX_OK;
+}
+
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
     if (pyramid_form) *pyramid_form = h->lastPyrForm;
@@ -1211,8 +1321,8 @@ int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* 
     if (dst_stride < w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_get_level: dst_stride too small");
     const uint8_t* src = h->d_pyr + L.pyrOff + (long long)frame * L.pyrFrameBytes +
                          (bordered ? (kPadL - kEdge) : ((long long)kEdge * L.pyrStride + kPadL));
+    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_stride, src, L.pyrStride, w, hh, hipMemcpyDeviceToHost, h->stream));      // (behind the kernels, in stream order)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(dst, dst_stride, src, L.pyrStride, w, hh, hipMemcpyDeviceToHost));
     if (width) *width = L.w;
     if (height) *height = L.h;
     return ORBX_OK;
@@ -1223,9 +1333,9 @@ int orbx_debug_num_candidates(orbx_handle* h, int frame, int level, int* n) {
     if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
         return fail(h, ORBX_ERR_BAD_ARGUMENT, "no such frame/level in the last batch");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     unsigned v = 0;
-    HIP_TRY(h, hipMemcpy(&v, h->d_candCount + frame * h->nlevels + level, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpyAsync(&v, h->d_candCount + frame * h->nlevels + level, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     *n = (int)v;
     return ORBX_OK;
 }
@@ -1243,11 +1353,11 @@ int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoin
     const FrameGeom& g = h->geom;
     const int nCells = (int)g.cells.size();
     std::vector<unsigned> counts(L.cellCount), seg(L.candCap);
+    HIP_TRY(h, hipMemcpyAsync(counts.data(), h->d_cellCount + (long long)frame * nCells + L.cellFirst, sizeof(unsigned) * L.cellCount,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(seg.data(), h->d_candSeg + L.candOff + (long long)frame * L.candCap, sizeof(unsigned) * L.candCap,
+                              hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(counts.data(), h->d_cellCount + (long long)frame * nCells + L.cellFirst, sizeof(unsigned) * L.cellCount,
-                         hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(seg.data(), h->d_candSeg + L.candOff + (long long)frame * L.candCap, sizeof(unsigned) * L.candCap,
-                         hipMemcpyDeviceToHost));
     int at = 0;
     for (int c = 0; c < L.cellCount; c++) {
         const int so = g.cells[L.cellFirst + c].segOff;
@@ -1270,9 +1380,9 @@ int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, p
     const LevelGeom& L = h->geom.lv[level];
     if (dst_stride < L.w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "dst_stride too small");
     if (h->lastBlurForm == 3) return fail(h, ORBX_ERR_UNSUPPORTED, "the last call blurred per keypoint inside k_describe: no blurred level exists (ORBX_PATCH_BLUR=0 keeps k_blur)");
+    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
+                                L.h, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy2D(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
-                           L.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
@@ -1597,18 +1707,30 @@ int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int
     if (device >= ndev) { g_createError = "orbx_vocabulary_create: device index out of range"; return ORBX_ERR_BAD_ARGUMENT; }
     orbx_vocabulary* v = new orbx_vocabulary();
     v->device = device; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->nNodes = n_nodes; v->nWords = words;
+    // the uploads go through a stream of their own and the function returns when THAT stream has drained: the tables have landed before any
+    // handle's stream can be given the vocabulary, and no other work on the device is waited for
+    hipStream_t us = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) {
+        g_createError = "orbx_vocabulary_create: cannot create the upload stream";
+        delete v;
+        return ORBX_ERR_HIP;
+    }
     auto up = [&](void** d, const void* src, size_t bytes) {
-        return hipMalloc(d, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
+        return hipMalloc(d, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpyAsync(*d, src, bytes, hipMemcpyHostToDevice, us) == hipSuccess);
     };
     std::vector<double> w0(weight, weight + n_nodes);
-    if (hipSetDevice(device) != hipSuccess || !up((void**)&v->d_childOff, off.data(), sizeof(int) * (n_nodes + 1)) ||
+    if (!up((void**)&v->d_childOff, off.data(), sizeof(int) * (n_nodes + 1)) ||
         !up((void**)&v->d_childList, list.data(), sizeof(int) * list.size()) || !up((void**)&v->d_desc, desc, (size_t)n_nodes * 32) ||
         !up((void**)&v->d_wordId, wid.data(), sizeof(uint32_t) * n_nodes) || !up((void**)&v->d_weight, w0.data(), sizeof(double) * n_nodes)) {
         g_createError = "orbx_vocabulary_create: device allocation or copy failed";
+        (void)hipStreamSynchronize(us);
+        (void)hipStreamDestroy(us);
         orbx_vocabulary_destroy(v);
         return ORBX_ERR_HIP;
     }
-    if (hipDeviceSynchronize() != hipSuccess) { orbx_vocabulary_destroy(v); return ORBX_ERR_HIP; }      // (the tables have landed before any handle's stream reads them: installGeometry has the reason)
+    const hipError_t landed = hipStreamSynchronize(us);
+    (void)hipStreamDestroy(us);
+    if (landed != hipSuccess) { g_createError = "orbx_vocabulary_create: upload failed"; orbx_vocabulary_destroy(v); return ORBX_ERR_HIP; }
     *out = v;
     return ORBX_OK;
 }
@@ -1746,6 +1868,10 @@ int orbx_profile_read(orbx_handle* h, double* total_ms, long* launches) {
     return ORBX_OK;
 }
 const char* orbx_profile_kernel_name(int slot) { return slot >= 0 && slot < ORBX_NUM_KERNELS ? kSlotNames[slot] : ""; }
+const char* orbx_profile_kernel_name_of(const orbx_handle* h, int slot) {
+    if (!h || slot < 0 || slot >= ORBX_NUM_KERNELS) return "";
+    return h->lastKernel[slot].empty() ? kSlotNames[slot] : h->lastKernel[slot].c_str();
+}
 
 long orbx_algorithmic_bytes(const orbx_handle* h, int rows, int cols, int n_out) {
     if (!h) return 0;

@@ -132,6 +132,11 @@ def load_library():
     L.orbx_compute_keypoints_octree.argtypes = [vp, vp, C.c_int, vp]
     L.orbx_fetch_pyramid.argtypes = [vp, C.c_int, C.POINTER(vp), vp, vp, vp, vp]
     L.orbx_debug_last_forms.argtypes = [vp, ip, ip, ip]
+    L.orbx_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.orbx_debug_clock_probe.argtypes = [vp, C.c_int]
+    L.orbx_debug_clock_read.argtypes = [vp, C.c_int, vp]
+    L.orbx_debug_policy.restype = C.c_char_p
+    L.orbx_debug_policy.argtypes = [vp]
     L.orbx_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, C.c_int,
                                      vp, vp, vp, vp]
     L.orbx_extract_batch_begin.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int]
@@ -179,6 +184,8 @@ def load_library():
     L.orbx_profile_read.argtypes = [vp, vp, vp]
     L.orbx_profile_kernel_name.restype = C.c_char_p
     L.orbx_profile_kernel_name.argtypes = [C.c_int]
+    L.orbx_profile_kernel_name_of.restype = C.c_char_p
+    L.orbx_profile_kernel_name_of.argtypes = [vp, C.c_int]
     L.orbx_algorithmic_bytes.restype = C.c_long
     L.orbx_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     _lib = L
@@ -187,6 +194,22 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- test aids (include/orbx.h: orbx_debug_set_option).  Not reachable from the environment; handles created AFTERWARDS carry the setting ----
+TEST_AIDS = ("poison", "lds_pollute", "fail_after_fast")
+
+
+def debug_set_option(name, value):
+    rc = load_library().orbx_debug_set_option(name.encode(), int(value))
+    if rc != ORBX_OK:
+        raise OrbxError(rc, "orbx_debug_set_option(%r)" % name)
+
+
+def debug_reset_options():
+    debug_set_option("poison", -1)
+    debug_set_option("lds_pollute", -1)
+    debug_set_option("fail_after_fast", 0)
 
 
 # ---- handle-free host helpers (no GPU needed) -------------------------------------------------------------
@@ -344,12 +367,13 @@ class ORBextractor:
 
     def extract_batch_begin(self, images, lapping=None, want_levels=False):
         """Asynchronous host-buffer form: enqueue H2D + path + D2H and return (one batch in flight per handle)."""
-        assert images.dtype == np.uint8 and images.ndim == 3 and images.flags["C_CONTIGUOUS"]
+        # rows may be padded (a view into a wider buffer, as a cv::Mat ROI): stride / frame_stride are passed as they are
+        assert images.dtype == np.uint8 and images.ndim == 3 and images.strides[2] == 1 and images.strides[1] >= images.shape[2] and images.strides[0] > 0
         B, rows, cols = images.shape
         lap = None
         if lapping is not None:
             lap = np.ascontiguousarray(np.broadcast_to(np.asarray(lapping, np.int32).reshape(-1, 2), (B, 2)))
-        self._check(self._L.orbx_extract_batch_begin(self._h, B, _ptr(images), rows, cols, cols, rows * cols, _ptr(lap), int(want_levels)))
+        self._check(self._L.orbx_extract_batch_begin(self._h, B, _ptr(images), rows, cols, images.strides[1], images.strides[0], _ptr(lap), int(want_levels)))
         self._pending = (B, images, lap)     # keep the buffers alive until the batch ends
 
     def extract_batch_end(self):
@@ -556,6 +580,19 @@ class ORBextractor:
             per_level.append(lvl[o:o + c].copy()); o += c
         return per_level
 
+    def policy(self):
+        """The launch-policy switches as orbx_create read them (include/orbx.h: orbx_debug_policy)."""
+        return (self._L.orbx_debug_policy(self._h) or b"").decode()
+
+    def clock_probe(self, slot):
+        """Asynchronous sample of the shader clock beside the handle's running work (include/orbx.h: orbx_debug_clock_probe)."""
+        self._check(self._L.orbx_debug_clock_probe(self._h, int(slot)))
+
+    def clock_read(self, n_slots):
+        ghz = np.zeros(n_slots, np.float64)
+        self._check(self._L.orbx_debug_clock_read(self._h, int(n_slots), _ptr(ghz)))
+        return ghz
+
     def last_forms(self):
         """(pyramid form, region side of k_pyr_cols, blur form) of the last call: include/orbx.h, orbx_debug_last_forms."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()
@@ -583,7 +620,8 @@ class ORBextractor:
     def profile_read(self):
         ms = np.zeros(ORBX_NUM_KERNELS, np.float64); n = np.zeros(ORBX_NUM_KERNELS, np.int64)
         self._check(self._L.orbx_profile_read(self._h, _ptr(ms), _ptr(n)))
-        return {self._L.orbx_profile_kernel_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(ORBX_NUM_KERNELS)}
+        # keyed by the kernel that ran in each slot on this handle, as rocprofv3 names it (k_pyr_cols, k_octree_256, ...)
+        return {self._L.orbx_profile_kernel_name_of(self._h, i).decode(): (float(ms[i]), int(n[i])) for i in range(ORBX_NUM_KERNELS)}
 
     def algorithmic_bytes(self, rows, cols, n_out):
         return int(self._L.orbx_algorithmic_bytes(self._h, rows, cols, n_out))

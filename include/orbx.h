@@ -103,7 +103,7 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff
                  orbx_keypoint* level_kps, int* level_counts);
 
 /* The same call without the last copy: the results stay in the handle's pinned result slab and the caller gets pointers into it, valid
- * until the next call on this handle (the C++ shim copies them straight into the caller's std::vector / cv::Mat: one copy instead of
+ * until the next result-producing call on this handle is MADE - its kernels write the same memory (the C++ shim copies them straight into the caller's std::vector / cv::Mat: one copy instead of
  * two).  want_levels != 0 also produces allLevelsKeypoints (level_kps flattened level by level, level_counts[nlevels]).  One frame per
  * call has NO copy command on the stream: the image goes through pinned staging in one H2D copy and the kernels write the slab in host
  * memory themselves. */
@@ -143,7 +143,11 @@ int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, 
 int orbx_extract_batch_end(orbx_handle* h, orbx_keypoint* kps, uint8_t* desc, int capacity, int* n_out, int* mono_out,
                            orbx_keypoint* level_kps, int* level_counts);
 /* Zero-copy variant of _end: waits, then hands out pointers into the handle's pinned result staging
- * (kps[f*capacity + i], desc[(f*capacity + i)*32], n_out[f], mono_out[f]); valid until the next _begin on this handle. */
+ * (kps[f*capacity + i], desc[(f*capacity + i)*32], n_out[f], mono_out[f]).
+ * Lifetime (same rule as orbx_extract_view): the pointers are valid until the NEXT CALL of any kind that produces results on this handle -
+ * orbx_extract*, _begin, orbx_compute_keypoints_octree - is MADE, not until it completes: with one frame per call the kernels of that next
+ * call write this very memory (there is no copy command whose completion would mark the overwrite).  Copy what you keep before calling again,
+ * or alternate two handles. */
 int orbx_extract_batch_end_view(orbx_handle* h, const orbx_keypoint** kps, const uint8_t** desc, int* capacity,
                                 const int** n_out, const int** mono_out);
 void* orbx_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
@@ -372,6 +376,23 @@ int orbx_debug_search_rounds(int* out4);
  * keypoint inside k_describe (no blurred level exists: orbx_debug_get_blurred has nothing to show). */
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
 
+/* Test aids.  They cannot be set from the environment: a test calls this BEFORE orbx_create and the handles created afterwards carry the
+ * setting.  name = "poison" (byte every device allocation of orbx_create is filled with; -1 = off), "lds_pollute" (byte every CU's LDS is
+ * filled with in front of every kernel; -1 = off), "fail_after_fast" (1: the next handle's first small-batch call returns ORBX_ERR_HIP
+ * between the FAST and the quad-tree launch, once).  Unknown name: ORBX_ERR_BAD_ARGUMENT. */
+int orbx_debug_set_option(const char* name, int value);
+
+/* The launch-policy switches as orbx_create read them, "NAME=value" separated by blanks, "(env)" behind a value that came from an ORBX_<NAME>
+ * environment variable (read once, at orbx_create; they choose between result-identical launch forms), and the test aids in force, if any.
+ * bench.py prints it as config.policy. */
+const char* orbx_debug_policy(const orbx_handle* h);
+
+/* The shader clock while the handle's work is running (bench.py: secondary.sustained).  orbx_debug_clock_probe enqueues, on a stream of
+ * its own and without waiting, one sleeping wave per CU that reads the shader-clock and the 100-MHz real-time counters 50 us apart, into
+ * slot 0..63; orbx_debug_clock_read waits for the probes launched so far and returns GHz per slot (0 for a slot never probed). */
+int orbx_debug_clock_probe(orbx_handle* h, int slot);
+int orbx_debug_clock_read(orbx_handle* h, int n_slots, double* ghz);
+
 /* ORBX_HOST_TIMING=1 in the environment: wall seconds of the one-frame host call (orbx_extract_view) accumulated per phase since the last read:
  * out8[0] enqueue (staging + copy + launches), [1] wait, [2] pointer query, [3] staging memcpy, [4] staging + H2D enqueue; *calls = calls summed. */
 int orbx_debug_host_timing(double* out8, long* calls);
@@ -392,6 +413,10 @@ int orbx_profile_reset(orbx_handle* h);
 /* Resolves pending events; fills total milliseconds and launch counts per kernel slot. */
 int orbx_profile_read(orbx_handle* h, double* total_ms, long* launches);
 const char* orbx_profile_kernel_name(int slot);
+/* ... and the kernel that last ran in that slot on this handle, by the name rocprofv3 prints (without template arguments): slot 1 is
+ * k_pyr_cols or k_resize, slot 3 k_fast or k_fast_wide, slot 4 k_octree_256 / _512 / _1024 (+ r: the 128-VGPR build, g: node arrays in HBM).
+ * bench.py keys roofline.kernel_ms_per_step with these, so that the line can be read next to profiles/ *_kernel_stats.md. */
+const char* orbx_profile_kernel_name_of(const orbx_handle* h, int slot);
 
 /* Algorithmic HBM bytes of one frame at this geometry (P0 + 2*S + 60*n_out). */
 long orbx_algorithmic_bytes(const orbx_handle* h, int rows, int cols, int n_out);

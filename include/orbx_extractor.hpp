@@ -35,6 +35,11 @@ namespace orbx {
 //   static Mat             wrapBordered(const uint8_t* src, int rows, int cols, ptrdiff_t step, int border)
 //                          // owning copy of the (rows + 2*border) x (cols + 2*border) buffer around src (= pixel (0,0)), returned as the
 //                          // rows x cols view into it: what mvImagePyramid[level] is in the reference (ORBextractor.cc:1173-1177)
+// Optional (the reference's exact operator() signature, inc/ORBextractor.h:58-61; present in CvTraits):
+//   using InputArray / OutputArray                                  // cv::InputArray, cv::OutputArray (references to the proxy classes)
+//   static Mat             getMat(InputArray)                       // _image.getMat()                    ORBextractor.cc:1086
+//   static uint8_t*        createOut(OutputArray, int rows, int cols)   // _descriptors.create(n, 32, CV_8U); the data of getMat()   :1106-1107
+//   static void            releaseOut(OutputArray)                  // _descriptors.release()             :1103
 template <class Traits>
 class BasicORBextractor {
 public:
@@ -81,28 +86,41 @@ public:
     // beyond what the caller's own vectors / Mat need to grow.
     int operator()(const Mat& image, const Mat& /*mask*/, std::vector<KeyPoint>& keypoints, Mat& descriptors,
                    std::vector<int>& vLappingArea, std::vector<std::vector<KeyPoint>>& allLevelsKeypoints) {
-        if (Traits::empty(image)) return -1;                                     // :1083-1084
-        if (!Traits::isU8C1(image)) throw std::invalid_argument("ORBextractor: image.type() != CV_8UC1");   // assert :1087
-        Reserve(Traits::cols(image), Traits::rows(image));                       // the reference has no size limit
-        int n = 0, mono = 0;
-        const orbx_keypoint *k = nullptr, *lk = nullptr;
-        const uint8_t* d = nullptr;
-        const int* counts = nullptr;
-        int rc = orbx_extract_view(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image),
-                                   vLappingArea.at(0), vLappingArea.at(1), 1, &k, &d, &n, &mono, &lk, &counts);
-        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
-        const KeyPoint* kp = reinterpret_cast<const KeyPoint*>(k);
-        keypoints.assign(kp, kp + n);                                            // _keypoints = vector<KeyPoint>(nkeypoints) :1112
-        if (n == 0) Traits::release(descriptors);                                // :1102-1103
-        else {
+        return extract(image, keypoints, vLappingArea, &allLevelsKeypoints, [&](int n) -> uint8_t* {
+            if (n == 0) { Traits::release(descriptors); return nullptr; }        // :1102-1103
             Traits::createU8(descriptors, n, 32);                                // :1106
-            std::memcpy(Traits::mutableData(descriptors), d, (size_t)n * 32);
-        }
-        const KeyPoint* lp = reinterpret_cast<const KeyPoint*>(lk);
-        allLevelsKeypoints.resize(nlevels);                                      // :1094
-        for (int l = 0, o = 0; l < nlevels; o += counts[l], l++) allLevelsKeypoints[l].assign(lp + o, lp + o + counts[l]);
-        mvImagePyramid.invalidate();
-        return mono;                                                             // :1161
+            return Traits::mutableData(descriptors);
+        });
+    }
+    // the tutorial clone's form (inc/ORBExtractor.h:55-56, src/orb_extractor/ORBExtractor.cpp): no allLevelsKeypoints
+    int operator()(const Mat& image, const Mat& /*mask*/, std::vector<KeyPoint>& keypoints, Mat& descriptors, std::vector<int>& vLappingArea) {
+        return extract(image, keypoints, vLappingArea, nullptr, [&](int n) -> uint8_t* {
+            if (n == 0) { Traits::release(descriptors); return nullptr; }
+            Traits::createU8(descriptors, n, 32);
+            return Traits::mutableData(descriptors);
+        });
+    }
+    // The reference's exact signature (inc/ORBextractor.h:58-61): cv::InputArray / cv::OutputArray, for callers that pass cv::noArray() as the
+    // mask, a std::vector<uchar> or a cv::UMat.  A template so that it only exists for traits that name the proxy types (CvTraits does); with
+    // cv::Mat arguments overload resolution still takes the Mat form above (exact match, no proxy objects).
+    template <class T = Traits>
+    int operator()(typename T::InputArray _image, typename T::InputArray /*_mask*/, std::vector<KeyPoint>& keypoints,
+                   typename T::OutputArray _descriptors, std::vector<int>& vLappingArea,
+                   std::vector<std::vector<KeyPoint>>& allLevelsKeypoints) {
+        const Mat image = T::getMat(_image);                                     // Mat image = _image.getMat(); :1086
+        return extract(image, keypoints, vLappingArea, &allLevelsKeypoints, [&](int n) -> uint8_t* {
+            if (n == 0) { T::releaseOut(_descriptors); return nullptr; }         // :1102-1103
+            return T::createOut(_descriptors, n, 32);                            // _descriptors.create(nkeypoints, 32, CV_8U); :1106
+        });
+    }
+    template <class T = Traits>
+    int operator()(typename T::InputArray _image, typename T::InputArray /*_mask*/, std::vector<KeyPoint>& keypoints,
+                   typename T::OutputArray _descriptors, std::vector<int>& vLappingArea) {      // inc/ORBExtractor.h:55-56
+        const Mat image = T::getMat(_image);
+        return extract(image, keypoints, vLappingArea, nullptr, [&](int n) -> uint8_t* {
+            if (n == 0) { T::releaseOut(_descriptors); return nullptr; }
+            return T::createOut(_descriptors, n, 32);
+        });
     }
 
     // inc/ORBextractor.h:87-90: the reference comments `protected:` out so that its demos can call the two stages themselves
@@ -179,6 +197,31 @@ public:
     orbx_handle* handle() { return h_; }
 
 private:
+    // operator() behind every signature: descOut(n) makes room for n descriptors in the caller's container and returns where they go
+    template <class DescOut>
+    int extract(const Mat& image, std::vector<KeyPoint>& keypoints, std::vector<int>& vLappingArea,
+                std::vector<std::vector<KeyPoint>>* allLevelsKeypoints, DescOut descOut) {
+        if (Traits::empty(image)) return -1;                                     // :1083-1084
+        if (!Traits::isU8C1(image)) throw std::invalid_argument("ORBextractor: image.type() != CV_8UC1");   // assert :1087
+        Reserve(Traits::cols(image), Traits::rows(image));                       // the reference has no size limit
+        int n = 0, mono = 0;
+        const orbx_keypoint *k = nullptr, *lk = nullptr;
+        const uint8_t* d = nullptr;
+        const int* counts = nullptr;
+        int rc = orbx_extract_view(h_, Traits::data(image), Traits::rows(image), Traits::cols(image), Traits::step(image),
+                                   vLappingArea.at(0), vLappingArea.at(1), allLevelsKeypoints ? 1 : 0, &k, &d, &n, &mono, &lk, &counts);
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
+        const KeyPoint* kp = reinterpret_cast<const KeyPoint*>(k);
+        keypoints.assign(kp, kp + n);                                            // _keypoints = vector<KeyPoint>(nkeypoints) :1112
+        if (uint8_t* out = descOut(n)) std::memcpy(out, d, (size_t)n * 32);
+        if (allLevelsKeypoints) {
+            const KeyPoint* lp = reinterpret_cast<const KeyPoint*>(lk);
+            allLevelsKeypoints->resize(nlevels);                                 // :1094
+            for (int l = 0, o = 0; l < nlevels; o += counts[l], l++) (*allLevelsKeypoints)[l].assign(lp + o, lp + o + counts[l]);
+        }
+        mvImagePyramid.invalidate();
+        return mono;                                                             // :1161
+    }
     void fetchLevels(std::vector<Mat>& levels) {
         const uint8_t* base = nullptr;
         size_t off[ORBX_MAX_LEVELS];
@@ -213,6 +256,12 @@ struct CvTraits {
     static void createU8(Mat& m, int r, int c) { m.create(r, c, CV_8U); }
     static void release(Mat& m) { m.release(); }
     static uint8_t* mutableData(Mat& m) { return m.data; }
+    // the reference's own argument types (inc/ORBextractor.h:58-61)
+    using InputArray = cv::InputArray;
+    using OutputArray = cv::OutputArray;
+    static Mat getMat(InputArray a) { return a.getMat(); }
+    static uint8_t* createOut(OutputArray a, int r, int c) { a.create(r, c, CV_8U); return a.getMat().data; }
+    static void releaseOut(OutputArray a) { a.release(); }
     static Mat wrapBordered(const uint8_t* s, int r, int c, ptrdiff_t step, int b) {
         Mat whole = Mat(r + 2 * b, c + 2 * b, CV_8UC1, (void*)(s - (ptrdiff_t)b * step - b), (size_t)step).clone();      // Mat temp(wholeSize, image.type()), :1174
         return whole(cv::Rect(b, b, c, r));                                                                              // temp(Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, sz.width, sz.height)), :1175

@@ -47,3 +47,10 @@ def _built_libraries():
         build_library()
     import helpers
     helpers.record_inputs()        # a failing comparison writes its inputs to gpurun_out/fail_*.npz (helpers.dump_failure)
+
+
+@pytest.fixture(autouse=True)
+def _no_test_aid_outlives_its_test():
+    yield
+    import helpers
+    helpers.reset_aids()

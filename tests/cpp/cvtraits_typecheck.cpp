@@ -5,6 +5,7 @@
 #include <opencv2/core/core.hpp>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "orbx_extractor.hpp"
 
@@ -37,6 +38,30 @@ int main(int argc, char** argv) {
         try { cv::Mat bgr(rows, cols, CV_8UC3); std::vector<cv::KeyPoint> k; cv::Mat d; vector<vector<cv::KeyPoint>> a; (*mpORBextractorLeft)(bgr, cv::Mat(), k, d, vLapping, a); }
         catch (const std::invalid_argument&) { refused = true; }
         if (!refused) return 5;
+        // the reference's exact signature (inc/ORBextractor.h:58-61: cv::InputArray / cv::OutputArray): the mask as cv::noArray(), the
+        // descriptors into an OutputArray that wraps a Mat - the same numbers as through the Mat overload
+        {
+            std::vector<cv::KeyPoint> k2;
+            cv::Mat d2;
+            vector<vector<cv::KeyPoint>> a2;
+            cv::_InputArray in(im);
+            cv::_OutputArray out(d2);
+            int mono2 = (*mpORBextractorLeft)(in, cv::noArray(), k2, out, vLapping, a2);
+            if (mono2 != monoLeft || k2.size() != mvKeys.size() || d2.rows != mDescriptors.rows || d2.cols != mDescriptors.cols) return 7;
+            if (k2.size() && memcmp(k2.data(), mvKeys.data(), k2.size() * sizeof(cv::KeyPoint))) return 7;
+            for (int r = 0; r < d2.rows; r++) if (memcmp(d2.data + (size_t)r * d2.step, mDescriptors.data + (size_t)r * mDescriptors.step, 32)) return 7;
+            if (a2.size() != allLevelsKeypoints.size()) return 7;
+            // ... mixed: a Mat image with cv::noArray() as the mask picks the proxy overload too
+            std::vector<cv::KeyPoint> k3; cv::Mat d3; vector<vector<cv::KeyPoint>> a3;
+            if ((*mpORBextractorLeft)(im, cv::noArray(), k3, d3, vLapping, a3) != monoLeft || k3.size() != mvKeys.size()) return 8;
+            // the tutorial clone's five-argument form (inc/ORBExtractor.h:55-56), Mat and proxy arguments
+            std::vector<cv::KeyPoint> k4, k5; cv::Mat d4, d5;
+            if ((*mpORBextractorLeft)(im, cv::Mat(), k4, d4, vLapping) != monoLeft || k4.size() != mvKeys.size() || d4.rows != mDescriptors.rows) return 9;
+            if ((*mpORBextractorLeft)(in, cv::noArray(), k5, cv::_OutputArray(d5), vLapping) != monoLeft || k5.size() != mvKeys.size() || d5.rows != mDescriptors.rows) return 9;
+            // an empty InputArray returns -1 as an empty Mat does (ORBextractor.cc:1083-1084)
+            std::vector<cv::KeyPoint> k6; cv::Mat d6; vector<vector<cv::KeyPoint>> a6;
+            if ((*mpORBextractorLeft)(cv::noArray(), cv::noArray(), k6, cv::_OutputArray(d6), vLapping, a6) != -1) return 10;
+        }
         // Frame::ComputeStereoMatches reads mvImagePyramid right after the call (Frame.cc:820): no call in between
         const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
         if (mpORBextractorLeft->mvImagePyramid.size() != 8 || mpORBextractorLeft->mvImagePyramid[0].cols != cols || nRows != rows) return 6;

@@ -66,4 +66,42 @@ private:
     int flags_ = 0;
     std::shared_ptr<std::vector<uchar>> own_;
 };
+// The argument proxies of OpenCV 3 (modules/core/include/opencv2/core/mat.hpp): `typedef const _InputArray& InputArray;`,
+// `typedef const _OutputArray& OutputArray;`, cv::noArray().  Only what ORBextractor::operator() does with them (inc/ORBextractor.h:58-61,
+// ORBextractor.cc:1086, 1103, 1106-1107): getMat(), create(rows, cols, type), release(); built from a Mat, a std::vector<uchar> or nothing.
+class _InputArray {
+public:
+    _InputArray() {}
+    _InputArray(const Mat& m) : mat_(const_cast<Mat*>(&m)) {}
+    _InputArray(const std::vector<uchar>& v) : vec_(const_cast<std::vector<uchar>*>(&v)) {}
+    Mat getMat(int = -1) const {
+        if (mat_) return *mat_;
+        if (vec_ && !vec_->empty()) return Mat(1, (int)vec_->size(), CV_8UC1, vec_->data(), vec_->size());      // a 1 x N view, as OpenCV gives
+        return Mat();
+    }
+    bool empty() const { return getMat().empty(); }
+protected:
+    Mat* mat_ = nullptr;
+    std::vector<uchar>* vec_ = nullptr;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray() {}
+    _OutputArray(Mat& m) { mat_ = &m; }
+    _OutputArray(std::vector<uchar>& v) { vec_ = &v; }
+    void create(int r, int c, int type) const {
+        if (mat_) { if (mat_->rows != r || mat_->cols != c || mat_->type() != type || !mat_->data) mat_->create(r, c, type); }
+        else if (vec_) vec_->resize((size_t)r * c);
+    }
+    void release() const { if (mat_) mat_->release(); else if (vec_) vec_->clear(); }
+};
+class _InputOutputArray : public _OutputArray {
+public:
+    _InputOutputArray() {}
+    _InputOutputArray(Mat& m) : _OutputArray(m) {}
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+typedef const _InputOutputArray& InputOutputArray;
+inline InputOutputArray noArray() { static _InputOutputArray none; return none; }
 }  // namespace cv

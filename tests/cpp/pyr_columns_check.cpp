@@ -9,10 +9,18 @@
 //     v >= w is column 2 (w - 1) - v), loaded / derived like any other; the replay blurs every region's owned pixels out of its rectangle
 //     exactly as the kernel reads it (three aligned dwords x0 - 4 .. x0 + 7, rows mirrored by index) and the assembled blurred levels equal a
 //     plain 7x7 blur (taps 18 34 49 55 49 34 18, REFLECT_101, ORBextractor.cc:1126-1127) of the whole levels, every pixel written exactly once.
+//  5. the WRITING role's thread dealing as the kernel computes it (k_pyramid.hip: doLevel) - the interior dword columns dealt dword by dword
+//     or walked column-wise in three runs (top mirror, interior, bottom mirror), the frame's columns byte by byte, all through float
+//     reciprocals - replayed for every writer count the launch shapes use (256 / 512 / 768 / 1024 threads): every owned (row, dword) is
+//     written by exactly one thread, from the source row copyMakeBorder's REFLECT_101 names (round 5; DESIGN.md 4j: the one miscompare of
+//     a soak was a bordered level 0 of 1014 x 432, w % 4 == 2, whose cause was never found - this closes the host-side candidates);
+//  6. a hash of every table the kernel reads (printed; tests/test_pyramid_columns.py runs the checker under two MALLOC_PERTURB_ values and
+//     a dirtied heap and expects the same hash: no uninitialised byte reaches the tables).
 // usage: pyr_columns_check <cols> <rows> <nlevels> <scaleFactor>      prints "ok ..." and exits 0, or the first violation and exits 1
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <algorithm>
 #include <vector>
 #include <string>
 
@@ -38,6 +46,69 @@ static uint8_t blurPx(const uint8_t* img, int w, int h, int x, int y) {      // 
 }
 #define FAIL(...) do { printf(__VA_ARGS__); printf("\n"); return 1; } while (0)
 
+// FNV-1a over the bytes of the tables the kernels read
+static unsigned long long g_hash = 1469598103934665603ull;
+static void hashBytes(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { g_hash ^= b[i]; g_hash *= 1099511628211ull; } }
+template <class T> static void hashVec(const std::vector<T>& v) { if (!v.empty()) hashBytes(v.data(), v.size() * sizeof(T)); }
+
+// The writing role of one level of one region exactly as k_pyr_cols deals it over `wstep` threads (k_pyramid.hip: doLevel; the same float
+// reciprocals: __frcp_rn(x) is the correctly rounded 1.0f / x).  count[(row - o.r0) * (o.dw1 - o.dw0) + (dw - o.dw0)]++ per store; a store
+// outside the owned rectangle, or a column-walk store from a source row other than REFLECT_101's, returns a message.
+static const char* replayWriters(const ColOwn own, int w, int h, int wstep, std::vector<int>& count) {
+    const int nrows = own.r1 - own.r0, ncols = own.dw1 - own.dw0;
+    count.assign((size_t)std::max(nrows, 0) * std::max(ncols, 0), 0);
+    if (nrows <= 0 || ncols <= 0) return nullptr;
+    auto store = [&](int row, int dw) -> bool {
+        if (row < own.r0 || row >= own.r1 || dw < own.dw0 || dw >= own.dw1) return false;
+        count[(size_t)(row - own.r0) * ncols + (dw - own.dw0)]++;
+        return true;
+    };
+    const int fa = std::max((int)own.dw0, kPadL / 4), fb = std::max(fa, std::min((int)own.dw1, kPadL / 4 + (w >> 2)));
+    for (int wtid = 0; wtid < wstep; wtid++) {
+        if (fb > fa && (fb - fa) * nrows <= 2 * wstep) {
+            const int ndw = fb - fa, total = ndw * nrows;
+            const float inv = 1.0f / (float)ndw;
+            for (int i = wtid; i < total; i += wstep) {
+                const int rr = (int)(((float)i + 0.5f) * inv), dw = fa + (i - rr * ndw), row = own.r0 + rr;
+                if (!store(row, dw)) return "dword-by-dword store outside the owned rectangle";
+            }
+        } else if (fb > fa) {
+            const int ndw = fb - fa;
+            const float rdw = 1.0f / (float)ndw;
+            const int ngrp = std::max((int)(((float)wstep + 0.5f) * rdw), 1);
+            const int per = (int)(((float)(nrows + ngrp - 1) + 0.5f) * (1.0f / (float)ngrp));
+            const int grp = (int)(((float)wtid + 0.5f) * rdw), c = wtid - grp * ndw;
+            if (grp < ngrp) {
+                if (c < 0 || c >= ndw) return "column-walk: column outside the interior columns";
+                const int rA = own.r0 + grp * per, rB = std::min(rA + per, (int)own.r1);
+                auto run = [&](int r0, int r1, int src0, int sstep) -> const char* {
+                    int src = src0;
+                    for (int row = r0; row < r1; row++, src += sstep) {
+                        if (src != refl(row - kEdge, h)) return "column-walk: source row differs from REFLECT_101";
+                        if (!store(row, fa + c)) return "column-walk store outside the owned rectangle";
+                    }
+                    return nullptr;
+                };
+                const int t1 = std::min(rB, kEdge), m0 = std::max(rA, kEdge), m1 = std::min(rB, kEdge + h), b0 = std::max(rA, kEdge + h);
+                const char* e = nullptr;
+                if (rA < t1 && (e = run(rA, t1, kEdge - rA, -1))) return e;
+                if (m0 < m1 && (e = run(m0, m1, m0 - kEdge, 1))) return e;
+                if (b0 < rB && (e = run(b0, rB, 2 * (h - 1) - (b0 - kEdge), -1))) return e;
+            }
+        }
+        const int nL = fa - own.dw0, nO = nL + (own.dw1 - fb);
+        if (nO > 0) {
+            const int total = nO * nrows;
+            const float inv = 1.0f / (float)nO;
+            for (int i = wtid; i < total; i += wstep) {
+                const int rr = (int)(((float)i + 0.5f) * inv), jj = i - rr * nO, dw = jj < nL ? own.dw0 + jj : fb + (jj - nL), row = own.r0 + rr;
+                if (!store(row, dw)) return "frame-column store outside the owned rectangle";
+            }
+        }
+    }
+    return nullptr;
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) return 2;
     const int cols = atoi(argv[1]), rows = atoi(argv[2]), nlevels = atoi(argv[3]);
@@ -48,6 +119,11 @@ int main(int argc, char** argv) {
     const std::string why = makeFrameGeom(t, rows, cols, g, 0, blurIn);
     if (!why.empty()) { printf("rejected: %s\n", why.c_str()); return 0; }
     layoutArenas(g, 1);
+    hashBytes(g.lv, sizeof(LevelGeom) * g.nlevels);
+    hashVec(g.cells);
+    for (int l = 0; l < nlevels; l++) { hashVec(g.rx[l]); hashVec(g.ry[l]); hashVec(g.foot[l]); hashVec(g.xq[l]); }
+    for (const std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
+        for (const FrameGeom::ColumnSet& cs : *sets) { hashVec(cs.columns); hashVec(cs.coef); }
     // the image and the whole levels, resized level by level
     std::vector<std::vector<uint8_t>> lvl(nlevels);
     lvl[0].resize((size_t)cols * rows);
@@ -144,6 +220,13 @@ int main(int argc, char** argv) {
                 const ColOwn o = c.own[l];
                 if (o.dw0 < 0 || o.dw1 > nd[l] || o.r0 < 0 || o.r1 > g.lv[l].pyrRows || o.dw1 < o.dw0 || o.r1 < o.r0) FAIL("px %d region %zu level %d: own rectangle", cs.px, ci, l);
                 const int wB = w + 2 * kEdge;
+                for (int wstep : {256, 512, 768, 1024}) {      // the writing role's thread counts of the launch shapes (launchPyrCols) and of the last level (everyone)
+                    std::vector<int> cnt;
+                    if (const char* e = replayWriters(o, w, h, wstep, cnt)) FAIL("px %d region %zu level %d, %d writers: %s", cs.px, ci, l, wstep, e);
+                    for (size_t i = 0; i < cnt.size(); i++)
+                        if (cnt[i] != 1) FAIL("px %d region %zu level %d, %d writers: owned dword (%d, %d) stored %d times by the kernel's dealing", cs.px, ci, l, wstep,
+                                              o.r0 + (int)(i / (size_t)(o.dw1 - o.dw0)), o.dw0 + (int)(i % (size_t)(o.dw1 - o.dw0)), cnt[i]);
+                }
                 for (int row = o.r0; row < o.r1; row++)
                     for (int dw = o.dw0; dw < o.dw1; dw++) {
                         written[l][(size_t)row * nd[l] + dw]++;
@@ -260,6 +343,6 @@ int main(int argc, char** argv) {
             }
         checked++;
     }
-    printf("ok %dx%d %d levels scale %.2f: %d cuts\n", cols, rows, nlevels, sf, checked);
+    printf("ok %dx%d %d levels scale %.2f hash %016llx: %d cuts\n", cols, rows, nlevels, sf, g_hash, checked);
     return 0;
 }

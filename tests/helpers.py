@@ -34,6 +34,29 @@ def sort_kps(k):
 LAST_INPUT = {}
 _fail_count = [0]
 
+# ---- switches of a test row ---------------------------------------------------------------------------------------------------
+# Launch-policy switches (ORBX_*) go to the environment, which orbx_create reads once; TEST AIDS ("aid:poison", "aid:lds_pollute",
+# "aid:fail_after_fast") cannot be set from the environment and go through orbx_debug_set_option (include/orbx.h).  conftest.py resets the
+# aids after every test.
+ACTIVE_AIDS = {}
+
+
+def apply_switches(switches, monkeypatch):
+    import extractorb_amd as X
+    for k, v in switches.items():
+        if k.startswith("aid:"):
+            X.debug_set_option(k[4:], int(v))
+            ACTIVE_AIDS[k[4:]] = int(v)
+        else:
+            monkeypatch.setenv(k, v)
+
+
+def reset_aids():
+    import extractorb_amd as X
+    if ACTIVE_AIDS:
+        X.debug_reset_options()
+        ACTIVE_AIDS.clear()
+
 
 def record_inputs():
     """Wraps extractorb_amd.ORBextractor.__call__ / extract_batch so that the last inputs are on file when a comparison fails."""
@@ -70,6 +93,7 @@ def dump_failure(what, **arrays):
         tag = re.sub(r"[^A-Za-z0-9_.-]+", "_", what)[:60]
         path = os.path.join(out, "fail_%d_%d_%s.npz" % (os.getpid(), _fail_count[0], tag))
         env = {k: v for k, v in os.environ.items() if k.startswith("ORBX_")}
+        env.update({"aid:" + k: v for k, v in ACTIVE_AIDS.items()})
         test = os.environ.get("PYTEST_CURRENT_TEST", "")
         keep = {("in_" + k): np.asarray(v) for k, v in LAST_INPUT.items()}
         keep.update({k: np.asarray(v) for k, v in arrays.items() if v is not None})

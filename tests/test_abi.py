@@ -39,6 +39,39 @@ def test_product_library_does_not_link_the_oracle():
                 assert "oracle_lib" not in text and "liborb_oracle" not in text, f
 
 
+def test_no_test_hook_is_reachable_from_the_environment():
+    """fault injection / memory poisoning / LDS pollution are test aids behind orbx_debug_set_option; the shipped
+    library reads no environment variable for them (a deployed process's environment cannot make an extractor fail)."""
+    strings = subprocess.check_output(["strings", "-a", X.library_path()], text=True)
+    for name in ("ORBX_TEST", "ORBX_POISON", "ORBX_LDS_POLLUTE", "FAIL_AFTER_FAST"):
+        assert name not in strings, name
+    L = X.load_library()
+    assert L.orbx_debug_set_option(b"no_such_aid", 1) == -2 and L.orbx_debug_set_option(None, 1) == -2
+    for name in X.orbextractor.TEST_AIDS:
+        assert L.orbx_debug_set_option(name.encode(), 1) == 0
+    X.debug_reset_options()
+    api = open(os.path.join(ROOT, "extractorb_amd", "csrc", "orbx_api.cpp")).read()
+    import re
+    read = set(re.findall(r'getenv\("(ORBX_[A-Z0-9_]+)"\)', api)) | set(re.findall(r'envInt\("(ORBX_[A-Z0-9_]+)"', api))
+    assert read and not [n for n in read if "TEST" in n or "POISON" in n or "POLLUTE" in n], read
+
+
+def test_handle_owned_memory_is_only_touched_in_stream_order():
+    """VERDICT round 4, item 4 / DESIGN.md 4j: every fill and copy of the host file names a stream (hipMemsetAsync / hipMemcpyAsync /
+    hipMemcpy2DAsync on the handle's stream, or the vocabulary's own upload stream) - no null-stream hipMemcpy / hipMemset whose order against
+    the handle's non-blocking stream would be an assumption, and no device-wide barrier that stalls other handles."""
+    import re
+    api = open(os.path.join(ROOT, "extractorb_amd", "csrc", "orbx_api.cpp")).read()
+    code = re.sub(r"//[^\n]*", "", api)
+    assert not re.findall(r"\bhipMem(?:cpy|set|cpy2D|setD8|setD32)\s*\(", code)
+    assert "hipDeviceSynchronize" not in code
+    assert "hipMemcpyToSymbol" not in code
+    # ... and the kernel files upload nothing outside diagnostic builds (the description's tables are static initialisers)
+    for f in ("k_describe.hip", "k_octree.hip", "k_pyramid.hip", "k_blur.hip", "k_stereo.hip", "k_match.hip", "k_bow.hip"):
+        text = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "extractorb_amd", "csrc", f)).read())
+        assert "hipMemcpyToSymbol" not in text and not re.findall(r"\bhipMem(?:cpy|set)\s*\(", text), f
+
+
 def test_keypoint_layout():
     assert X.KEYPOINT_DTYPE.itemsize == 28
     assert [X.KEYPOINT_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == \

@@ -27,6 +27,14 @@ def test_two_ranks_run_the_gather_branch_and_rank0_checks_what_arrived():
     v = j["verified"]
     assert v["bit_exact"] is True and v["ranks_checked"] == [0, 1] and v["frames_of_other_ranks"] == {"1": [1, 2]}
     assert v["frames"] == [0, 1, 2] and v["keypoints"] > 4000
+    # the diagnostics a first real SCALE run needs: every rank's own step time, what the wait for the previous gather
+    # cost each rank, and - on hardware - rank 0's kernels with the gather running (absent in the rehearsal, and said so)
+    m = j["multi_gpu"]
+    assert len(m["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in m["per_rank_ms_per_step"])
+    assert max(m["per_rank_ms_per_step"]) == j["ms_per_step"]                      # the line's step time is the slowest rank's
+    g = m["gather_exposed_ms"]
+    assert len(g["host_blocked_ms_per_step"]) == 2 and len(g["stream_stalled_ms_per_step"]) == 2 and all(v >= 0 for v in g["host_blocked_ms_per_step"])
+    assert m["rank0_kernel_ms_per_step"] is None and "rehearsal" in m["rank0_kernel_ms_note"]
     c4 = j["secondary"]["configs4_64_per_gpu"]       # BASELINE.json configs[4]'s code path (here 3 frames per rank), timed under the same rules
     assert c4["global_frames_per_step"] == 6 and c4["steps"] == 3 and c4["fps"] > 0 and "gathered to rank 0" in c4["note"]
 
@@ -43,3 +51,4 @@ def test_no_gather_leaves_results_on_their_ranks():
     r, j = run(extra_args=("--no-gather",))
     assert r.returncode == 0, r.stderr[-4000:]
     assert j["verified"]["ranks_checked"] == [0] and j["verified"]["bit_exact"] is True
+    assert j["multi_gpu"]["gather_exposed_ms"] is None and len(j["multi_gpu"]["per_rank_ms_per_step"]) == 2

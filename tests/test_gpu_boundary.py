@@ -130,20 +130,25 @@ def test_batch_results_come_back_in_one_slab():
 
 def test_a_call_that_dies_between_fast_and_quadtree_leaves_no_stale_leaf_tables():
     """the leaf tables k_fast fills are only zero again once k_octree has consumed them.  A call that returns in between
-    (injected: ORBX_TEST_FAIL_AFTER_FAST, one shot) must not inflate the next call's counts."""
+    (injected: the test aid "fail_after_fast" of orbx_debug_set_option, one shot) must not inflate the next call's counts."""
     code = r'''
 import os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-os.environ["ORBX_TEST_FAIL_AFTER_FAST"] = "1"
+os.environ["ORBX_TEST_FAIL_AFTER_FAST"] = "1"      # (the environment cannot inject it any more: must have no effect)
 import numpy as np
 import extractorb_amd as X, oracle_lib as O
 from extractorb_amd import synth
 img = synth.frames("noise", 3, 2, 480, 640)
+ex0 = X.ORBextractor(1000)
+ex0(img[0])                                          # no failure: the aid is not reachable from the environment
+assert "test_aids" not in ex0.policy(), ex0.policy()
+X.debug_set_option("fail_after_fast", 1)
 ex = X.ORBextractor(1000)
+assert "fail_after_fast:1" in ex.policy(), ex.policy()
 try:
     ex(img[0]); print("NOFAIL")
 except X.OrbxError as e:
-    assert "ORBX_TEST_FAIL_AFTER_FAST" in str(e), e
+    assert "fail_after_fast" in str(e), e
 mono, k, d, lvl = ex(img[1])
 wm, wk, wd = O.Oracle(1000).extract(img[1], (0, 1000))
 assert mono == wm and k.tobytes() == wk.tobytes() and np.array_equal(d, wd), "stale leaf tables"

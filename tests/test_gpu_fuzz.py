@@ -1,6 +1,6 @@
 """Bounded, seeded randomised parity sweep under -m gpu: tools/fuzz_parity.py's generator (random image sizes, feature counts,
 level counts, scale factors 1.1-2.0, thresholds, lapping areas, content), every stage and the final arrays against the oracle,
-under each kernel-variant switch.  The totals are written to gpurun_out/r04_fuzz_parity.json on the GPU box (copied to
+under each kernel-variant switch.  The totals are written to gpurun_out/r05_fuzz_parity.json on the GPU box (copied to
 profiles/r02_fuzz_parity.md)."""
 import json
 import os
@@ -13,38 +13,39 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 pytestmark = pytest.mark.gpu
 
-# (environment switches, cases, seed): the switches are read by orbx_create
+# (switches, cases, seed): ORBX_* = launch-policy switches in the environment, read once by orbx_create; "aid:*" = test aids, set through
+# orbx_debug_set_option (they cannot come from the environment): helpers.apply_switches
 CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THREADS": "512"}, 8, 103),
            ({"ORBX_OCT_THREADS": "1024"}, 8, 104), ({}, 8, 105), ({}, 8, 106),
            # FAST with a workgroup per cell (the form of calls with few cells, round 3) whatever the size, and never
-           ({"ORBX_FAST_WIDE": "1"}, 8, 121), ({"ORBX_FAST_WIDE": "0"}, 8, 122), ({"ORBX_FAST_WIDE": "1", "ORBX_LEAF_FRAMES": "0", "ORBX_LDS_POLLUTE": "77"}, 8, 123),
+           ({"ORBX_FAST_WIDE": "1"}, 8, 121), ({"ORBX_FAST_WIDE": "0"}, 8, 122), ({"ORBX_FAST_WIDE": "1", "ORBX_LEAF_FRAMES": "0", "aid:lds_pollute": "77"}, 8, 123),
            ({"ORBX_RESIZE_BYTEWISE": "1"}, 8, 107),
            # the 128-VGPR quad-tree variants (short phase-2 passes) at every workgroup size; seed 103 draws sparse levels
            ({"ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 103), ({"ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            ({"ORBX_OCT_THREADS": "1024", "ORBX_OCT_ROOMY": "1"}, 8, 108),
            # the pyramid as one launch per level (the form of large batches of large frames), and region by region with the coarser cuts
            ({"ORBX_PYR_COLS": "0"}, 8, 117), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "56"}, 8, 118), ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "112"}, 8, 119),
-           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_RESIZE_BYTEWISE": "1", "ORBX_LDS_POLLUTE": "201"}, 8, 120),
+           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_RESIZE_BYTEWISE": "1", "aid:lds_pollute": "201"}, 8, 120),
            # every device allocation of the handle filled with a byte pattern: nothing may depend on what hipMalloc returns
-           ({"ORBX_POISON": "165"}, 8, 111), ({"ORBX_POISON": "255"}, 8, 112),
+           ({"aid:poison": "165"}, 8, 111), ({"aid:poison": "255"}, 8, 112),
            # ... nor on what the previous workgroup left in LDS (every CU's LDS filled with a byte in front of every kernel)
-           ({"ORBX_LDS_POLLUTE": "165"}, 8, 113), ({"ORBX_LDS_POLLUTE": "255", "ORBX_POISON": "90"}, 8, 114),
+           ({"aid:lds_pollute": "165"}, 8, 113), ({"aid:lds_pollute": "255", "aid:poison": "90"}, 8, 114),
            # small batches start the quad-tree from k_fast's leaf tables by default (round 3); these keep the kernel's own first sweep under test
            ({"ORBX_LEAF_FRAMES": "0"}, 8, 115), ({"ORBX_LEAF_FRAMES": "0", "ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            # ... and the leaf tables with poisoned allocations (they must be zero between calls whatever hipMalloc returned)
-           ({"ORBX_POISON": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116),
+           ({"aid:poison": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116),
            # round 4: the region-major pyramid that also blurs (the finest five levels, and all of them), the copy-back form of the one-frame host call
            ({"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1"}, 8, 124),
-           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_BLUR_IN_COLS": "1", "ORBX_BLUR_IN_LEVELS": "8", "ORBX_LDS_POLLUTE": "99"}, 8, 125),
-           ({"ORBX_ZERO_COPY": "0", "ORBX_POISON": "33"}, 8, 126)]
+           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_BLUR_IN_COLS": "1", "ORBX_BLUR_IN_LEVELS": "8", "aid:lds_pollute": "99"}, 8, 125),
+           ({"ORBX_ZERO_COPY": "0", "aid:poison": "33"}, 8, 126)]
 _totals = []
 
 
 @pytest.mark.parametrize("env,n,seed", CONFIGS, ids=[",".join("%s=%s" % kv for kv in c[0].items()) or "default" for c in CONFIGS])
 def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
     import fuzz_parity
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    import helpers
+    helpers.apply_switches(env, monkeypatch)
     done, skipped, nkp, nbytes = fuzz_parity.run(n, seed)
     assert done + skipped == n and done >= n // 2
     _totals.append(dict(switches=env, seed=seed, drawn=n, bit_exact=done, rejected_geometries=skipped, keypoints=nkp,
@@ -52,7 +53,7 @@ def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        json.dump(_totals, open(os.path.join(out, "r04_fuzz_parity.json"), "w"), indent=1)
+        json.dump(_totals, open(os.path.join(out, "r05_fuzz_parity.json"), "w"), indent=1)
     except OSError:
         pass
 
@@ -72,7 +73,7 @@ def test_seeded_batch_shape_sweep_under_the_overlap_policies(env, monkeypatch):
     """The same sweep with every batch counted as large (ORBX_SPLIT_MIN_MPX=0), so that the overlap forms of large batches - the blur on its side
     stream (the default), staggered tails - and the blurring pyramid meet every batch shape, not only the benchmark's."""
     import fuzz_batches
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    import helpers
+    helpers.apply_switches(env, monkeypatch)
     done, skipped, checked = fuzz_batches.run(10, 37)
     assert done + skipped == 10 and done >= 8 and checked >= 2 * done

@@ -20,14 +20,16 @@ def checker(tmp_path_factory):
     return exe
 
 
-def run(exe, cols, rows, nlevels, sf):
-    r = subprocess.run([exe, str(cols), str(rows), str(nlevels), str(sf)], capture_output=True, text=True, timeout=300)
+def run(exe, cols, rows, nlevels, sf, env=None):
+    r = subprocess.run([exe, str(cols), str(rows), str(nlevels), str(sf)], capture_output=True, text=True, timeout=300,
+                       env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, "%dx%d levels %d scale %s: %s" % (cols, rows, nlevels, sf, r.stdout.strip())
     return r.stdout.strip()
 
 
 @pytest.mark.parametrize("cols,rows,nlevels,sf", [(640, 480, 8, 1.2), (752, 480, 8, 1.2), (517, 333, 8, 1.2), (1241, 376, 8, 1.2), (1920, 1080, 8, 1.2),
-                                                  (752, 480, 12, 1.1), (800, 600, 3, 2.0), (322, 241, 2, 1.2), (512, 512, 4, 1.5), (1280, 720, 8, 1.2)])
+                                                  (752, 480, 12, 1.1), (800, 600, 3, 2.0), (322, 241, 2, 1.2), (512, 512, 4, 1.5), (1280, 720, 8, 1.2),
+                                                  (1014, 432, 2, 1.5), (1014, 432, 2, 1.2), (1018, 433, 3, 1.3)])      # (w % 4 == 2: DESIGN.md 4j)
 def test_the_cuts_rebuild_the_level_by_level_pyramid(checker, cols, rows, nlevels, sf):
     out = run(checker, cols, rows, nlevels, sf)
     assert out.startswith("ok") and not out.endswith(": 0 cuts"), out
@@ -43,3 +45,14 @@ def test_random_geometries(checker):
         out = run(checker, cols, rows, nlevels, sf)
         ok += out.startswith("ok")
     assert ok >= 12      # (the rest are geometries orbx_create rejects: a level narrower than a FAST cell)
+
+
+@pytest.mark.parametrize("cols,rows,nlevels,sf", [(1014, 432, 2, 1.5), (640, 480, 8, 1.2), (517, 333, 4, 1.3), (1920, 1080, 8, 1.2)])
+def test_no_uninitialised_byte_reaches_the_tables(checker, cols, rows, nlevels, sf):
+    """the geometry of the one unexplained border miscompare (1014 x 432, two levels) and the benchmark's, built under two
+    MALLOC_PERTURB_ fills (glibc writes the complement of the byte into every malloc'ed block and the byte into every freed one): the hash
+    over every table the kernels read - level records, cells, resize coefficients, column records, every region's rectangles / owned
+    rectangles / dealing / coefficient lists of every cut - must not move."""
+    outs = [run(checker, cols, rows, nlevels, sf, env=e) for e in (None, {"MALLOC_PERTURB_": "17"}, {"MALLOC_PERTURB_": "201"})]
+    hashes = {o.split(" hash ")[1].split(":")[0] for o in outs}
+    assert all(o.startswith("ok") for o in outs) and len(hashes) == 1, outs

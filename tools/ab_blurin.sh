@@ -2,7 +2,7 @@
 # A/B of the blur inside the region-major pyramid (ORBX_BLUR_IN_COLS=1, the finest ORBX_BLUR_IN_LEVELS levels) against the separate k_blur, per
 # batch size, alternating inside ONE call (memory-bound kernels are bimodal between processes).
 # usage (GPU box): CFGS="in,levels,shape ..." bash tools/ab_blurin.sh [workload] [batches]
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}"
 WL=${1:-mono640}; BS=${2:-"512 128 32"}
 for b in $BS; do for cfg in ${CFGS:-0,5,-1 1,3,-1 1,5,-1 0,5,-1}; do IFS=, read a l v <<< "$cfg"
   ORBX_SPLIT=0 ORBX_BLUR_IN_COLS=$a ORBX_BLUR_IN_LEVELS=$l ORBX_PYR_COLS_VARIANT=$v python bench.py --workload $WL --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-verify 2>/dev/null | python -c "

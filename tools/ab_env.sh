@@ -1,7 +1,7 @@
 #!/bin/bash
 # Generic A/B of environment switches inside ONE gpurun call (alternating; memory-bound kernels are bimodal between processes).
 # usage (GPU box): bash tools/ab_env.sh "<bench args>" "ENV1=a ENV2=b" "ENV1=c" ...      (each quoted group = one configuration; "" = defaults)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}"
 ARGS=$1; shift
 for rep in 1 2; do for cfg in "$@"; do
   env $cfg python bench.py $ARGS --no-cpu-baseline --no-extras --no-verify 2>/dev/null | python -c "

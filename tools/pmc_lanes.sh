@@ -2,7 +2,7 @@
 # GPU box: lane utilisation and instruction counts per kernel (SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)), optionally for other builds of the
 # library (diagnostic knock-outs).   usage: tools/pmc_lanes.sh [library ...]
 cd /tmp && export TMPDIR=/tmp ORBX_SPLIT=0
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}
 for lib in "" "$@"; do
   tag=$(echo "${lib:-default}" | tr '/.' '__')
   [ -n "$lib" ] && export ORBX_LIBRARY=$R/$lib

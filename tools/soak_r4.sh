@@ -1,7 +1,7 @@
 #!/bin/bash
 # Longer fuzz soaks of round 4's forms on the GPU box (one gpurun call): single frames and batch shapes under the default policy, the patch blur,
 # the blurring pyramid, the copy-back host path and the forced overlap forms.  Totals -> gpurun_out/r4_soak.txt
-cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4_soak.txt; : > $OUT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}"; OUT=gpurun_out/r4_soak.txt; : > $OUT
 run() { echo "## $1 :: $2" >> $OUT; env $1 timeout -k 10 600 python $2 2>&1 | tail -1 >> $OUT || echo "FAILED" >> $OUT; }
 run "" "tools/fuzz_parity.py 150 401"
 run "ORBX_PATCH_BLUR=1" "tools/fuzz_parity.py 120 402"

@@ -2,7 +2,7 @@
 # Fuzz soak of the second half of round 4 (one polarity per pixel in k_fast's score pass, pair ballots in its NMS (the prefilter
 # variant was still there when this ran: rows 602 / 603 / 614 forced it on and off), k_pyr_cols' bank row records / host-made dealing / straight writer runs, the blur's dot4 horizontal sums and saturating pack) on the GPU
 # box: every FAST variant forced, both pyramid forms, every blur form.  Totals -> gpurun_out/r4b_soak.txt
-cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4b_soak.txt; : > $OUT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}"; OUT=gpurun_out/r4b_soak.txt; : > $OUT
 run() { echo "## $1 :: $2" >> $OUT; env $1 timeout -k 10 600 python $2 2>&1 | tail -1 >> $OUT || echo "FAILED" >> $OUT; }
 run "" "tools/fuzz_parity.py 300 601"
 run "" "tools/fuzz_parity.py 200 602"

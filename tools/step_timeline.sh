@@ -2,7 +2,7 @@
 # GPU box: kernel start / end times of ONE overlapped step of the default bench (rocprofv3 --kernel-trace), relative to the step's first kernel.
 # usage: tools/step_timeline.sh [bench args]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}
 rm -rf $R/gpurun_out/step_tl
 timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/step_tl --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-verify "$@" > $R/gpurun_out/step_tl.log 2>&1
 python3 - "$(find $R/gpurun_out/step_tl -name '*kernel_trace.csv' | head -1)" <<'PY'

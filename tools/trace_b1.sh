@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp ORBX_SPLIT=0
+R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}; cd /tmp; export TMPDIR=/tmp ORBX_SPLIT=0
 rm -rf $R/gpurun_out/trace_b1; mkdir -p $R/gpurun_out/trace_b1
 timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/trace_b1 --output-format csv -- python3 $R/bench.py --steps 50 --warmup 5 --batch 1 --no-cpu-baseline --no-extras > $R/gpurun_out/trace_b1/log.txt 2>&1
 cd $R; f=$(find gpurun_out/trace_b1 -name "*kernel_trace.csv" | head -1); python3 - "$f" <<'PY'

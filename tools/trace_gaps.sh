@@ -1,7 +1,7 @@
 #!/bin/bash
 # Launch boundaries of a single-frame call at several frame sizes (rocprofv3 --kernel-trace): the gap between a kernel's end and the next one's
 # start against the bytes the first one wrote.  usage (GPU box): bash tools/trace_gaps.sh
-R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp ORBX_SPLIT=0
+R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}; cd /tmp; export TMPDIR=/tmp ORBX_SPLIT=0
 for sz in "240 320" "480 640" "720 1280" "1080 1920"; do set -- $sz
   rm -rf $R/gpurun_out/trace_gap; mkdir -p $R/gpurun_out/trace_gap
   timeout -k 10 200 rocprofv3 --kernel-trace -d $R/gpurun_out/trace_gap --output-format csv -- python3 $R/tools/gap_probe.py $1 $2 60 > $R/gpurun_out/trace_gap/log.txt 2>&1
