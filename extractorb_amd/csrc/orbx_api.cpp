@@ -83,6 +83,9 @@ void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const i
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 void launchClockProbe(hipStream_t, unsigned long long*, int, int, unsigned);
+size_t pipeLdsBytes(int M, int P, int R, int XT);
+bool pipeCanRun(int maxRoiW, int maxRoiH);
+void launchPipe(hipStream_t, const PipeArgs&, int itemsPerFrame, int frames, size_t ldsBytes);
 }  // namespace orbx
 
 using namespace orbx;
@@ -227,6 +230,12 @@ struct orbx_handle {
     int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
     unsigned short* d_rowList = nullptr;
     float *d_uRight = nullptr, *d_depth = nullptr;
+    // the pipelined launch (k_pipe.hip; enqueueBatch): role tables of the current geometry, one per set of roles a pipeline step can hold
+    PipeRole* d_roles = nullptr;
+    size_t rolesCap = 0, roleOff[16] = {};
+    int roleCount[16] = {};
+    int pipeMode = 0;                  // ORBX_PIPE=1: every full call of frames up to half a megapixel runs pipelined (opt-in: measured slower)
+    int pipeChunk = 128;               // ORBX_PIPE_CHUNK: frames per pipeline step
     // clock probe (orbx_debug_clock_probe: bench.py's sustained-load figure), allocated on first use
     hipStream_t probeStream = nullptr;
     unsigned long long* d_clock = nullptr;
@@ -282,7 +291,7 @@ void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_xq, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
-                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth, h->d_clock};
+                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth, h->d_clock, h->d_roles};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
@@ -415,6 +424,36 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         stage(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size());
         stage(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size());
     }
+    // ---- role tables of the pipelined launch (k_pipe.hip): for every set of roles a pipeline step can hold, the order in which a frame's
+    //      workgroups are dispatched: the quad-tree levels first (the longest chains of barriers start earliest, level 0 = the heaviest first),
+    //      then FAST chunks, keypoint groups and blur blocks interleaved evenly, so that every CU holds a mix of issue-bound and
+    //      latency-bound workgroups for the whole launch ----
+    std::vector<PipeRole> roleTab;
+    size_t roleOff[16] = {};
+    int roleCount[16] = {};
+    {
+        const int fastChunks = ((int)g.cells.size() + 3) / 4, descGroups = (g.selPerFrame + 7) / 8, blurBlocks = (nBlurLanes[0] + 255) / 256;
+        for (int mask = 1; mask < 16; mask++) {
+            roleOff[mask] = roleTab.size();
+            if (mask & (1 << kPipeO))
+                for (int l = 0; l < g.nlevels; l++) roleTab.push_back(PipeRole{(unsigned short)kPipeO, (unsigned short)l});
+            const int roles3[3] = {kPipeF, kPipeD, kPipeB};
+            const int want[3] = {mask & (1 << kPipeF) ? fastChunks : 0, mask & (1 << kPipeD) ? descGroups : 0, mask & (1 << kPipeB) ? blurBlocks : 0};
+            int done[3] = {0, 0, 0};
+            for (int k = want[0] + want[1] + want[2]; k > 0; k--) {
+                int best = -1;
+                for (int r = 0; r < 3; r++)      // the role with the largest share of its items still to come (ties: FAST first)
+                    if (done[r] < want[r] && (best < 0 || (long long)(want[r] - done[r]) * want[best] > (long long)(want[best] - done[best]) * want[r])) best = r;
+                roleTab.push_back(PipeRole{(unsigned short)roles3[best], (unsigned short)done[best]});
+                done[best]++;
+            }
+            roleCount[mask] = (int)(roleTab.size() - roleOff[mask]);
+            if (fastChunks > 65535 || descGroups > 65535 || blurBlocks > 65535 || roleCount[mask] > 65535) { roleCount[mask] = 0; roleTab.resize(roleOff[mask]); }      // (no pipelined form for this geometry)
+        }
+    }
+    const size_t roleAt = (image.size() + 15) & ~(size_t)15;      // (the tables ride in the same staging block; their device block is sized below)
+    image.resize(roleAt + roleTab.size() * sizeof(PipeRole));
+    if (!roleTab.empty()) std::memcpy(image.data() + roleAt, roleTab.data(), roleTab.size() * sizeof(PipeRole));
     // ---- pass 2: the uploads, in stream order ----
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // the device tables and the staging block may still be in use by queued work
     h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
@@ -427,11 +466,20 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipHostMalloc(&h->h_tab, want));
         h->hTabBytes = want;
     }
+    if (roleTab.size() > h->rolesCap) {      // (after the wait above: nothing queued reads the old tables)
+        if (h->d_roles) (void)hipFree(h->d_roles);
+        h->d_roles = nullptr; h->rolesCap = 0;
+        const size_t want = roleTab.size() + roleTab.size() / 4 + 64;
+        HIP_TRY(h, hipMalloc(&h->d_roles, want * sizeof(PipeRole)));
+        h->rolesCap = want;
+    }
     std::memcpy(h->h_tab, image.data(), image.size());
     for (const Upload& u : ups) HIP_TRY(h, hipMemcpyAsync(u.dst, h->h_tab + u.at, u.bytes, hipMemcpyHostToDevice, h->stream));
+    if (!roleTab.empty()) HIP_TRY(h, hipMemcpyAsync(h->d_roles, h->h_tab + roleAt, roleTab.size() * sizeof(PipeRole), hipMemcpyHostToDevice, h->stream));
     for (int l = 0; l < kMaxLevels; l++) { h->rxOff[l] = rxOff[l]; h->ryOff[l] = ryOff[l]; h->xqOff[l] = xqOff[l]; h->footOff[l] = footOff[l]; }
     for (int i = 0; i < 8; i++) { h->colsOff[i] = colsOff[i]; h->colCoefOff[i] = colCoefOff[i]; }
     for (int v = 0; v < 3; v++) { h->nBlurLanes[v] = nBlurLanes[v]; h->blurItemOff[v] = blurItemOff[v]; h->blurLaneOff[v] = blurLaneOff[v]; }
+    for (int m = 0; m < 16; m++) { h->roleOff[m] = roleOff[m]; h->roleCount[m] = roleCount[m]; }
     {
         const long long px = (long long)g.lv[0].w * g.lv[0].h;
         int T = px <= 500000 ? 256 : (px <= 1200000 ? 512 : 1024);   // measured: 640x480 -> 256, 1280x720 -> 512, 1920x1080 -> 1024 (512 equal)
@@ -510,11 +558,19 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // patch reads at large frames, and the one raw tile is fewer bytes than a raw + a blurred one.  Measured (us per step, k_blur beside FAST ->
     // patch blur): 128 x 1920x1080 x 2000 (ratio 0.50) 3041-3052 -> 2717-2723; 128 x 1280x720 x 1500 (0.84) 1448-1455 -> 1358-1364; 512 x 640x480 x
     // 1000 (1.67) 1929-1937 -> 1993-2000: taken up to a ratio of 1.25.  ORBX_PATCH_BLUR=1 / 0 forces / forbids it.
+    // Round 5: ... and up to a ratio of 1.75 once the batch is large (>= 240 Mpx of pyramid: 256 frames of 640x480 x 1000).  Since round 4's
+    // instruction work the two forms are level there (512 x 640x480 x 1000: 1725-1729 us with k_blur beside FAST, 1735 with the patch blur, A/B in
+    // one gpurun call, -0.4 ... -0.6 %; 256 / 1024 frames the same; 64 frames -1.5 %, 1200 features per frame -3.5 %: not taken there), and the
+    // patch blur moves 4.75 MB per frame through HBM instead of 8.0 (no blurred level is written or re-read) and leaves the
+    // blurred arena (1 MB per frame) untouched: where the clock says "equal", the bytes decide.
     // A back-only pass (orbx_compute_keypoints_octree) describes from what the front part of the EARLIER call left: if that call blurred per
     // keypoint (form 3) no blurred level exists and this pass must do the same, whatever its own frame count would choose; otherwise the blurred
     // levels exist (or are owed to the FAST launch: blurOwed) and are used.
+    const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
+    const long long patchPx4 = (long long)h->nfeatures * 43 * 37 * 4;      // 4 x the patches' pixels of horizontal pass
     const bool patchBlur = !(stages & kStageFront) ? h->lastBlurForm == 3
-                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (long long)h->nfeatures * 43 * 37 * 4 <= 5LL * g.sumPixels));
+                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (patchPx4 <= 5LL * g.sumPixels || (bigBatch && patchPx4 <= 7LL * g.sumPixels)) &&
+                                                 h->pipeMode <= 0));      // (the pipelined form deals the blur's rows to its launches)
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     // Overlap inside one call (round 4): the blurred levels are read by k_description only, the LAST launch, so the blur of a large batch runs on
     // a side stream beside FAST and the quad-tree: pyramid -> {blur | FAST -> quad-tree} -> description.  k_blur is the one HBM-bound kernel of the
@@ -523,8 +579,17 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // 999-1007; 128 x 1080p 3094-3136 (halves) -> 3021-3029; 128 frames of 640x480 and fewer: no difference.  A low-priority side stream only starts
     // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time).  (Round 2's two
     // half-batches side by side - removed in round 4 - are the "halves" figures above; profiles/r02_split_sweep.md.)
-    const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
-    const bool blurSide = h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
+    // The pipelined form (round 5; k_pipe.hip): the stages behind the pyramid as ONE launch per pipeline step over chunks of the batch - step t
+    // holds the FAST cells and blur rows of chunk t, the quad-tree levels of chunk t - 1 and the keypoints of chunk t - 2, interleaved workgroup
+    // by workgroup, every dependency pointing to an earlier launch.  Built as round 4's verdict asked, bit-exact, and MEASURED SLOWER than the
+    // launch DAG below (512 x 640x480: 1813-1824 us against 1700-1709; DESIGN.md 4k has the timeline and the reason: the step already runs at
+    // 0.90 of the SUM of its kernels' issue times, a workgroup of the mixed launch reserves the union of the roles' LDS - six per CU instead of
+    // FAST's eight - and every wave slot a latency-bound role holds is one FAST cannot hide its own latencies with), so nothing selects it by
+    // default: ORBX_PIPE=1 takes it for every full call of frames up to half a megapixel (the quad-tree role is the 256-thread body).
+    const bool pipeOK = (stages & kStageFront) && (stages & kStageBack) && !h->profiling && !patchBlur && !h->d_octArena && h->octThreads[0] == 256 &&
+                        pipeCanRun(g.maxRoiW, g.maxRoiH) && h->roleCount[15] > 0 && !h->resizeBytewise;
+    const bool pipe = pipeOK && h->pipeMode > 0;
+    const bool blurSide = !pipe && h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
     bool blurJoin[2] = {false, false};
     int blurF0[2] = {0, 0}, blurBn[2] = {0, 0};
     auto front = [&](hipStream_t st, int f0, int Bn) {
@@ -548,7 +613,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             cs = pickCut(g.colSets);
             // ORBX_BLUR_IN_COLS=1: the regions also blur what they own of the finest levels before they move on (bit-exact; slower than k_blur
             // beside FAST: DESIGN.md §4)
-            if (cs && h->blurInCols > 0 && !patchBlur) {
+            if (cs && h->blurInCols > 0 && !patchBlur && !pipe) {
                 const FrameGeom::ColumnSet* cb = pickCut(g.colSetsBlur);
                 if (cb && cb->px == cs->px) cs = cb;
             }
@@ -588,9 +653,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
-        h->lastBlurForm = patchBlur ? 3 : (blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0));
-        h->blurOwed = !patchBlur && !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
-        if (patchBlur) {
+        h->lastBlurForm = pipe ? 4 : (patchBlur ? 3 : (blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0)));
+        h->blurOwed = !pipe && !patchBlur && !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
+        if (pipe) {
+            // (the blur rows are a role of the pipelined launches below)
+        } else if (patchBlur) {
             // (k_describe blurs per keypoint: no blurred level is written)
         } else if (blurInside) {
             if (h->nBlurLanes[2] > 0) {      // the coarse levels the regions do not blur
@@ -701,7 +768,30 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // whole-batch pyramid would leave the blur to the FIRST half's FAST launch only — found by the batch-shape fuzz)
     const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 4 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
                          !h->profiling && B >= 2 && bigBatch && doFront && doBack && !blurRidesWithFast(B);
-    if (stagger) {
+    if (pipe) {
+        front(st, 0, B);      // the pyramid of the whole batch (k_pyr_cols; the blur is a role of the steps)
+        const int Bc = h->pipeChunk, C = (B + Bc - 1) / Bc;
+        const size_t ldsBytes = pipeLdsBytes(h->octM, h->octP, h->octR, h->octXT);
+        PipeArgs a{};
+        a.lv = h->d_lv; a.nlevels = g.nlevels; a.pyr = h->d_pyr; a.blur = h->d_blur;
+        a.cells = h->d_cells; a.nCells = (int)g.cells.size(); a.iniTh = h->iniTh; a.minTh = h->minTh; a.candSeg = h->d_candSeg; a.cellCount = h->d_cellCount;
+        a.blurItems = h->d_tiles + h->blurItemOff[0]; a.laneItem = h->d_laneItem + h->blurLaneOff[0]; a.nBlurLanes = h->nBlurLanes[0];
+        a.cellOff = h->d_cellOff; a.candPos = h->d_candPos; a.candCount = h->d_candCount; a.nodeOf = h->d_nodeOf; a.sel = h->d_sel; a.selPerFrame = g.selPerFrame;
+        a.levelCount = h->d_levelCount; a.levelLap = h->d_levelLap; a.lapArea = h->d_lap; a.M = h->octM; a.P = h->octP; a.R = h->octR; a.XT = h->octXT;
+        a.outK = d_kps; a.outD = d_desc; a.capacity = capacity; a.nOut = d_nOut; a.monoOut = d_monoOut; a.outLevelK = d_levelK; a.outLevelCounts = d_levelCounts;
+        auto chunkOf = [&](int c, int& f0, int& n) { f0 = c * Bc; n = c >= 0 && c < C ? std::min(Bc, B - f0) : 0; if (n == 0) f0 = 0; };
+        for (int t = 0; t < C + 2; t++) {
+            chunkOf(t, a.fF0, a.fFn);
+            a.bF0 = a.fF0; a.bFn = a.fFn;
+            chunkOf(t - 1, a.oF0, a.oFn);
+            chunkOf(t - 2, a.dF0, a.dFn);
+            const int mask = (a.fFn ? (1 << kPipeF) | (1 << kPipeB) : 0) | (a.oFn ? 1 << kPipeO : 0) | (a.dFn ? 1 << kPipeD : 0);
+            a.roles = h->d_roles + h->roleOff[mask];
+            pollute(st);
+            launchPipe(st, a, h->roleCount[mask], std::max(a.fFn, std::max(a.oFn, a.dFn)), ldsBytes);
+        }
+        h->lastKernel[S_FAST] = h->lastKernel[S_OCTREE] = h->lastKernel[S_DESCRIBE] = h->lastKernel[S_BLUR] = "k_pipe";
+    } else if (stagger) {
         struct Join {
             orbx_handle* h; hipStream_t st; bool armed = false;
             ~Join() { if (armed) { (void)hipEventRecord(h->evJoin, h->aux); (void)hipStreamWaitEvent(st, h->evJoin, 0); } }
@@ -966,6 +1056,8 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = envInt("ORBX_SPLIT", 1);
+    h->pipeMode = envInt("ORBX_PIPE", 0);
+    h->pipeChunk = std::max(1, envInt("ORBX_PIPE_CHUNK", 128));
     h->fuseSmall = envInt("ORBX_FUSE_SMALL", 1) != 0;
     {
         const char* e = getenv("ORBX_SPLIT_MIN_MPX");

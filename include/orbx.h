@@ -373,7 +373,8 @@ int orbx_debug_search_rounds(int* out4);
 /* Which launch forms the last call took (results never depend on them; the parity tests assert the form they mean to cover and the
  * published timings name theirs): pyramid_form 0 = k_pyr_cols (region-major, *pyramid_cut_px = side of its regions), 1 = k_pyr_first +
  * one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the FAST launch, 2 = inside k_pyr_cols (k_blur keeps the coarse levels), 3 = per
- * keypoint inside k_describe (no blurred level exists: orbx_debug_get_blurred has nothing to show). */
+ * keypoint inside k_describe (no blurred level exists: orbx_debug_get_blurred has nothing to show), 4 = blur rows dealt to the pipelined
+ * launches (k_pipe: large batches; the FAST cells, quad-tree levels and keypoints of successive chunks of the batch share each launch). */
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
 
 /* Test aids.  They cannot be set from the environment: a test calls this BEFORE orbx_create and the handles created afterwards carry the

@@ -67,8 +67,10 @@ def test_seeded_batch_shape_sweep():
 
 
 @pytest.mark.parametrize("env", [{"ORBX_SPLIT_MIN_MPX": "0"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3"},
-                                 {"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1", "ORBX_SPLIT_MIN_MPX": "0"}],
-                         ids=["blur-aside", "staggered-tails", "blur-in-regions"])
+                                 {"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1", "ORBX_SPLIT_MIN_MPX": "0"},
+                                 # round 5: the pipelined launches (k_pipe) for every batch shape the form admits, chunks of 5 and of 32 frames, the first with polluted LDS
+                                 {"ORBX_PIPE": "1", "ORBX_PIPE_CHUNK": "5", "aid:lds_pollute": "119"}, {"ORBX_PIPE": "1", "ORBX_PIPE_CHUNK": "32", "aid:poison": "201"}],
+                         ids=["blur-aside", "staggered-tails", "blur-in-regions", "pipelined-5", "pipelined-32"])
 def test_seeded_batch_shape_sweep_under_the_overlap_policies(env, monkeypatch):
     """The same sweep with every batch counted as large (ORBX_SPLIT_MIN_MPX=0), so that the overlap forms of large batches - the blur on its side
     stream (the default), staggered tails - and the blurring pyramid meet every batch shape, not only the benchmark's."""

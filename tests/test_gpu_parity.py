@@ -329,6 +329,59 @@ def test_fast_on_dense_natural_and_sparse_content():
             assert_same_result(out[f][:3], want, "%s frame %d" % (variant, f))
 
 
+@pytest.mark.parametrize("B,chunk", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 4), (9, 16), (24, 8)])
+def test_pipelined_launches_give_the_serial_result(B, chunk, monkeypatch):
+    """Round 5: the stages behind the pyramid as one launch per pipeline step (k_pipe.hip) - FAST cells + blur rows of chunk t, quad-tree levels
+    of chunk t - 1, keypoints of chunk t - 2 in one grid - forced for small batches with chunks that do and do not divide the batch (a short
+    last chunk, a chunk larger than the batch, one-frame chunks): every frame's final arrays, per-level keypoints and blurred levels against the
+    oracle, and byte for byte against the serial launches of the same extractor parameters."""
+    parts = [("noise", 21, (B + 2) // 3), ("natural", 22, (B + 1) // 3), ("sparse", 23, B // 3)]
+    frames = np.concatenate([synth.frames(v, seed, n, 480, 640) for v, seed, n in parts if n > 0])[:B]
+    assert len(frames) == B
+    lap = [(0, 1000) if f % 2 == 0 else (100 + 7 * f, 400) for f in range(B)]
+    monkeypatch.setenv("ORBX_PIPE", "0")
+    serial = X.ORBextractor(1000, max_batch=B).extract_batch(frames, lap)
+    monkeypatch.setenv("ORBX_PIPE", "1")
+    monkeypatch.setenv("ORBX_PIPE_CHUNK", str(chunk))
+    ex = X.ORBextractor(1000, max_batch=B)
+    assert "PIPE=1(env)" in ex.policy() and "PIPE_CHUNK=%d(env)" % chunk in ex.policy()
+    out = ex.extract_batch(frames, lap)
+    assert ex.last_forms()[2] == 4, ex.last_forms()          # the blur rows rode in the pipelined launches
+    for f in range(B):
+        assert_same_result(out[f][:3], serial[f][:3], "pipelined vs serial, frame %d" % f)
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(out[f][3], serial[f][3])), "per-level keypoints, frame %d" % f
+    for f in sorted({0, B // 2, B - 1}):
+        o, want = oracle_run(frames[f], 1000, lap[f])
+        assert_same_result(out[f][:3], want, "pipelined vs oracle, frame %d" % f)
+        for l in (0, 3, 7):
+            assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "blurred level %d of frame %d" % (l, f)
+    again = ex.extract_batch(frames[::-1].copy(), lap[::-1])          # the same handle again (what bench.py's timed steps do)
+    for f in range(B):
+        assert_same_result(again[B - 1 - f][:3], out[f][:3], "second call, frame %d" % f)
+
+
+def test_pipelined_launches_on_a_large_batch_with_the_default_chunk(monkeypatch):
+    """256 frames of 640x480 x 1000 features as two pipeline chunks of 128 (ORBX_PIPE=1; the form is opt-in: it measured slower than the launch
+    DAG): first / last frames of each chunk against the oracle; without the switch the same batch takes the serial forms and
+    gives the same bytes."""
+    B = 256
+    base = synth.frames("noise", 0, 16, 480, 640)
+    frames = np.concatenate([base] * (B // 16))
+    frames[127] = synth.frames("textured", 1, 1, 480, 640)[0]
+    frames[128] = synth.frames("natural", 2, 1, 480, 640)[0]
+    ref = X.ORBextractor(1000, max_batch=B)
+    want = ref.extract_batch(frames)
+    assert ref.last_forms()[2] == 3, ref.last_forms()          # the default of large batches: the blur per keypoint inside k_describe
+    monkeypatch.setenv("ORBX_PIPE", "1")
+    ex = X.ORBextractor(1000, max_batch=B)
+    out = ex.extract_batch(frames)
+    assert ex.last_forms()[2] == 4, ex.last_forms()
+    for f in (0, 127, 128, 255):
+        assert_same_result(out[f][:3], oracle_run(frames[f])[1], "256 frames pipelined, frame %d" % f)
+    for f in range(B):
+        assert_same_result(out[f][:3], want[f][:3], "pipelined vs default, frame %d" % f)
+
+
 def test_async_host_api_with_two_handles_and_pinned_input():
     """orbx_extract_batch_begin / _end called directly (the test was lost with the prefilter variant): two handles in flight, a
     second begin on a busy handle and an end without a begin are errors, and every branch of the upload - pinned memory copied as it lies,
