@@ -96,6 +96,15 @@ constexpr int kPbRows = 2 * (kBriefReach + 3) + 1;    // 43
 constexpr int kPbStride = 44;                         // 11 dwords
 constexpr int kPbRawBytes = (kPbRows * kPbStride + 15) & ~15;               // 1904
 constexpr int kPbLds = kPbRawBytes + kBlurRows * kBlurStride;               // 3384 bytes per keypoint
+// The patch blur's lanes (round 5).  The rotated pattern only reaches a DISC of the 37 x 37 blurred patch: a sample (row r, column q) is the
+// rounding of a point at most sqrt(338) = 18.385 from the keypoint (the largest |(x, y)| of the pattern, ORBextractor.cc:148-406), so column
+// group g (columns q = 4 g - 18 .. 4 g - 15) is read at |r| <= rmax(g) = floor(1/2 + sqrt(338.5 - max(min|q| - 1/2, 0)^2)) only: 11, 15, 17, 18,
+// 18, 18, 18, 16, 13, 6 -> 310 of the box's 370 (group, row) items; tests/test_tables.py derives the bounds from the pattern and sweeps every
+// 0.0005 degrees for samples outside them.  The 32 lanes of a keypoint take (group, first row, rows) runs of at most 12 rows (six trips of the
+// two-row blur loop; the box dealt as 10 groups x 3 runs of 13 was seven): entry = group | first row << 8 | rows << 16.
+static __constant__ unsigned c_pbRun[32] = {
+    0x0c0700, 0x0b1300, 0x0c0301, 0x0a0f01, 0x091901, 0x0c0102, 0x0c0d02, 0x0b1902, 0x0a0003, 0x0a0a03, 0x0a1403, 0x071e03, 0x0a0004, 0x0a0a04, 0x0a1404, 0x071e04,
+    0x0a0005, 0x0a0a05, 0x0a1405, 0x071e05, 0x0a0006, 0x0a0a06, 0x0a1406, 0x071e06, 0x0c0207, 0x0c0e07, 0x091a07, 0x0a0508, 0x0a0f08, 0x071908, 0x080c09, 0x051409};
 
 // One half-wave (32 lanes) per kept keypoint; the two keypoints of a wave share a level (selOff is even):
 //   * both patches are staged in LDS with aligned dword loads that are all in flight at once: a half-wave covers
@@ -214,6 +223,8 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
     int m10 = 0, m01 = 0;
     uint8_t* blurT;
     int blurMis;
+    unsigned pbRun = 0;
+    if constexpr (PB) pbRun = c_pbRun[hl];      // (requested ahead of the tile's loads)
     if constexpr (PB) {
         // ---- stage the raw 43 x 44 tile, re-aligned: 8 lanes per tile row (6 load an 8-byte pair of source dwords - 4-byte aligned: one
         //      global_load_dwordx2 -, 11 re-aligned dwords stored), four rows per step: 11 load instructions per wave (dword loads: 22; the gather is bound
@@ -260,10 +271,10 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
             m10 = (int)s1 - 16 * (int)s0;     // sum u*I
             m01 = v * (int)s0;                // v * sum I
         }
-        // ---- the 7x7 blur of the 37 x 37 patch (:1126-1127): lane = (run of rows, column group); outputs o = 13 r .. read tile rows o .. o + 6 ----
-        if (hl < 30) {
-            const int r = (hl * 205) >> 11, g4 = hl - 10 * r;      // hl / 10 for hl < 32
-            const int o0 = 13 * r, nOut = r == 2 ? kBlurRows - 26 : 13;
+        // ---- the 7x7 blur of the part of the 37 x 37 patch the rotated pattern can reach (:1126-1127): lane = one (column group, run of rows) of
+        //      c_pbRun; output row o reads tile rows o .. o + 6 ----
+        {
+            const int g4 = (int)(pbRun & 0xff), o0 = (int)((pbRun >> 8) & 0xff), nOut = (int)(pbRun >> 16);
             const uint8_t* src = rawT + o0 * kPbStride + 4 * g4;
             uint8_t* dst = blurT + o0 * kBlurStride + 4 * g4;
             blurRun(nOut,

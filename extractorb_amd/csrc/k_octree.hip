@@ -82,6 +82,11 @@ __device__ unsigned long long g_octSpans[2 * 16];      // (start, end) of frame 
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
+// (256 and 512 resident threads: three waves per SIMD = 168 VGPRs, where the body needs no scratch at all - 144 - against 9 / 7 spilled
+// registers at 128; the host counts residency for these two at 768 threads per CU, launchOctree's caller.  1024 threads are four waves per SIMD
+// by themselves: 128 VGPRs is their ceiling.)
+#undef OCT_W
+#define OCT_W 3
 #define OCT_T 256
 #define OCT_NAME(x) x##_256r
 #include "k_octree_body.inc"
@@ -92,6 +97,8 @@ __device__ unsigned long long g_octSpans[2 * 16];      // (start, end) of frame 
 #include "k_octree_body.inc"
 #undef OCT_T
 #undef OCT_NAME
+#undef OCT_W
+#define OCT_W 4
 #define OCT_GLOBAL 1
 #define OCT_T 1024
 #define OCT_NAME(x) x##_1024g

@@ -2,291 +2,21 @@
 //
 // This is the product path.  It has no CPU fallback: without a HIP device orbx_create fails with
 // ORBX_ERR_NO_DEVICE, and nothing here includes, links or calls anything under oracle/.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <ctime>
-#include <string>
-#include <vector>
-
-#include "orbx.h"
-#include "orbx_geometry.hpp"
-
-namespace orbx {
-// launch wrappers, defined in the k_*.hip files
-void launchPyrFirst(hipStream_t, const uint8_t*, long long, long long, const LevelGeom&, const LevelGeom*, int, int, int, int,
-                    const ResizeX*, const QuadRec*, const ResizeX*, const TileFoot*, uint8_t*, int, int, bool, int, int);
-void launchResize(hipStream_t, const LevelGeom&, const LevelGeom&, int, int, const ResizeX*, const QuadRec*, const ResizeX*, const TileFoot*,
-                  uint8_t*, int, int, bool, int, int);
-struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kfFirst, kfStep, curFirst, curStep, twoKeyFrames; };
-size_t bowMatchLdsBytes(int capacity, bool stageDesc);
-void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
-void launchLdsPollute(hipStream_t, int, int, unsigned*);
-void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, uint8_t*, int, int, int, bool, int, int, int);
-void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
-void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
-                int, int, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
-bool fastCanCarryBlur(int, int);
-size_t octreeLdsBytes(int M, int P, int R, int XT);
-void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
-                  unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*, LeafTables);
-void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
-                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, bool, int, int);
-bool checkUmax(const int* umax16);
-hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
-struct StereoParams {
-    float scale[kMaxLevels], invScale[kMaxLevels];
-    float bf, b;
-    int nlevels, capacity, rowCap;
-};
-struct CameraParams { float fx, fy, cx, cy, k1, k2, p1, p2, k3; };
-struct FrameFinishParams { CameraParams cam; float minX, minY, wInv, hInv; int capacity; };
-void launchFrameFinish(hipStream_t, const Keypoint*, const int*, const FrameFinishParams&, Keypoint*, int*, int*, int*, int);
-void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const StereoParams&,
-                  int, int*, unsigned short*, float*, float*, int*, int*, int);
-struct InitMatchParams {
-    float minX, minY, wInv, hInv, r, nnRatio;
-    int checkOrientation, capacity, slotCapacity, f1First, f1Step, f2First, f2Step;
-};
-size_t initMatchLdsBytes(int capacity, int slotCapacity);
-int initMatchSlotCapacity(int capacity);
-void launchSearchInit(hipStream_t, const Keypoint*, const uint8_t*, const int*, const int*, const int*, const InitMatchParams&,
-                      float*, int*, int*, int);
-struct ProjQuery { float u, v, ur, radius; int minLevel, maxLevel, flags; float angle; };
-struct ProjectParams {
-    float fx, fy, cx, cy, minX, maxX, minY, maxY;
-    float scale[kMaxLevels];
-    float mbf, mb, th;
-    int mono, capacity, lastFirst, lastStep, curFirst, curStep;
-};
-struct ProjSearchParams {
-    float minX, minY, wInv, hInv, nnRatio;
-    int ratioMode, checkOrientation, capacity, queryCapacity, curFirst, curStep, descFirst, descStep, maxDist;
-};
-size_t projSearchLdsBytes(int capacity, int queryCapacity, bool topList);
-void launchProjectLast(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const float*, const float*, const ProjectParams&,
-                       ProjQuery*, int);
-void launchSearchProj(hipStream_t, const ProjQuery*, const uint8_t*, const int*, const Keypoint*, const uint8_t*, const int*, const int*,
-                      const int*, const float*, uint8_t*, const ProjSearchParams&, int*, int*, int);
-struct VocabDevice {
-    const int* childOff; const int* childList; const uint32_t* desc; const double* weight; const uint32_t* wordId;
-    int nNodes, k, L, scoring, weighting;
-};
-void launchBow(hipStream_t, const VocabDevice&, const uint8_t*, const int*, int, int, uint32_t*, double*, uint32_t*, uint32_t*, double*, int*,
-               uint32_t*, uint32_t*, int*, int);
-struct RgbdParams { int capacity, rows, cols, isU16, scale; long long stride, frame; float factor, mbf; };
-void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const int*, const uint8_t*, const RgbdParams&, float*, float*, int);
-struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
-void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
-void launchClockProbe(hipStream_t, unsigned long long*, int, int, unsigned);
-size_t pipeLdsBytes(int M, int P, int R, int XT);
-bool pipeCanRun(int maxRoiW, int maxRoiH);
-void launchPipe(hipStream_t, const PipeArgs&, int itemsPerFrame, int frames, size_t ldsBytes);
-}  // namespace orbx
-
-using namespace orbx;
+#include "orbx_internal.hpp"
 
 static_assert(sizeof(orbx_keypoint) == sizeof(Keypoint), "orbx_keypoint layout");
 static_assert(sizeof(orbx_proj_query) == sizeof(ProjQuery), "orbx_proj_query layout");
 
-static double g_hostT[8];
-static long g_hostN;
-static const bool g_hostTiming = getenv("ORBX_HOST_TIMING") && atoi(getenv("ORBX_HOST_TIMING")) != 0;      // tools/host_call_anatomy.py
-static inline double nowSec() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-
-namespace {
-// Test aids (tests/ only).  They are NOT reachable from the environment: a test sets them through orbx_debug_set_option() before orbx_create,
-// so nothing in a deployed process's environment can poison an extractor's memory or make a call fail.
-struct TestAids {
-    int poison = -1;          // "poison": byte every device allocation of orbx_create is filled with (no kernel may depend on what hipMalloc returns)
-    int ldsPollute = -1;      // "lds_pollute": byte every CU's LDS is filled with in front of every kernel
-    int failAfterFast = 0;    // "fail_after_fast": the next handle's first call with leaf tables returns between k_fast and k_octree (one shot)
-};
+double g_hostT[8];
+long g_hostN;
+const bool g_hostTiming = getenv("ORBX_HOST_TIMING") && atoi(getenv("ORBX_HOST_TIMING")) != 0;      // tools/host_call_anatomy.py
 TestAids g_aids;
-enum Slot { S_LEVEL0 = 0, S_RESIZE, S_BLUR, S_FAST, S_OCTREE, S_DESCRIBE, S_MISC, S_TOTAL, S_STEREO, S_FRAME };
-const char* kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
+const char* const kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_blur", "k_fast",
                                             "k_octree", "k_describe", "memset+copies", "batch_total",
                                             "k_stereo_rows+match+filter", "k_frame_finish+k_search_init+k_search_proj"};
 thread_local std::string g_createError;
 
-struct EventPair { hipEvent_t a, b; int slot; };
-}  // namespace
-
-struct orbx_handle {
-    int device = 0;
-    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
-    float scaleFactor = 0;
-    int maxW = 0, maxH = 0, maxB = 0;
-    ScaleTables tabs;
-    FrameGeom geom;        // geometry of the image size of the last call
-    FrameGeom maxGeom;     // geometry of max_width x max_height (sizes the arenas)
-    hipStream_t stream = nullptr;
-    bool ownStream = false;
-    std::string err;
-
-    // arenas (sized once)
-    size_t pyrBytes = 0, blurBytes = 0, candEntries = 0, selEntries = 0, cellCap = 0, rxCap = 0, tileCap = 0;
-    uint8_t *d_input = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
-    unsigned *d_candPos = nullptr, *d_candSeg = nullptr;   // packed (x,y,response): compacted / per-cell segments
-    unsigned* d_cellCount = nullptr;                      // [frame][cell] candidates emitted by k_fast
-    int* d_cellOff = nullptr;                             // [frame][cell] offset of the cell in the compacted array
-    unsigned short* d_nodeOf = nullptr;
-    unsigned* d_candCount = nullptr;
-    unsigned* d_sink = nullptr;         // written by the LDS polluter (test aid)
-    uint2* d_sel = nullptr;
-    int *d_levelCount = nullptr, *d_levelLap = nullptr, *d_lap = nullptr;
-    LevelGeom* d_lv = nullptr;
-    CellDesc* d_cells = nullptr;
-    ResizeX *d_rx = nullptr, *d_ry = nullptr;
-    QuadRec* d_xq = nullptr;            // per level: the tile resize's dword-column records (FrameGeom::xq)
-    size_t xqCap = 0, xqOff[kMaxLevels] = {};
-    PyrColumn* d_cols = nullptr;        // regions of the region-major pyramid (k_pyr_cols)
-    size_t colsCap = 0, colsOff[8] = {};   // first column of each cut of the geometry in d_cols
-    ResizeX* d_colCoef = nullptr;       // the regions' coefficient lists, cut after cut
-    size_t colCoefCap = 0, colCoefOff[8] = {};
-    ColLevels* d_colLevels = nullptr;
-    int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
-    int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
-    int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
-    int patchBlur = -1;                 // ORBX_PATCH_BLUR: 1 = k_describe blurs each keypoint's patch itself (no blurred levels), 0 = never, default: by features per pixel (enqueueBatch)
-    int blurInCols = 0;                 // ORBX_BLUR_IN_COLS=1: the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken (opt-in: slower)
-    int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
-    TileFoot* d_foot = nullptr;
-    size_t footCap = 0, footOff[kMaxLevels] = {};
-    BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
-    unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
-    size_t laneCap = 0;
-    int nBlurLanes[3] = {0, 0, 0};     // [0]: 32-row blocks of every level, [1]: 8-row blocks (small batches), [2]: 32-row blocks of the levels k_pyr_cols<.., BLUR> leaves (>= blurInLevels)
-    size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
-    int blurInLevels = 5;              // ORBX_BLUR_IN_LEVELS: the finest levels the region-major pyramid blurs itself when it carries the blur (the halo compounds
-                                       // down the chain: 640x480, 112-px regions, derived pixels +3 % for 3 levels = 70 % of the blur's pixels, +9 % for 5 = 89 %, +30 % for all 8)
-    size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
-    size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
-    uint8_t* d_octArena = nullptr;
-    int octM = 0, octP = 0, octR = 0, octXT = 0;   // quad-tree LDS: max nodes, sort size, roots covered by the dense phase
-    // small batches: per-(frame, level, root) leaf counters / best keys filled by k_fast's emit, consumed and cleared by k_octree
-    // (orbx_device.hpp: LeafTables); d_leafCode = [2][nlevels][octXT] host-built x / y path codes of the current geometry
-    int leafFrames = 0;            // frames covered (ORBX_LEAF_FRAMES, default 128; 0 = off)
-    int* d_leafHist = nullptr;
-    unsigned* d_leafBest = nullptr;
-    uint8_t* d_leafCode = nullptr;
-    // outputs of the host path: ONE result slab [n | mono | level counts | keypoints | descriptors | per-level keypoints], section-major for the
-    // frames of the call (outLayout), on the device (d_out) and in pinned host memory (h_out).  A batch comes back with ONE D2H copy of the part the
-    // caller asked for; ONE frame per call (the reference's call shape, Frame.cc:419-427) has no copy at all: the kernels write the slab in
-    // pinned host memory themselves (tools/host_zero_copy.py: +3.8 us on the kernels against 4-6 copy commands of ~10 us each)
-    int outCap = 0;
-    uint8_t *d_out = nullptr, *h_out = nullptr;
-    size_t outBytes = 0;
-    bool zeroCopy = true;              // ORBX_ZERO_COPY=0: a single frame also goes through d_out and the D2H copy
-    // pinned staging
-    int* h_lap = nullptr;
-    std::vector<int> lapCached;
-    uint8_t* h_in = nullptr;           // pageable input of a few frames is gathered here (tight rows), then ONE asynchronous H2D copy
-    size_t hInBytes = 0;
-    uint8_t* h_pyr = nullptr;          // orbx_fetch_pyramid: one frame's bordered levels (allocated on first use)
-    size_t hPyrBytes = 0;
-    uint8_t* h_tab = nullptr;          // installGeometry: the geometry's tables, packed, copied to the device arenas on the handle's stream
-    size_t hTabBytes = 0;
-    // where the results of the last host-buffer batch are: as the kernels see them (dev: d_out, or h_out when written zero-copy) and on the host
-    struct OutView { Keypoint* k = nullptr; uint8_t* d = nullptr; int* n = nullptr; int* mono = nullptr; Keypoint* lk = nullptr; int* lc = nullptr; };
-    OutView dev, host;
-    bool pyramidOnly = false;          // the last call was orbx_compute_pyramid: the handle holds a pyramid (and blurred levels) but no results
-    bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
-    bool testFailAfterFast = false;    // test aid "fail_after_fast" (orbx_debug_set_option)
-    bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
-    int lastPyrForm = -1, lastPyrCut = 0, lastBlurForm = -1;      // orbx_debug_last_forms
-    std::string lastKernel[ORBX_NUM_KERNELS];                      // the kernel (rocprofv3's name, without template arguments) that last ran in each profile slot
-    int lastB = 0;
-    int lastHostB = 0;           // frames whose results the handle itself holds (the result slab: h->dev / h->host): set by the host-buffer path only
-    int pendingB = 0;            // frames of the batch begun with orbx_extract_batch_begin and not yet ended
-    bool pendingLevels = false;
-    int octThreads[kMaxLevels] = {};   // quad-tree workgroup size per level (installGeometry: one size for all levels,
-                                       // chosen by the image area — separate launches per size measured slower)
-    int octThreadsForced = 0;          // ORBX_OCT_THREADS
-    int ldsPollute = -1;               // test aid "lds_pollute" (orbx_debug_set_option): every CU's LDS is filled with the byte in front of every kernel
-    std::string policy;                // the launch-policy switches as read at orbx_create (orbx_debug_policy)
-    bool octRoomyForced = false;       // ORBX_OCT_ROOMY: the 128-VGPR variants whatever the batch (tests reach every variant with it)
-    int numCUs = 256;
-    bool resizeBytewise = false;    // ORBX_RESIZE_BYTEWISE: force the byte-gather resize (diagnostic)
-    // the internal stream and the events of the two-half overlap (enqueueBatch)
-    hipStream_t aux = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
-    hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
-    int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream (the largest also stagger
-                                       // their tails: enqueueBatch); 0 = no overlap of any kind; 3 = staggered tails for every large batch
-    bool fuseSmall = true;             // ORBX_FUSE_SMALL=0: small batches keep the blur as a launch of its own
-    long long splitMinPixels = 0;      // ORBX_SPLIT_MIN_MPX: smallest half (pyramid pixels) worth its own kernels
-    // ComputeBoW scratch (allocated on first use): per-feature word id / weight / node
-    size_t bowEntries = 0;
-    uint32_t *d_bowWord = nullptr, *d_bowNode = nullptr;
-    double* d_bowWeight = nullptr;
-    // stereo matching (allocated on first use)
-    int stereoPairs = 0, stereoCap = 0, stereoRows = 0;
-    int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
-    unsigned short* d_rowList = nullptr;
-    float *d_uRight = nullptr, *d_depth = nullptr;
-    // the pipelined launch (k_pipe.hip; enqueueBatch): role tables of the current geometry, one per set of roles a pipeline step can hold
-    PipeRole* d_roles = nullptr;
-    size_t rolesCap = 0, roleOff[16] = {};
-    int roleCount[16] = {};
-    int pipeMode = 0;                  // ORBX_PIPE=1: every full call of frames up to half a megapixel runs pipelined (opt-in: measured slower)
-    int pipeChunk = 128;               // ORBX_PIPE_CHUNK: frames per pipeline step
-    // clock probe (orbx_debug_clock_probe: bench.py's sustained-load figure), allocated on first use
-    hipStream_t probeStream = nullptr;
-    unsigned long long* d_clock = nullptr;
-    // profiling
-    bool profiling = false;
-    std::vector<EventPair> pending;
-    double profMs[ORBX_NUM_KERNELS] = {};
-    long profN[ORBX_NUM_KERNELS] = {};
-};
-
 namespace {
-
-#define HIP_TRY(h, expr)                                                                                 \
-    do {                                                                                                 \
-        hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess) {                                                                          \
-            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                \
-            return ORBX_ERR_HIP;                                                                         \
-        }                                                                                                \
-    } while (0)
-
-int fail(orbx_handle* h, int code, const std::string& msg) {
-    h->err = msg;
-    return code;
-}
-
-int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-
-// Byte offsets of the sections of the result slab for a call of B frames (capacity cap per frame).  What every caller wants comes first, so
-// that the D2H copy of a batch is one contiguous range: [0, noLevels) without the per-level arrays, [0, all) with them.
-struct OutLayout { size_t n, mono, counts, kps, desc, levelK, noLevels, all; };
-OutLayout outLayout(int B, int cap, int nlevels) {
-    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
-    OutLayout o;
-    o.n = 0;
-    o.mono = up(sizeof(int) * (size_t)B);
-    o.counts = o.mono + up(sizeof(int) * (size_t)B);
-    o.kps = o.counts + up(sizeof(int) * (size_t)B * nlevels);
-    o.desc = o.kps + up(sizeof(Keypoint) * (size_t)cap * B);
-    o.noLevels = o.desc + up((size_t)32 * cap * B);
-    o.levelK = o.noLevels;
-    o.all = o.levelK + up(sizeof(Keypoint) * (size_t)cap * B);
-    return o;
-}
-orbx_handle::OutView outView(uint8_t* base, const OutLayout& o) {
-    orbx_handle::OutView v;
-    v.n = (int*)(base + o.n); v.mono = (int*)(base + o.mono); v.lc = (int*)(base + o.counts);
-    v.k = (Keypoint*)(base + o.kps); v.d = base + o.desc; v.lk = (Keypoint*)(base + o.levelK);
-    return v;
-}
-
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_xq, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
@@ -489,22 +219,6 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     h->geom = g;
     return ORBX_OK;
 }
-
-struct Prof {
-    orbx_handle* h; int slot; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-    Prof(orbx_handle* h_, int s, hipStream_t st_ = nullptr) : h(h_), slot(s), st(st_ ? st_ : h_->stream) {
-        if (h->profiling) {
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, st);
-        }
-    }
-    ~Prof() {
-        if (h->profiling) {
-            (void)hipEventRecord(b, st);
-            h->pending.push_back(EventPair{a, b, slot});
-        }
-    }
-};
 
 int checkFrameArgs(orbx_handle* h, int n_frames, int rows, int cols) {
     if (n_frames < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "n_frames < 1");
@@ -719,8 +433,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
             int octT[kMaxLevels];
             // (the "resident" variants are compiled for 4 waves per SIMD = 128 VGPRs, no scratch: 1024 threads per CU-SIMD set)
-            const long long slots = 1024LL * h->numCUs, wgs = (long long)Bn * g.nlevels;   // threads resident at once at 4 waves per SIMD
-            int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots ? 512 : (wgs * 256 <= slots ? 256 : 0));
+            // (... the 1024-thread one; the 512- and 256-thread resident variants are compiled for 3 waves per SIMD - no scratch -: 768 threads per CU)
+            const long long slots = 1024LL * h->numCUs, slots3 = 768LL * h->numCUs, wgs = (long long)Bn * g.nlevels;   // threads resident at once at 4 / 3 waves per SIMD
+            int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots3 ? 512 : (wgs * 256 <= slots3 ? 256 : 0));
             if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
             // ... but with the first sweep done by k_fast (leaf tables) what is left of a level is a chain of barriers over a list of at most
             // quota + 3 nodes: when 256 threads still give every node of the list its own thread (the short pass forms) the small workgroup
@@ -1244,14 +959,6 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff
                               mono_out, level_kps, level_counts);
 }
 
-// ORBX_HOST_TIMING=1: where a one-frame host call spends its wall time (tools/host_call_anatomy.py): seconds accumulated per phase
-int orbx_debug_host_timing(double* out8, long* calls) {
-    if (!out8 || !calls) return ORBX_ERR_BAD_ARGUMENT;
-    for (int i = 0; i < 8; i++) { out8[i] = g_hostT[i]; g_hostT[i] = 0; }
-    *calls = g_hostN; g_hostN = 0;
-    return ORBX_OK;
-}
-
 int orbx_extract_view(orbx_handle* h, const uint8_t* img, int rows, int cols, ptrdiff_t stride, int lap0, int lap1, int want_levels,
                       const orbx_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_out, const orbx_keypoint** level_kps,
                       const int** level_counts) {
@@ -1353,55 +1060,6 @@ int orbx_fetch_pyramid(orbx_handle* h, int frame, const uint8_t** base, size_t* 
     return ORBX_OK;
 }
 
-int orbx_debug_set_option(const char* name, int value) {
-    if (!name) return ORBX_ERR_BAD_ARGUMENT;
-    const std::string n(name);
-    if (n == "poison") g_aids.poison = value;
-    else if (n == "lds_pollute") g_aids.ldsPollute = value;
-    else if (n == "fail_after_fast") g_aids.failAfterFast = value;
-    else return ORBX_ERR_BAD_ARGUMENT;
-    return ORBX_OK;
-}
-
-const char* orbx_debug_policy(const orbx_handle* h) { return h ? h->policy.c_str() : ""; }
-
-// The shader clock while the handle's work is running: one sleeping wave per CU on a stream of its own (k_clock.hip), asynchronous.
-enum { kClockSlots = 64, kClockTicks = 5000 };      // 5000 ticks of 100 MHz = 50 us per probe
-int orbx_debug_clock_probe(orbx_handle* h, int slot) {
-    if (!h || slot < 0 || slot >= kClockSlots) return ORBX_ERR_BAD_ARGUMENT;
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->probeStream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->probeStream, hipStreamNonBlocking));
-        HIP_TRY(h, hipMalloc(&h->d_clock, sizeof(unsigned long long) * 2 * kClockSlots * h->numCUs));
-        HIP_TRY(h, hipMemsetAsync(h->d_clock, 0, sizeof(unsigned long long) * 2 * kClockSlots * h->numCUs, h->probeStream));
-    }
-    launchClockProbe(h->probeStream, h->d_clock, slot, h->numCUs, kClockTicks);
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-int orbx_debug_clock_read(orbx_handle* h, int n_slots, double* ghz) {
-    if (!h || !ghz || n_slots < 1 || n_slots > kClockSlots) return ORBX_ERR_BAD_ARGUMENT;
-    if (!h->probeStream) return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_debug_clock_read: no probe was launched");
-    HIP_TRY(h, hipSetDevice(h->device));
-    std::vector<unsigned long long> v((size_t)2 * n_slots * h->numCUs);
-    HIP_TRY(h, hipMemcpyAsync(v.data(), h->d_clock, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->probeStream));
-    HIP_TRY(h, hipStreamSynchronize(h->probeStream));
-    for (int s = 0; s < n_slots; s++) {
-        double dt = 0, dr = 0;
-        for (int w = 0; w < h->numCUs; w++) { dt += (double)v[2 * ((size_t)s * h->numCUs + w)]; dr += (double)v[2 * ((size_t)s * h->numCUs + w) + 1]; }
-        ghz[s] = dr > 0 ? 0.1 * dt / dr : 0.0;      // cycles per 10-ns tick -> GHz
-    }
-    return ORBX_OK;
-}
-
-int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (pyramid_form) *pyramid_form = h->lastPyrForm;
-    if (pyramid_cut_px) *pyramid_cut_px = h->lastPyrCut;
-    if (blur_form) *blur_form = h->lastBlurForm;
-    return ORBX_OK;
-}
-
 int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* dst, ptrdiff_t dst_stride, int* width,
                    int* height) {
     if (!h || !dst) return ORBX_ERR_BAD_ARGUMENT;
@@ -1418,558 +1076,6 @@ int orbx_get_level(orbx_handle* h, int frame, int level, int bordered, uint8_t* 
     if (width) *width = L.w;
     if (height) *height = L.h;
     return ORBX_OK;
-}
-
-int orbx_debug_num_candidates(orbx_handle* h, int frame, int level, int* n) {
-    if (!h || !n) return ORBX_ERR_BAD_ARGUMENT;
-    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "no such frame/level in the last batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    unsigned v = 0;
-    HIP_TRY(h, hipMemcpyAsync(&v, h->d_candCount + frame * h->nlevels + level, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *n = (int)v;
-    return ORBX_OK;
-}
-
-int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoint* out, int capacity) {
-    int n = 0;
-    int rc = orbx_debug_num_candidates(h, frame, level, &n);
-    if (rc != ORBX_OK) return rc;
-    const LevelGeom& L = h->geom.lv[level];
-    if (n > L.candCap) return fail(h, ORBX_ERR_CAPACITY, "candidate arena overflow (internal bound violated)");
-    if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity too small");
-    if (n == 0) return ORBX_OK;
-    // The quad-tree compacts the keys into candPos only when it has to sweep them more than once; the per-cell segments
-    // k_fast wrote always hold them, in the reference's order (cell by cell, raster order inside a cell).
-    const FrameGeom& g = h->geom;
-    const int nCells = (int)g.cells.size();
-    std::vector<unsigned> counts(L.cellCount), seg(L.candCap);
-    HIP_TRY(h, hipMemcpyAsync(counts.data(), h->d_cellCount + (long long)frame * nCells + L.cellFirst, sizeof(unsigned) * L.cellCount,
-                              hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(seg.data(), h->d_candSeg + L.candOff + (long long)frame * L.candCap, sizeof(unsigned) * L.candCap,
-                              hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    int at = 0;
-    for (int c = 0; c < L.cellCount; c++) {
-        const int so = g.cells[L.cellFirst + c].segOff;
-        for (unsigned i = 0; i < counts[c] && at < n; i++) {
-            const unsigned w = seg[so + i];
-            orbx_keypoint& k = out[at++];
-            k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff); k.size = 7.f; k.angle = -1.f;
-            k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
-        }
-    }
-    if (at != n) return fail(h, ORBX_ERR_HIP, "candidate count and per-cell counts disagree (internal)");
-    return ORBX_OK;
-}
-
-int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, ptrdiff_t dst_stride) {
-    if (!h || !dst) return ORBX_ERR_BAD_ARGUMENT;
-    if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "no such frame/level in the last batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const LevelGeom& L = h->geom.lv[level];
-    if (dst_stride < L.w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "dst_stride too small");
-    if (h->lastBlurForm == 3) return fail(h, ORBX_ERR_UNSUPPORTED, "the last call blurred per keypoint inside k_describe: no blurred level exists (ORBX_PATCH_BLUR=0 keeps k_blur)");
-    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
-                                L.h, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return ORBX_OK;
-}
-
-namespace {
-// rows covered by one right keypoint's band [floor(y - 2s), ceil(y + 2s)], s = the coarsest level's scale
-int bandRows(const orbx_handle* h) { return 2 * (int)std::ceil(2.0 * h->tabs.scale[h->nlevels - 1]) + 2; }
-
-int stereoEnsure(orbx_handle* h, int nPairs, int capacity, int rows) {
-    if (nPairs <= h->stereoPairs && capacity <= h->stereoCap && rows <= h->stereoRows) return ORBX_OK;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    void* old[] = {h->d_rowOff, h->d_sadDist, h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth};
-    for (void* p : old) if (p) (void)hipFree(p);
-    h->d_rowOff = h->d_sadDist = h->d_nMatched = nullptr; h->d_rowList = nullptr; h->d_uRight = h->d_depth = nullptr;
-    h->stereoPairs = nPairs > h->stereoPairs ? nPairs : h->stereoPairs;
-    h->stereoCap = capacity > h->stereoCap ? capacity : h->stereoCap;
-    h->stereoRows = rows > h->stereoRows ? rows : h->stereoRows;
-    const size_t P = h->stereoPairs, C = h->stereoCap;
-    HIP_TRY(h, hipMalloc(&h->d_rowOff, P * (h->stereoRows + 1) * sizeof(int)));
-    HIP_TRY(h, hipMalloc(&h->d_rowList, P * C * bandRows(h) * sizeof(unsigned short)));
-    HIP_TRY(h, hipMalloc(&h->d_sadDist, P * C * sizeof(int)));
-    HIP_TRY(h, hipMalloc(&h->d_nMatched, P * sizeof(int)));
-    HIP_TRY(h, hipMalloc(&h->d_uRight, P * C * sizeof(float)));
-    HIP_TRY(h, hipMalloc(&h->d_depth, P * C * sizeof(float)));
-    return ORBX_OK;
-}
-
-int stereoEnqueue(orbx_handle* h, int n_pairs, const Keypoint* d_kps, const uint8_t* d_desc, const int* d_n, int capacity,
-                  float bf, float b, float* d_u, float* d_d, int* d_nm) {
-    if (h->geom.nlevels == 0 || 2 * n_pairs > h->lastB || n_pairs < 1)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "stereo matching needs the 2*n_pairs frames of the last extract batch on this handle");
-    if (!(b > 0.f) || !(bf > 0.f)) return fail(h, ORBX_ERR_BAD_ARGUMENT, "bf and b must be positive");
-    if (capacity > 65535) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 65535 keypoints per eye");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const int rows = h->geom.rows;
-    int rc = stereoEnsure(h, n_pairs, capacity, rows);
-    if (rc != ORBX_OK) return rc;
-    StereoParams sp;
-    for (int l = 0; l < kMaxLevels; l++) { sp.scale[l] = l < h->nlevels ? h->tabs.scale[l] : 1.f; sp.invScale[l] = l < h->nlevels ? h->tabs.invScale[l] : 1.f; }
-    sp.bf = bf; sp.b = b; sp.nlevels = h->nlevels; sp.capacity = capacity; sp.rowCap = h->stereoCap * bandRows(h);
-    {
-        Prof p(h, S_STEREO);
-        launchStereo(h->stream, h->d_lv, h->d_pyr, d_kps, d_desc, d_n, sp, rows, h->d_rowOff, h->d_rowList, d_u, d_d, h->d_sadDist,
-                     d_nm, n_pairs);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-}  // namespace
-
-int orbx_stereo_match_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out,
-                             int capacity, float bf, float b, float* d_u_right, float* d_depth, int* d_n_matched) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_kps || !d_desc || !d_n_out || !d_u_right || !d_depth || !d_n_matched || capacity < 1)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer or capacity < 1");
-    return stereoEnqueue(h, n_pairs, (const Keypoint*)d_kps, d_desc, d_n_out, capacity, bf, b, d_u_right, d_depth, d_n_matched);
-}
-
-int orbx_stereo_match_last(orbx_handle* h, int n_pairs, float bf, float b, float* u_right, float* depth, int capacity,
-                           int* n_matched) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!u_right || !depth || !n_matched || capacity < 1 || n_pairs < 1) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity < 1 or n_pairs < 1");
-    // the handle only holds results of the host-buffer path (orbx_extract / orbx_extract_batch / _begin + _end); after
-    // orbx_extract_batch_device the results live in the caller's buffers: use orbx_stereo_match_device there
-    if (h->pendingB) return fail(h, ORBX_ERR_BAD_ARGUMENT, "a batch is still in flight: call orbx_extract_batch_end first");
-    if (2 * n_pairs > h->lastHostB)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "orbx_stereo_match_last needs the 2*n_pairs frames of the last orbx_extract_batch call on this handle "
-                                              "(after orbx_extract_batch_device use orbx_stereo_match_device)");
-    const int cap = h->outCap;
-    for (int p = 0; p < n_pairs; p++) {     // counts of the left eyes, copied to the host by that call
-        const int n = h->host.n[2 * p];
-        if (n < 0 || n > cap) return fail(h, ORBX_ERR_HIP, "corrupt keypoint count in the handle's staging (internal)");
-        if (n > capacity) return fail(h, ORBX_ERR_CAPACITY, "capacity smaller than the left keypoint count");
-    }
-    int rc = stereoEnsure(h, n_pairs, cap, h->geom.rows > 0 ? h->geom.rows : 1);
-    if (rc != ORBX_OK) return rc;
-    rc = stereoEnqueue(h, n_pairs, h->dev.k, h->dev.d, h->dev.n, cap, bf, b, h->d_uRight, h->d_depth, h->d_nMatched);
-    if (rc != ORBX_OK) return rc;
-    std::vector<float> hu((size_t)n_pairs * cap), hd((size_t)n_pairs * cap);
-    HIP_TRY(h, hipMemcpyAsync(hu.data(), h->d_uRight, hu.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(hd.data(), h->d_depth, hd.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(n_matched, h->d_nMatched, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (int p = 0; p < n_pairs; p++) {
-        const int n = h->host.n[2 * p];
-        std::memcpy(u_right + (size_t)p * capacity, hu.data() + (size_t)p * cap, sizeof(float) * n);
-        std::memcpy(depth + (size_t)p * capacity, hd.data() + (size_t)p * cap, sizeof(float) * n);
-    }
-    return ORBX_OK;
-}
-
-namespace {
-// cv::undistortPoints for one point, host twin of the device routine in k_frame.hip (same operation order, doubles;
-// this file is compiled with -ffp-contract=off)
-void undistortHost(const orbx_camera& c, float xin, float yin, float* xo, float* yo) {
-    const double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy, ifx = 1. / fx, ify = 1. / fy;
-    const double k[12] = {c.k1, c.k2, c.p1, c.p2, c.k3, 0, 0, 0, 0, 0, 0, 0};
-    double x = xin, y = yin;
-    const double u = x, v = y;
-    x = (x - cx) * ifx; y = (y - cy) * ify;
-    const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; j++) {
-        const double r2 = x * x + y * y;
-        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
-        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
-        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
-        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
-    *xo = (float)(xx * ww); *yo = (float)(yy * ww);
-}
-}  // namespace
-
-int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float* b) {
-    if (!cam || !b || cols < 1 || rows < 1 || !(cam->fx > 0.f) || !(cam->fy > 0.f)) return ORBX_ERR_BAD_ARGUMENT;
-    if (cam->k1 != 0.0f) {
-        float m[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
-        for (int i = 0; i < 4; i++) undistortHost(*cam, m[i][0], m[i][1], &m[i][0], &m[i][1]);
-        b[0] = m[0][0] < m[2][0] ? m[0][0] : m[2][0]; b[1] = m[1][0] > m[3][0] ? m[1][0] : m[3][0];
-        b[2] = m[0][1] < m[1][1] ? m[0][1] : m[1][1]; b[3] = m[2][1] > m[3][1] ? m[2][1] : m[3][1];
-    } else {
-        b[0] = 0.0f; b[1] = (float)cols; b[2] = 0.0f; b[3] = (float)rows;
-    }
-    return ORBX_OK;
-}
-
-int orbx_stereo_from_rgbd_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un,
-                                 const int* d_n_out, int capacity, const void* d_depth, int depth_is_u16, int rows, int cols,
-                                 ptrdiff_t depth_stride_bytes, ptrdiff_t depth_frame_stride_bytes, float depth_map_factor, float mbf,
-                                 float* d_u_right, float* d_depth_out) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    const ptrdiff_t elem = depth_is_u16 ? 2 : 4;
-    if (!d_kps || !d_kps_un || !d_n_out || !d_depth || !d_u_right || !d_depth_out || capacity < 1 || n_frames < 1 || rows < 1 || cols < 1 ||
-        depth_stride_bytes < (ptrdiff_t)cols * elem || (depth_stride_bytes % elem) != 0 || (depth_frame_stride_bytes % elem) != 0 ||
-        ((uintptr_t)d_depth % elem) != 0 || n_frames > 65535)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames/rows/cols < 1, or a depth stride / pointer that is not a multiple of the element size");
-    HIP_TRY(h, hipSetDevice(h->device));
-    RgbdParams p;
-    p.capacity = capacity; p.rows = rows; p.cols = cols; p.isU16 = depth_is_u16 != 0;
-    p.scale = p.isU16 || std::fabs(depth_map_factor - 1.0f) > 1e-5f;      // Tracking.cc:1003
-    p.stride = depth_stride_bytes; p.frame = depth_frame_stride_bytes; p.factor = depth_map_factor; p.mbf = mbf;
-    launchStereoFromRgbd(h->stream, (const Keypoint*)d_kps, (const Keypoint*)d_kps_un, d_n_out, (const uint8_t*)d_depth, p, d_u_right,
-                         d_depth_out, n_frames);
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-int orbx_gray_from_color_device(orbx_handle* h, int n_frames, const uint8_t* d_src, int rows, int cols, int channels, int red_first,
-                                ptrdiff_t src_stride, ptrdiff_t src_frame_stride, uint8_t* d_gray, ptrdiff_t gray_stride,
-                                ptrdiff_t gray_frame_stride) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_src || !d_gray || n_frames < 1 || rows < 1 || cols < 1 || (channels != 3 && channels != 4) ||
-        src_stride < (ptrdiff_t)cols * channels || gray_stride < cols || rows > 65535 || n_frames > 65535)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, channels not 3 or 4, stride shorter than a row, or more than 65535 rows / frames");
-    HIP_TRY(h, hipSetDevice(h->device));
-    GrayParams p;
-    p.rows = rows; p.cols = cols; p.channels = channels; p.redFirst = red_first != 0;
-    p.srcStride = src_stride; p.srcFrame = src_frame_stride; p.dstStride = gray_stride; p.dstFrame = gray_frame_stride;
-    p.aligned = (((uintptr_t)d_src | (uintptr_t)src_stride | (uintptr_t)src_frame_stride) & 3) == 0;
-    launchGray(h->stream, d_src, d_gray, p, n_frames);
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
-                             const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
-                             int* d_grid_idx, int* d_n_inside) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_kps || !d_n_out || !cam || !bounds4 || !d_kps_un || !d_grid_off || !d_grid_idx || !d_n_inside || capacity < 1 ||
-        n_frames < 1 || !(cam->fx > 0.f) || !(cam->fy > 0.f) || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames < 1, non-positive focal length or empty bounds");
-    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
-    HIP_TRY(h, hipSetDevice(h->device));
-    FrameFinishParams p;
-    p.cam = CameraParams{cam->fx, cam->fy, cam->cx, cam->cy, cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
-    p.minX = bounds4[0]; p.minY = bounds4[2];
-    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
-    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
-    p.capacity = capacity;
-    {
-        Prof pr(h, S_FRAME);
-        launchFrameFinish(h->stream, (const Keypoint*)d_kps, d_n_out, p, (Keypoint*)d_kps_un, d_grid_off, d_grid_idx, d_n_inside, n_frames);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-int orbx_search_for_initialization_device(orbx_handle* h, int n_pairs, int frame1_first, int frame1_step, int frame2_first,
-                                          int frame2_step, const orbx_keypoint* d_kps_un, const uint8_t* d_desc,
-                                          const int* d_n_out, int capacity, const int* d_grid_off, const int* d_grid_idx,
-                                          const float* bounds4, float* d_prev_matched, int window_size, float nn_ratio,
-                                          int check_orientation, int* d_matches12, int* d_n_matches) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_kps_un || !d_desc || !d_n_out || !d_grid_off || !d_grid_idx || !bounds4 || !d_prev_matched || !d_matches12 ||
-        !d_n_matches || capacity < 1 || n_pairs < 1 || frame1_first < 0 || frame2_first < 0 || frame1_step < 0 || frame2_step < 0 ||
-        window_size < 0 || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1, negative frame index/step/window or empty bounds");
-    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
-    const int slotCap = initMatchSlotCapacity(capacity);
-    if (slotCap < 64)
-        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (4 bytes per keypoint + 52 per level-0 keypoint of frame 2, 160 KB per CU)");
-    HIP_TRY(h, hipSetDevice(h->device));
-    InitMatchParams p;
-    p.minX = bounds4[0]; p.minY = bounds4[2];
-    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
-    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
-    p.r = (float)window_size; p.nnRatio = nn_ratio; p.checkOrientation = check_orientation != 0; p.capacity = capacity; p.slotCapacity = slotCap;
-    p.f1First = frame1_first; p.f1Step = frame1_step; p.f2First = frame2_first; p.f2Step = frame2_step;
-    {
-        Prof pr(h, S_FRAME);
-        launchSearchInit(h->stream, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off, d_grid_idx, p, d_prev_matched, d_matches12,
-                         d_n_matches, n_pairs);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-int orbx_project_last_frame_device(orbx_handle* h, int n_pairs, int last_first, int last_step, int cur_first, int cur_step,
-                                   const orbx_keypoint* d_kps, const orbx_keypoint* d_kps_un, const int* d_n_out, int capacity,
-                                   const uint8_t* d_mp_flags, const float* d_world, const float* d_poses, const orbx_camera* cam,
-                                   const float* bounds4, float mbf, float mb, float th, int mono, orbx_proj_query* d_queries) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_kps || !d_kps_un || !d_n_out || !d_mp_flags || !d_world || !d_poses || !cam || !bounds4 || !d_queries || capacity < 1 || n_pairs < 1 ||
-        n_pairs > 65535 || last_first < 0 || cur_first < 0 || last_step < 0 || cur_step < 0 || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1, more than 65535 pairs, negative frame index/step or empty bounds");
-    HIP_TRY(h, hipSetDevice(h->device));
-    ProjectParams p;
-    p.fx = cam->fx; p.fy = cam->fy; p.cx = cam->cx; p.cy = cam->cy;
-    p.minX = bounds4[0]; p.maxX = bounds4[1]; p.minY = bounds4[2]; p.maxY = bounds4[3];
-    for (int l = 0; l < kMaxLevels; l++) p.scale[l] = l < h->nlevels ? h->tabs.scale[l] : h->tabs.scale[h->nlevels - 1];   // CurrentFrame.mvScaleFactors
-    p.mbf = mbf; p.mb = mb; p.th = th; p.mono = mono != 0; p.capacity = capacity;
-    p.lastFirst = last_first; p.lastStep = last_step; p.curFirst = cur_first; p.curStep = cur_step;
-    {
-        Prof pr(h, S_FRAME);
-        launchProjectLast(h->stream, (const Keypoint*)d_kps, (const Keypoint*)d_kps_un, d_n_out, d_mp_flags, d_world, d_poses, p, (ProjQuery*)d_queries, n_pairs);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-int orbx_search_by_projection_device(orbx_handle* h, int n_pairs, int cur_first, int cur_step, const orbx_proj_query* d_queries,
-                                     const uint8_t* d_query_desc, int desc_first, int desc_step, const int* d_n_queries, int query_capacity,
-                                     const orbx_keypoint* d_kps_un, const uint8_t* d_desc, const int* d_n_out, int capacity,
-                                     const int* d_grid_off, const int* d_grid_idx, const float* bounds4, const float* d_u_right,
-                                     uint8_t* d_occupied, int ratio_mode, float nn_ratio, int max_distance, int check_orientation,
-                                     int* d_matches, int* d_n_matches) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_queries || !d_query_desc || !d_kps_un || !d_desc || !d_n_out || !d_grid_off || !d_grid_idx || !bounds4 || !d_matches || !d_n_matches ||
-        capacity < 1 || query_capacity < 1 || n_pairs < 1 || cur_first < 0 || cur_step < 0 || desc_first < 0 || desc_step < 0 || max_distance < 0 ||
-        !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/query_capacity/n_pairs < 1, negative frame index/step or empty bounds");
-    if (capacity > 32767) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 32767 keypoints per frame");
-    if (projSearchLdsBytes(capacity, query_capacity, false) > 160 * 1024 - 512)
-        return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large for the LDS-resident search (64 bytes per keypoint, 160 KB per CU)");
-    HIP_TRY(h, hipSetDevice(h->device));
-    ProjSearchParams p;
-    p.minX = bounds4[0]; p.minY = bounds4[2];
-    p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
-    p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
-    p.nnRatio = nn_ratio; p.ratioMode = ratio_mode != 0; p.checkOrientation = check_orientation != 0;
-    p.capacity = capacity; p.queryCapacity = query_capacity; p.curFirst = cur_first; p.curStep = cur_step;
-    p.descFirst = desc_first; p.descStep = desc_step; p.maxDist = max_distance < 255 ? max_distance : 255;
-    {
-        Prof pr(h, S_FRAME);
-        launchSearchProj(h->stream, (const ProjQuery*)d_queries, d_query_desc, d_n_queries, (const Keypoint*)d_kps_un, d_desc, d_n_out, d_grid_off,
-                         d_grid_idx, d_u_right, d_occupied, p, d_matches, d_n_matches, n_pairs);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-}  // extern "C"
-
-struct orbx_vocabulary {
-    int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, nNodes = 0, nWords = 0;
-    int *d_childOff = nullptr, *d_childList = nullptr;
-    uint32_t *d_desc = nullptr, *d_wordId = nullptr;
-    double* d_weight = nullptr;
-};
-
-extern "C" {
-
-void orbx_vocabulary_destroy(orbx_vocabulary* v) {
-    if (!v) return;
-    (void)hipSetDevice(v->device);
-    void* dev[] = {v->d_childOff, v->d_childList, v->d_desc, v->d_wordId, v->d_weight};
-    for (void* p : dev) if (p) (void)hipFree(p);
-    delete v;
-}
-
-int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int weighting, int n_nodes, const int* parent,
-                           const uint8_t* is_leaf, const uint8_t* desc, const double* weight, int device) {
-    if (!out) return ORBX_ERR_BAD_ARGUMENT;
-    *out = nullptr;
-    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3 ||      // TemplatedVocabulary.h:1359
-        n_nodes < 2 || !parent || !is_leaf || !desc || !weight) {
-        g_createError = "orbx_vocabulary_create: bad argument (0<=k<=20, 1<=L<=10, scoring 0..5, weighting 0..3, at least a root and one node)";
-        return ORBX_ERR_BAD_ARGUMENT;
-    }
-    // children in node order (m_nodes[pid].children.push_back(nid), :1392), word ids to the leaves in node order (:1409-1415)
-    std::vector<int> cnt(n_nodes + 1, 0), off(n_nodes + 1, 0), list(n_nodes - 1);
-    for (int n = 1; n < n_nodes; n++) {
-        if (parent[n] < 0 || parent[n] >= n) { g_createError = "orbx_vocabulary_create: parent[n] must name an earlier node"; return ORBX_ERR_BAD_ARGUMENT; }
-        cnt[parent[n]]++;
-    }
-    for (int n = 0; n < n_nodes; n++) off[n + 1] = off[n] + cnt[n];
-    std::vector<int> fill(off.begin(), off.end() - 1);
-    for (int n = 1; n < n_nodes; n++) list[fill[parent[n]]++] = n;
-    std::vector<uint32_t> wid(n_nodes, 0);
-    int words = 0;
-    for (int n = 1; n < n_nodes; n++) {
-        if (is_leaf[n]) { if (cnt[n]) { g_createError = "orbx_vocabulary_create: a leaf with children"; return ORBX_ERR_BAD_ARGUMENT; } wid[n] = (uint32_t)words++; }
-        else if (!cnt[n]) { g_createError = "orbx_vocabulary_create: an inner node without children (the reference would treat it as a word without an id)"; return ORBX_ERR_BAD_ARGUMENT; }
-    }
-    if (!cnt[0]) { g_createError = "orbx_vocabulary_create: the root has no children"; return ORBX_ERR_BAD_ARGUMENT; }
-    for (int n = 0; n < n_nodes; n++)      // k_bow_words packs (distance << 8 | child rank): a node's fan-out must fit the rank byte
-        if (cnt[n] > 256) { g_createError = "orbx_vocabulary_create: a node with more than 256 children (the header's k allows at most 20)"; return ORBX_ERR_BAD_ARGUMENT; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_createError = "orbx_vocabulary_create: no HIP device (this library has no CPU path)"; return ORBX_ERR_NO_DEVICE; }
-    if (device < 0 && hipGetDevice(&device) != hipSuccess) return ORBX_ERR_HIP;
-    if (device >= ndev) { g_createError = "orbx_vocabulary_create: device index out of range"; return ORBX_ERR_BAD_ARGUMENT; }
-    orbx_vocabulary* v = new orbx_vocabulary();
-    v->device = device; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->nNodes = n_nodes; v->nWords = words;
-    // the uploads go through a stream of their own and the function returns when THAT stream has drained: the tables have landed before any
-    // handle's stream can be given the vocabulary, and no other work on the device is waited for
-    hipStream_t us = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) {
-        g_createError = "orbx_vocabulary_create: cannot create the upload stream";
-        delete v;
-        return ORBX_ERR_HIP;
-    }
-    auto up = [&](void** d, const void* src, size_t bytes) {
-        return hipMalloc(d, bytes ? bytes : 4) == hipSuccess && (bytes == 0 || hipMemcpyAsync(*d, src, bytes, hipMemcpyHostToDevice, us) == hipSuccess);
-    };
-    std::vector<double> w0(weight, weight + n_nodes);
-    if (!up((void**)&v->d_childOff, off.data(), sizeof(int) * (n_nodes + 1)) ||
-        !up((void**)&v->d_childList, list.data(), sizeof(int) * list.size()) || !up((void**)&v->d_desc, desc, (size_t)n_nodes * 32) ||
-        !up((void**)&v->d_wordId, wid.data(), sizeof(uint32_t) * n_nodes) || !up((void**)&v->d_weight, w0.data(), sizeof(double) * n_nodes)) {
-        g_createError = "orbx_vocabulary_create: device allocation or copy failed";
-        (void)hipStreamSynchronize(us);
-        (void)hipStreamDestroy(us);
-        orbx_vocabulary_destroy(v);
-        return ORBX_ERR_HIP;
-    }
-    const hipError_t landed = hipStreamSynchronize(us);
-    (void)hipStreamDestroy(us);
-    if (landed != hipSuccess) { g_createError = "orbx_vocabulary_create: upload failed"; orbx_vocabulary_destroy(v); return ORBX_ERR_HIP; }
-    *out = v;
-    return ORBX_OK;
-}
-
-int orbx_vocabulary_load_text(orbx_vocabulary** out, const char* path, int device) {
-    if (!out) return ORBX_ERR_BAD_ARGUMENT;
-    *out = nullptr;
-    FILE* f = path ? std::fopen(path, "r") : nullptr;
-    if (!f) { g_createError = "orbx_vocabulary_load_text: cannot open the file"; return ORBX_ERR_BAD_ARGUMENT; }
-    int k = 0, L = 0, n1 = 0, n2 = 0;
-    if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4) { std::fclose(f); g_createError = "orbx_vocabulary_load_text: bad header"; return ORBX_ERR_BAD_ARGUMENT; }
-    std::vector<int> parent(1, 0);
-    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
-    std::vector<double> weight(1, 0.0);
-    for (;;) {      // one node per line: parent, is-leaf, FORB::L = 32 descriptor bytes, weight (TemplatedVocabulary.h:1378-1419)
-        int pid = 0, isLeaf = 0;
-        if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
-        uint8_t d[32];
-        bool ok = true;
-        for (int i = 0; i < 32 && ok; i++) { int b = 0; ok = std::fscanf(f, "%d", &b) == 1; d[i] = (uint8_t)b; }
-        double w = 0;
-        if (!ok || std::fscanf(f, "%lf", &w) != 1) { std::fclose(f); g_createError = "orbx_vocabulary_load_text: truncated node line"; return ORBX_ERR_BAD_ARGUMENT; }
-        parent.push_back(pid); leaf.push_back(isLeaf > 0); weight.push_back(w);
-        desc.insert(desc.end(), d, d + 32);
-    }
-    std::fclose(f);
-    return orbx_vocabulary_create(out, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), device);
-}
-
-int orbx_vocabulary_info(const orbx_vocabulary* v, int* k, int* L, int* n_nodes, int* n_words) {
-    if (!v) return ORBX_ERR_BAD_ARGUMENT;
-    if (k) *k = v->k;
-    if (L) *L = v->L;
-    if (n_nodes) *n_nodes = v->nNodes;
-    if (n_words) *n_words = v->nWords;
-    return ORBX_OK;
-}
-
-int orbx_compute_bow_device(orbx_handle* h, const orbx_vocabulary* v, int n_frames, const uint8_t* d_desc, const int* d_n_out, int capacity,
-                            int levels_up, uint32_t* d_word_ids, double* d_word_weights, int* d_n_words, uint32_t* d_feat_nodes,
-                            uint32_t* d_feat_idx, int* d_n_feat) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!v || !d_desc || !d_n_out || !d_word_ids || !d_word_weights || !d_n_words || !d_feat_nodes || !d_feat_idx || !d_n_feat || capacity < 1 ||
-        n_frames < 1 || n_frames > 65535)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_frames < 1 or more than 65535 frames");
-    if (v->device != h->device) return fail(h, ORBX_ERR_BAD_ARGUMENT, "the vocabulary lives on another device than the handle");
-    if (capacity > 16384) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity above 16384 keypoints per frame (the per-frame sort runs in LDS)");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const size_t need = (size_t)n_frames * capacity;
-    if (need > h->bowEntries) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        void* old[] = {h->d_bowWord, h->d_bowNode, h->d_bowWeight};
-        for (void* p : old) if (p) (void)hipFree(p);
-        h->d_bowWord = h->d_bowNode = nullptr; h->d_bowWeight = nullptr; h->bowEntries = 0;
-        HIP_TRY(h, hipMalloc(&h->d_bowWord, need * sizeof(uint32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_bowNode, need * sizeof(uint32_t)));
-        HIP_TRY(h, hipMalloc(&h->d_bowWeight, need * sizeof(double)));
-        h->bowEntries = need;
-    }
-    VocabDevice V{v->d_childOff, v->d_childList, v->d_desc, v->d_weight, v->d_wordId, v->nNodes, v->k, v->L, v->scoring, v->weighting};
-    {
-        Prof pr(h, S_FRAME);
-        launchBow(h->stream, V, d_desc, d_n_out, capacity, levels_up, h->d_bowWord, h->d_bowWeight, h->d_bowNode, d_word_ids, d_word_weights, d_n_words,
-                  d_feat_nodes, d_feat_idx, d_n_feat, n_frames);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-
-static int searchByBow(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step, const uint32_t* d_feat_nodes,
-                       const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags, const uint8_t* d_cur_mp_flags,
-                       const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio, int th_low,
-                       int check_orientation, int* d_matches, int* d_n_matches) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    if (!d_feat_nodes || !d_feat_idx || !d_n_feat || !d_kf_mp_flags || !d_kps || !d_desc || !d_n_out || !d_matches || !d_n_matches ||
-        capacity < 1 || n_pairs < 1 || kf_first < 0 || cur_first < 0 || kf_first + (long long)(n_pairs - 1) * kf_step < 0 ||
-        cur_first + (long long)(n_pairs - 1) * cur_step < 0)
-        return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer, capacity/n_pairs < 1 or a negative frame index");
-    if (capacity > 65535 || bowMatchLdsBytes(capacity, false) > 150 * 1024) return fail(h, ORBX_ERR_UNSUPPORTED, "capacity too large: the node columns and the match table of a pair live in LDS");
-    HIP_TRY(h, hipSetDevice(h->device));
-    BowMatchParams p{nn_ratio, th_low, check_orientation ? 1 : 0, capacity, kf_first, kf_step, cur_first, cur_step, d_cur_mp_flags ? 1 : 0};
-    {
-        Prof pr(h, S_FRAME);
-        launchSearchBow(h->stream, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, d_cur_mp_flags, (const Keypoint*)d_kps, d_desc, d_n_out, p, d_matches,
-                        d_n_matches, n_pairs);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return ORBX_OK;
-}
-int orbx_search_by_bow_device(orbx_handle* h, int n_pairs, int kf_first, int kf_step, int cur_first, int cur_step,
-                              const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat, const uint8_t* d_kf_mp_flags,
-                              const orbx_keypoint* d_kps, const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio,
-                              int th_low, int check_orientation, int* d_matches, int* d_n_matches) {
-    return searchByBow(h, n_pairs, kf_first, kf_step, cur_first, cur_step, d_feat_nodes, d_feat_idx, d_n_feat, d_kf_mp_flags, nullptr, d_kps, d_desc,
-                       d_n_out, capacity, nn_ratio, th_low, check_orientation, d_matches, d_n_matches);
-}
-int orbx_search_by_bow_keyframes_device(orbx_handle* h, int n_pairs, int kf1_first, int kf1_step, int kf2_first, int kf2_step,
-                                        const uint32_t* d_feat_nodes, const uint32_t* d_feat_idx, const int* d_n_feat,
-                                        const uint8_t* d_kf1_mp_flags, const uint8_t* d_kf2_mp_flags, const orbx_keypoint* d_kps,
-                                        const uint8_t* d_desc, const int* d_n_out, int capacity, float nn_ratio, int th_low,
-                                        int check_orientation, int* d_matches12, int* d_n_matches) {
-    if (h && !d_kf2_mp_flags) return fail(h, ORBX_ERR_BAD_ARGUMENT, "null pointer (the second keyframe's MapPoint flags)");
-    return searchByBow(h, n_pairs, kf1_first, kf1_step, kf2_first, kf2_step, d_feat_nodes, d_feat_idx, d_n_feat, d_kf1_mp_flags, d_kf2_mp_flags, d_kps,
-                       d_desc, d_n_out, capacity, nn_ratio, th_low, check_orientation, d_matches12, d_n_matches);
-}
-
-int orbx_profile_enable(orbx_handle* h, int enable) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    h->profiling = enable != 0;
-    return ORBX_OK;
-}
-int orbx_profile_reset(orbx_handle* h) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    h->pending.clear();
-    for (int i = 0; i < ORBX_NUM_KERNELS; i++) { h->profMs[i] = 0; h->profN[i] = 0; }
-    return ORBX_OK;
-}
-int orbx_profile_read(orbx_handle* h, double* total_ms, long* launches) {
-    if (!h) return ORBX_ERR_BAD_ARGUMENT;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (auto& ev : h->pending) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { h->profMs[ev.slot] += ms; h->profN[ev.slot]++; }
-        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
-    }
-    h->pending.clear();
-    for (int i = 0; i < ORBX_NUM_KERNELS; i++) {
-        if (total_ms) total_ms[i] = h->profMs[i];
-        if (launches) launches[i] = h->profN[i];
-    }
-    return ORBX_OK;
-}
-const char* orbx_profile_kernel_name(int slot) { return slot >= 0 && slot < ORBX_NUM_KERNELS ? kSlotNames[slot] : ""; }
-const char* orbx_profile_kernel_name_of(const orbx_handle* h, int slot) {
-    if (!h || slot < 0 || slot >= ORBX_NUM_KERNELS) return "";
-    return h->lastKernel[slot].empty() ? kSlotNames[slot] : h->lastKernel[slot].c_str();
-}
-
-long orbx_algorithmic_bytes(const orbx_handle* h, int rows, int cols, int n_out) {
-    if (!h) return 0;
-    FrameGeom g;
-    if (!makeFrameGeom(h->tabs, rows, cols, g).empty()) return 0;
-    return (long)rows * cols + 2 * (long)g.sumPixels + 60L * n_out;
 }
 
 }  // extern "C"

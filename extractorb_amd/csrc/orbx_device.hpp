@@ -109,6 +109,7 @@ struct LeafTables { int* hist; unsigned* best; const uint8_t* xcode; const uint8
 // ---- the pipelined launch (k_pipe.hip): one launch per pipeline step, its workgroups dealt four roles by a host-made table ----
 enum { kPipeF = 0, kPipeB = 1, kPipeO = 2, kPipeD = 3 };      // FAST cells / blur rows of chunk t, quad-tree levels of chunk t - 1, keypoints of chunk t - 2
 struct PipeRole { unsigned short role, index; };               // one workgroup of a frame's share of the launch: which body, which of its items
+#ifdef __HIPCC__      // (the argument block names HIP vector types: the host-only checkers under tests/cpp include this header with g++)
 struct PipeArgs {
     const PipeRole* roles;               // [gridDim.y]: the interleaved deal (orbx_api.cpp: pipeRoleTable)
     const LevelGeom* lv; int nlevels;
@@ -123,6 +124,7 @@ struct PipeArgs {
     // D: frames [dF0, dF0 + dFn)
     Keypoint* outK; uint8_t* outD; int capacity; int* nOut; int* monoOut; Keypoint* outLevelK; int* outLevelCounts; int dF0, dFn;
 };
+#endif
 
 constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (plus a 6-row halo)
 #ifndef ORBX_BLUR_SMALL_ROWS

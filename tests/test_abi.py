@@ -50,7 +50,7 @@ def test_no_test_hook_is_reachable_from_the_environment():
     for name in X.orbextractor.TEST_AIDS:
         assert L.orbx_debug_set_option(name.encode(), 1) == 0
     X.debug_reset_options()
-    api = open(os.path.join(ROOT, "extractorb_amd", "csrc", "orbx_api.cpp")).read()
+    api = "".join(open(os.path.join(ROOT, "extractorb_amd", "csrc", f)).read() for f in ("orbx_api.cpp", "orbx_rows.cpp", "orbx_debug.cpp", "orbx_internal.hpp"))
     import re
     read = set(re.findall(r'getenv\("(ORBX_[A-Z0-9_]+)"\)', api)) | set(re.findall(r'envInt\("(ORBX_[A-Z0-9_]+)"', api))
     assert read and not [n for n in read if "TEST" in n or "POISON" in n or "POLLUTE" in n], read
@@ -61,7 +61,7 @@ def test_handle_owned_memory_is_only_touched_in_stream_order():
     hipMemcpy2DAsync on the handle's stream, or the vocabulary's own upload stream) - no null-stream hipMemcpy / hipMemset whose order against
     the handle's non-blocking stream would be an assumption, and no device-wide barrier that stalls other handles."""
     import re
-    api = open(os.path.join(ROOT, "extractorb_amd", "csrc", "orbx_api.cpp")).read()
+    api = "".join(open(os.path.join(ROOT, "extractorb_amd", "csrc", f)).read() for f in ("orbx_api.cpp", "orbx_rows.cpp", "orbx_debug.cpp", "orbx_internal.hpp"))
     code = re.sub(r"//[^\n]*", "", api)
     assert not re.findall(r"\bhipMem(?:cpy|set|cpy2D|setD8|setD32)\s*\(", code)
     assert "hipDeviceSynchronize" not in code

@@ -120,3 +120,42 @@ def test_unsupported_geometries_are_rejected():
         X.compute_cell_grid(120, 160, 7)          # coarsest level narrower than one cell
     with pytest.raises(X.OrbxError):
         X.compute_cell_grid(2000, 400, 0)         # nIni == 0 in the reference (undefined behaviour there)
+
+
+def test_patch_blur_runs_cover_every_pixel_the_rotated_pattern_can_read():
+    """k_describe<PB> (round 5) blurs only the part of a keypoint's 37 x 37 patch the rotated pattern can reach: the run table c_pbRun of
+    k_describe_body.hpp - (column group, first row, rows) per lane - must hold, per group, exactly the rows |r| <= rmax(group) of the bound
+    derived from the pattern's largest radius, and no sample of any rotation may fall outside it (swept every 0.0005 degrees with the kernel's
+    float arithmetic: products and sums rounded separately, half-even rounding)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "extractorb_amd", "csrc", "k_describe_body.hpp")).read()
+    body = text[text.index("c_pbRun[32] = {"):]
+    entries = [int(t, 16) for t in re.findall(r"0x[0-9a-fA-F]{6}", body[:body.index("};")])]
+    assert len(entries) == 32
+    pat = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "orbx_brief_pattern.inc")).read(), flags=re.S)
+    pts = np.array([int(t) for t in re.findall(r"-?\d+", pat)]).reshape(-1, 2)
+    r2 = int((pts ** 2).sum(1).max())
+    assert r2 == 338
+    covered = {g: set() for g in range(10)}
+    for e in entries:
+        g, o0, n = e & 0xff, (e >> 8) & 0xff, e >> 16
+        assert 0 <= g < 10 and 1 <= n <= 12 and 0 <= o0 and o0 + n <= 37          # at most six trips of the two-row loop; inside the 37-row tile
+        rows = set(range(o0, o0 + n))
+        assert not rows & covered[g]
+        covered[g] |= rows
+    for g in range(10):
+        qmin = min(abs(4 * g - 18 + k) for k in range(4) if 4 * g - 18 + k <= 18)
+        rmax = min(18, int(np.floor(0.5 + np.sqrt(r2 + 0.5 - max(qmin - 0.5, 0) ** 2))))
+        assert covered[g] == set(range(18 - rmax, 18 + rmax + 1)), g
+    ang = np.arange(0, 360, 0.0005, dtype=np.float32)
+    rad = (ang * np.float32(np.pi / 180.0)).astype(np.float32)
+    a, b = np.cos(rad).astype(np.float32), np.sin(rad).astype(np.float32)
+    need = np.zeros((37, 37), bool)
+    for x, y in pts.astype(np.float32):
+        r = np.rint((x * b).astype(np.float32) + (y * a).astype(np.float32)).astype(int)
+        q = np.rint((x * a).astype(np.float32) - (y * b).astype(np.float32)).astype(int)
+        assert np.abs(r).max() <= 18 and np.abs(q).max() <= 18
+        need[r + 18, q + 18] = True
+    for row, col in zip(*np.nonzero(need)):
+        assert int(row) in covered[int(col) // 4], (row - 18, col - 18)
