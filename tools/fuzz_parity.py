@@ -56,6 +56,11 @@ def run(n_cases, seed, progress=False):
 
 
 if __name__ == "__main__":
+    # test aids of the soak scripts: FUZZ_AIDS="poison=165,lds_pollute=77" (they cannot come from ORBX_* variables: include/orbx.h, orbx_debug_set_option)
+    if os.environ.get("FUZZ_AIDS"):
+        import extractorb_amd as _X
+        for kv in os.environ["FUZZ_AIDS"].split(","):
+            _X.debug_set_option(kv.split("=")[0], int(kv.split("=")[1]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
