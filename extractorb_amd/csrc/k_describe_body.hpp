@@ -101,10 +101,14 @@ constexpr int kPbLds = kPbRawBytes + kBlurRows * kBlurStride;               // 3
 // group g (columns q = 4 g - 18 .. 4 g - 15) is read at |r| <= rmax(g) = floor(1/2 + sqrt(338.5 - max(min|q| - 1/2, 0)^2)) only: 11, 15, 17, 18,
 // 18, 18, 18, 16, 13, 6 -> 310 of the box's 370 (group, row) items; tests/test_tables.py derives the bounds from the pattern and sweeps every
 // 0.0005 degrees for samples outside them.  The 32 lanes of a keypoint take (group, first row, rows) runs of at most 12 rows (six trips of the
-// two-row blur loop; the box dealt as 10 groups x 3 runs of 13 was seven): entry = group | first row << 8 | rows << 16.
+// two-row blur loop; the box dealt as 10 groups x 3 runs of 13 was seven): entry = group | first row << 8 | rows << 16.  WHERE the runs of a group are cut
+// matters: the 32 lanes read tile rows (first row + i) x 11 dwords + group, and a first cut (runs of 10 / 12 rows from the top) had them collide in the LDS
+// banks 4.4-fold on average (SQ_LDS_BANK_CONFLICT: 514 cycles per wave, the old 10 x 3 layout: 2-fold) - which ate the instructions the disc saves.  The cuts
+// below come from a search (simulated annealing over the partitions; cost = sum over the loop's LDS instructions of the largest number of lanes on one
+// bank, loads of the raw tile and stores of the blurred one): 143 against 259 for the first cut and 66 for a conflict-free walk.
 static __constant__ unsigned c_pbRun[32] = {
-    0x0c0700, 0x0b1300, 0x0c0301, 0x0a0f01, 0x091901, 0x0c0102, 0x0c0d02, 0x0b1902, 0x0a0003, 0x0a0a03, 0x0a1403, 0x071e03, 0x0a0004, 0x0a0a04, 0x0a1404, 0x071e04,
-    0x0a0005, 0x0a0a05, 0x0a1405, 0x071e05, 0x0a0006, 0x0a0a06, 0x0a1406, 0x071e06, 0x0c0207, 0x0c0e07, 0x091a07, 0x0a0508, 0x0a0f08, 0x071908, 0x080c09, 0x051409};
+    0x0b0700, 0x0c1200, 0x080301, 0x0b0b01, 0x0c1601, 0x0c0102, 0x0c0d02, 0x0b1902, 0x050003, 0x0c0503, 0x091103, 0x0b1a03, 0x050004, 0x0c0504, 0x081104,
+    0x0c1904, 0x060005, 0x0c0605, 0x091205, 0x0a1b05, 0x050006, 0x0c0506, 0x0c1106, 0x081d06, 0x0b0207, 0x0b0d07, 0x0b1807, 0x0c0508, 0x0c1108, 0x031d08, 0x010c09, 0x0c0d09};
 
 // One half-wave (32 lanes) per kept keypoint; the two keypoints of a wave share a level (selOff is even):
 //   * both patches are staged in LDS with aligned dword loads that are all in flight at once: a half-wave covers
