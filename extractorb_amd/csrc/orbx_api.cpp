@@ -475,13 +475,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         ~BlurJoin() { for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0); }
     } blurGuard{h, st, blurJoin};
     const bool doFront = (stages & kStageFront) != 0, doBack = (stages & kStageBack) != 0;
-    // Staggered tails (the largest batches: twice the pixels of `bigBatch`; ORBX_SPLIT=3: every big batch): FAST in two halves back to back on the
+    // Staggered tails (the largest batches: 1.5 x the pixels of `bigBatch` - round 5: 384 x 640x480 1315-1324 -> 1301-1308 us, 256 frames no difference;
+    // rounds 3-4: twice; ORBX_SPLIT=3: every big batch): FAST in two halves back to back on the
     // caller's stream; the first half's quad-tree and description (barrier- and latency-bound: 0.4-0.6 of the issue rate) run on the internal
     // stream under the second half's FAST.  512 x 640x480: 1913-1914 -> 1888-1894 us; 256 frames and 128 x 1080p: no difference (k_fast fills the chip;
     // what runs beside it mostly adds its own issue time)
     // (never with the blur riding in the FAST launch, the form of SMALL batches, which an ORBX_SPLIT_MIN_MPX=0 test run also counts as big: the
     // whole-batch pyramid would leave the blur to the FIRST half's FAST launch only — found by the batch-shape fuzz)
-    const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 4 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
+    const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 3 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
                          !h->profiling && B >= 2 && bigBatch && doFront && doBack && !blurRidesWithFast(B);
     if (pipe) {
         front(st, 0, B);      // the pyramid of the whole batch (k_pyr_cols; the blur is a role of the steps)
