@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
                             atomicAdd(&tHist[li], 1u);
                             atomicMax(&tBest[li], val);
                         } else {
-                            const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
+                            const unsigned cellOfRoot = leafTableEntry(lt, f, c.level, xc, yc);
                             atomicAdd(lt.hist + cellOfRoot, 1);
                             atomicMax(lt.best + cellOfRoot, val);
                         }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
             if (n) {
                 const int er = (int)(((float)e + 0.5f) * __frcp_rn((float)nxl));      // e / nxl (exact: e < 1024, the quotient is >= 0.5 / nxl away from an integer)
                 const int xc = xc0 + (e - er * nxl), yc = yc0 + er;
-                const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
+                const unsigned cellOfRoot = leafTableEntry(lt, f, c.level, xc, yc);
                 atomicAdd(lt.hist + cellOfRoot, (int)n);
                 atomicMax(lt.best + cellOfRoot, tBest[e]);
             }
@@ -296,7 +296,9 @@ void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGe
     BlurTail tail{blurItems, blurLaneItem, blurLanes, blur, fastChunks};
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
     if (wide && maxRoiW <= 45 && maxRoiH <= 45) {      // few cells: a workgroup per cell
-        if (blurItems) hipLaunchKernelGGL((k_fast_wide<48, 45, true>), xcdGrid(nCells + (blurLanes + 255) / 256, B), block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
+        if (blurItems)
+            hipLaunchKernelGGL((k_fast_wide<48, 45, true>), xcdGrid(nCells + (blurLanes + 255) / 256, B), block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh,
+                               minTh, candSeg, cellCount, f0, B, tail, lt);
         else hipLaunchKernelGGL((k_fast_wide<48, 45, false>), xcdGrid(nCells, B), block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, candSeg, cellCount, f0, B, tail, lt);
         return;
     }

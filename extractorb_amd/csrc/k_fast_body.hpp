@@ -122,7 +122,8 @@ extern "C" int orbx_debug_fast_mid(unsigned long long* out) { return (int)hipMem
 #define FAST_CLOCK_BEGIN const unsigned long long fcR0 = __builtin_amdgcn_s_memrealtime(), fcT0 = __builtin_amdgcn_s_memtime();
 #define FAST_CLOCK_END do { const unsigned long long fcT1 = __builtin_amdgcn_s_memtime(), fcR1 = __builtin_amdgcn_s_memrealtime(); \
         const unsigned fcW = (unsigned)(f * nCells + ci); \
-        if (lane == 0 && (fcW & 63u) == 0u) { g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1))] = fcT1 - fcT0; g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1)) + 1] = fcR1 - fcR0; } } while (0)
+        if (lane == 0 && (fcW & 63u) == 0u) { g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1))] = fcT1 - fcT0; \
+                                              g_fastClock[2 * ((fcW >> 6) & (kFastClockSlots - 1)) + 1] = fcR1 - fcR0; } } while (0)
 #else
 #define FAST_CLOCK_BEGIN
 #define FAST_CLOCK_END do {} while (0)
@@ -407,7 +408,7 @@ __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int
                         ldsAtomicAdd(&tHist[li], 1u);
                         ldsAtomicMax(&tBest[li], val);
                     } else {
-                        const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
+                        const unsigned cellOfRoot = leafTableEntry(lt, f, c.level, xc, yc);
                         atomicAdd(lt.hist + cellOfRoot, 1);
                         atomicMax(lt.best + cellOfRoot, val);
                     }
@@ -423,7 +424,7 @@ __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int
             if (n) {
                 const int er = (int)(((float)e + 0.5f) * __frcp_rn((float)nxl));      // e / nxl (exact: e < 1024, the quotient is >= 0.5 / nxl away from an integer)
                 const int xc = xc0 + (e - er * nxl), yc = yc0 + er;
-                const unsigned cellOfRoot = ((unsigned)(f * lt.nlevels + c.level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves + (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));      // (32 bits: orbx_api.cpp checks frames x levels x roots x 1024 < 2^30 entries)
+                const unsigned cellOfRoot = leafTableEntry(lt, f, c.level, xc, yc);
                 atomicAdd(lt.hist + cellOfRoot, (int)n);
                 atomicMax(lt.best + cellOfRoot, tBest[e]);
             }

@@ -527,10 +527,14 @@ void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long lo
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
-    constexpr int blurMinRun = 8;      // (measured, 512 x 640x480, three levels inside: runs of >= 8 rows 617 us, 16: 668, 24: 680, 32: 770 - few long runs leave most of a workgroup at the level's barrier)
+    // (measured, 512 x 640x480, three levels inside: runs of >= 8 rows 617 us, 16: 668, 24: 680, 32: 770 - few long runs leave most of a workgroup at the
+    // level's barrier)
+    constexpr int blurMinRun = 8;
 #define ORBX_COLS_LAUNCH(P, T, TD) do { \
-        if (blur) hipLaunchKernelGGL((k_pyr_cols<P, T, TD, true>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, blur, blurLevels, blurMinRun, bufEvenBytes, f0, B); \
-        else hipLaunchKernelGGL((k_pyr_cols<P, T, TD, false>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, pyr, blur, 0, blurMinRun, bufEvenBytes, f0, B); \
+        if (blur) hipLaunchKernelGGL((k_pyr_cols<P, T, TD, true>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, \
+                                     pyr, blur, blurLevels, blurMinRun, bufEvenBytes, f0, B); \
+        else hipLaunchKernelGGL((k_pyr_cols<P, T, TD, false>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, \
+                                pyr, blur, 0, blurMinRun, bufEvenBytes, f0, B); \
     } while (0)
     (void)packed;      // (the host only takes this form when the taps of every column quad fit the packed step's 8-byte window)
     if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);

@@ -178,7 +178,10 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
                 done[best]++;
             }
             roleCount[mask] = (int)(roleTab.size() - roleOff[mask]);
-            if (fastChunks > 65535 || descGroups > 65535 || blurBlocks > 65535 || roleCount[mask] > 65535) { roleCount[mask] = 0; roleTab.resize(roleOff[mask]); }      // (no pipelined form for this geometry)
+            if (fastChunks > 65535 || descGroups > 65535 || blurBlocks > 65535 || roleCount[mask] > 65535) {      // (no pipelined form for this geometry)
+                roleCount[mask] = 0;
+                roleTab.resize(roleOff[mask]);
+            }
         }
     }
     const size_t roleAt = (image.size() + 15) & ~(size_t)15;      // (the tables ride in the same staging block; their device block is sized below)

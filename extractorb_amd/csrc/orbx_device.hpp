@@ -105,6 +105,13 @@ ORBX_HD inline int octXCode(int x, float hX, int nIni) {
 //   hist / best : [frame][level][R][kOctLeaves]   (zero between calls: k_octree clears what it loads)
 //   xcode / ycode : [level][XT] host-built octXCode / octAxisPath of every rectangle column / row
 struct LeafTables { int* hist; unsigned* best; const uint8_t* xcode; const uint8_t* ycode; int R, XT, nlevels, frames; };
+#ifdef __HIPCC__
+// Entry of leaf cell (x code xc, y code yc) of frame f, level `level` in hist / best (32 bits: orbx_create keeps frames x levels x roots x 1024 below 2^30)
+__device__ __forceinline__ unsigned leafTableEntry(const LeafTables& lt, int f, int level, int xc, int yc) {
+    return ((unsigned)(f * lt.nlevels + level) * (unsigned)lt.R + (unsigned)(xc >> kOctDepth)) * kOctLeaves +
+           (unsigned)((yc << kOctDepth) | (xc & ((1 << kOctDepth) - 1)));
+}
+#endif
 
 // ---- the pipelined launch (k_pipe.hip): one launch per pipeline step, its workgroups dealt four roles by a host-made table ----
 enum { kPipeF = 0, kPipeB = 1, kPipeO = 2, kPipeD = 3 };      // FAST cells / blur rows of chunk t, quad-tree levels of chunk t - 1, keypoints of chunk t - 2

@@ -355,7 +355,11 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (l < top && x1 >= x0 && y1 >= y0) {      // taps of the rectangle of level l + 1
                         const std::vector<ResizeX>& X = g.rx[l + 1];
                         const std::vector<ResizeX>& Y = g.ry[l + 1];
-                        for (int xv = x0; xv <= x1; xv++) { const int x = refl(xv, g.lv[l + 1].w); nx0 = std::min(nx0, (int)std::min(X[x].sx0, X[x].sx1)); nx1 = std::max(nx1, (int)std::max(X[x].sx0, X[x].sx1)); }
+                        for (int xv = x0; xv <= x1; xv++) {
+                            const int x = refl(xv, g.lv[l + 1].w);
+                            nx0 = std::min(nx0, (int)std::min(X[x].sx0, X[x].sx1));
+                            nx1 = std::max(nx1, (int)std::max(X[x].sx0, X[x].sx1));
+                        }
                         for (int y = y0; y <= y1; y++) { ny0 = std::min(ny0, (int)std::min(Y[y].sx0, Y[y].sx1)); ny1 = std::max(ny1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
                     }
                     const bool blur = l < nblur;
