@@ -209,3 +209,22 @@ def test_first_call_on_fresh_handles_has_every_border_byte():
             for l in range(nl):
                 got = ex.image_pyramid_level(l, 0, bordered=True)
                 assert np.array_equal(got, want[l]), "handle %d, %dx%d level %d: %d bytes of the bordered level differ" % (rep, cols, rows, l, int((got != want[l]).sum()))
+
+
+def test_clock_probe_and_policy_string():
+    """Round 5 introspection bench.py relies on: the shader-clock probe (one sleeping wave per CU stamps s_memtime against the 100-MHz s_memrealtime,
+    asynchronous, on a stream of its own) reports a plausible clock beside a running batch, and the policy string lists the switches orbx_create read."""
+    ex = X.ORBextractor(1000, max_batch=8)
+    frames = synth.frames("noise", 5, 8, 480, 640)
+    for slot in range(3):
+        ex.clock_probe(slot)
+        ex.extract_batch(frames)
+    ghz = ex.clock_read(4)
+    assert all(1.0 < v < 3.5 for v in ghz[:3]), ghz          # MI355X: up to 2.4 GHz
+    assert ghz[3] == 0.0                                     # a slot never probed
+    with pytest.raises(X.OrbxError):
+        ex.clock_probe(64)
+    pol = ex.policy()
+    for key in ("SPLIT=1", "PIPE=0", "PIPE_CHUNK=128", "PATCH_BLUR=-1", "LEAF_FRAMES=128", "ZERO_COPY=1"):
+        assert key in pol, pol
+    assert "(env)" not in pol and "test_aids" not in pol, pol
