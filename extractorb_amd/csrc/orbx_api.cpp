@@ -509,7 +509,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             launchPipe(st, a, h->roleCount[mask], std::max(a.fFn, std::max(a.oFn, a.dFn)), ldsBytes);
         }
-        h->lastKernel[S_FAST] = h->lastKernel[S_OCTREE] = h->lastKernel[S_DESCRIBE] = h->lastKernel[S_BLUR] = "k_pipe";
     } else if (stagger) {
         struct Join {
             orbx_handle* h; hipStream_t st; bool armed = false;

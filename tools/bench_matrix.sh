@@ -33,6 +33,8 @@ echo "# ORBX_FUSE_SMALL=0 --steps 300 --batch 1" >> gpurun_out/matrix.jsonl; ORB
 echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd1080" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd1080 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd720" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd720 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_SPLIT=3 --steps 30 --batch 256" >> gpurun_out/matrix.jsonl; ORBX_SPLIT=3 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --batch 256 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_PATCH_BLUR=0 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_PIPE=1 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_PIPE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 run --steps 30 --handles 2
 timeout -k 10 300 python tools/host_path_rate.py > gpurun_out/host_path.txt 2>&1
 echo done
