@@ -2,7 +2,7 @@
 # Fuzz soaks of round 5's forms on the GPU box (two gpurun calls: part 1 / part 2): the default policy (patch blur over the disc for large batches, the
 # separate blur below), both blur forms forced, the pipelined launches with chunks that do and do not divide the batches, the stream-ordered create /
 # geometry uploads on fresh handles (every fuzz draw is a fresh handle), the resident quad-tree builds without scratch, with and without the test aids.
-# Totals -> gpurun_out/r5_soak_<part>.txt          usage: tools/soak_r5.sh 1|2|3
+# Totals -> gpurun_out/r5_soak_<part>.txt          usage: tools/soak_r5.sh 1|2|3|4
 cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT) or export it}"; PART=${1:-1}; OUT=gpurun_out/r5_soak_$PART.txt; : > $OUT
 run() { echo "## $1 :: $2" >> $OUT; env $1 timeout -k 10 420 python $2 2>&1 | tail -1 >> $OUT || echo "FAILED" >> $OUT; }
 if [ "$PART" = 1 ]; then
@@ -22,6 +22,13 @@ elif [ "$PART" = 3 ]; then      # the long one: single frames on fresh handles, 
   run "FUZZ_AIDS=poison=119" "tools/fuzz_parity.py 800 803"
   run "ORBX_PATCH_BLUR=1" "tools/fuzz_parity.py 800 804"
   run "" "tools/fuzz_batches.py 200 805"
+elif [ "$PART" = 4 ]; then      # more of the same on the very last sources: new seeds, the pipelined form, the separate blur, poisoned arenas
+  run "" "tools/fuzz_parity.py 1000 901"
+  run "" "tools/fuzz_parity.py 1000 902"
+  run "ORBX_PIPE=1" "tools/fuzz_parity.py 1000 903"
+  run "ORBX_PATCH_BLUR=0" "tools/fuzz_parity.py 800 904"
+  run "FUZZ_AIDS=poison=201,lds_pollute=55" "tools/fuzz_parity.py 800 905"
+  run "ORBX_PIPE=1 ORBX_PIPE_CHUNK=5" "tools/fuzz_batches.py 150 906"
 else
   run "" "tools/fuzz_batches.py 120 711"
   run "ORBX_PIPE=1 ORBX_PIPE_CHUNK=1" "tools/fuzz_batches.py 50 712"
