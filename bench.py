@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even at N = 1 (what --gpus N > 1 does "
                     "by itself when no launcher set RANK)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed slab")
+    ap.add_argument("--prime-steps", type=int, default=64, help="untimed steps in front of the warm-up steps (the clock settles over the first ~100 ms "
+                    "of load; 0 = the warm-up steps only)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0, help="N = 1: length of the sustained-load window behind the timed steps "
                     "(secondary.sustained; 0 = skip; --no-extras skips it too)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --stub-extractor)")
@@ -328,6 +330,7 @@ def main():
         gathered = [[torch.empty_like(slab) for _ in range(world)] for _ in range(len(slabs))]
     pending = [None] * len(slabs)      # the gather that last read slab k (and last wrote gathered[k])
     counter = [0]
+    prime_steps = 0 if stub else args.prime_steps      # untimed steps in front of the warm-up steps (below)
     # what the gather costs the step (SCALE diagnostics): the time `pending[k].wait()` holds up the slab's next writer - on the host (gloo
     # blocks the caller) and on the handle's stream (RCCL's wait is a stream dependency: measured between two events around it)
     exposed = dict(on=False, host_s=0.0, events=[])
@@ -365,7 +368,7 @@ def main():
             finish_and_track(e_, b)
         if bow:
             compute_bow(e_, b)
-        if corrupt_rank == rank and counter[0] == 1 + args.warmup + args.steps:
+        if corrupt_rank == rank and counter[0] == 1 + prime_steps + args.warmup + args.steps:
             slabs[k][off_d + (B - 1) * cap * 32] ^= 0xFF      # (test switch: one descriptor byte of the last timed step's last frame)
         if gather:
             if j != 0:
@@ -393,6 +396,12 @@ def main():
         d_world[:, :, 1] = (un[:, :, 1] - 240.0) / 500.0 * Zp
         d_world[:, :, 2] = Zp
         torch.cuda.synchronize()
+    # Untimed priming beyond the warm-up count (round 5): the driver's 5 warm-up steps are 8 ms, and the first timed window of a fresh process lay 0-2 %
+    # below the rate the same process holds for seconds (secondary.sustained: the chip's clock settles over the first ~100 ms of load).  A fixed number of
+    # untimed steps (the same on every rank: the gather is a collective) brings the timed K steps into that steady state; `priming_steps` is in the line.
+    for _ in range(prime_steps):
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -909,7 +918,7 @@ def main():
                        **({"mean_bow_matches_per_pair": round(float(d_nmb.float().mean().item()), 1)} if refkf else {}),
                        "handles_per_gpu": nH, "policy": ex.policy(),
                        "parallelism": "frames sharded %d/GPU%s" % (B, ", RCCL gather of result slabs to rank 0 overlapped with the next step" if gather else "")},
-            "value_basis": value_basis,
+            "value_basis": value_basis, "priming_steps": prime_steps,
             "verified": verified, "roofline": roofline, "cpu_baseline": cpu, "multi_gpu": multi,
             "secondary": ({**extras, **({"configs4_64_per_gpu": cfg5} if cfg5 else {})}) or None,
         }
