@@ -1,7 +1,7 @@
 """bench.py's N > 1 branch at world size 2 in the CPU suite: `python bench.py --gpus 2 --backend gloo
---stub-extractor` goes through spawn_ranks -> torch.distributed.run -> two ranks -> gloo group, and runs the file's own step() /
-pending[] / fence() / configs[4] / max-over-ranks code with CPU tensors; the slabs are written by the oracle (a REHEARSAL: the line says
-value = null).  Rank 0 checks frames of EVERY rank's gathered slab against the oracle on that rank's frames, and a wrong slab makes the
+--extractor-factory bench_stub:make_extractor` goes through spawn_ranks -> torch.distributed.run -> two ranks -> gloo group, and runs the file's own step() /
+pending[] / fence() / configs[4] / max-over-ranks code with CPU tensors; the slabs are written by tests/bench_stub.py (the oracle on host
+memory - a REHEARSAL: the line says value = null; bench.py itself contains no stand-in extractor, it only imports the module the flag names).  Rank 0 checks frames of EVERY rank's gathered slab against the oracle on that rank's frames, and a wrong slab makes the
 process exit non-zero."""
 import json
 import os
@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(extra_env=None, extra_args=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-extractor", "--batch", "3", "--steps", "3",
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests")] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--extractor-factory", "bench_stub:make_extractor", "--batch", "3", "--steps", "3",
                         "--warmup", "1", *extra_args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     return r, (json.loads(lines[0]) if len(lines) == 1 else None)
@@ -52,3 +53,17 @@ def test_no_gather_leaves_results_on_their_ranks():
     assert r.returncode == 0, r.stderr[-4000:]
     assert j["verified"]["ranks_checked"] == [0] and j["verified"]["bit_exact"] is True
     assert j["multi_gpu"]["gather_exposed_ms"] is None and len(j["multi_gpu"]["per_rank_ms_per_step"]) == 2
+
+
+def test_bench_py_names_the_oracle_only_in_its_checking_legs():
+    """no line of bench.py may import the oracle outside the post-timing `verified` / `cpu_baseline` /
+    `hd1080` legs; the stand-in extractor of the rehearsal lives in tests/bench_stub.py behind --extractor-factory."""
+    src = open(os.path.join(ROOT, "bench.py")).read().splitlines()
+    imports = [i for i, l in enumerate(src) if "import oracle_lib" in l]
+    t0 = next(i for i, l in enumerate(src) if l.strip() == "t0 = time.perf_counter()")
+    t1 = next(i for i, l in enumerate(src) if l.strip() == "elapsed = time.perf_counter() - t0")
+    assert imports and all(i > t1 for i in imports), "an oracle import in front of / inside the timed region: %s" % imports
+    assert t0 < t1
+    for i in imports:
+        assert "checker" in src[i], src[i]
+    assert "StubExtractor" not in "\n".join(src) and "O_stub" not in "\n".join(src)
