@@ -1,5 +1,5 @@
-// k_describe_body.hpp - IC_Angle, rotated BRIEF and the final placement of one workgroup's eight keypoints as a device function: k_describe.hip
-// launches it as a kernel of its own, k_pipe.hip runs it as one role of the pipelined launch.  See k_describe.hip for the algorithm.
+// k_describe_body.hpp - IC_Angle, rotated BRIEF and the final placement of one workgroup's eight keypoints as a device function; k_describe.hip
+// launches it.  See k_describe.hip for the algorithm.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -138,8 +138,8 @@ struct DescLds {
     static constexpr int kWtabOff = (kPatches + 15) & ~15, kBytes = kWtabOff + 4 * kWtabWords;
 };
 
-// One workgroup = eight keypoint slots [8 chunk, 8 chunk + 8) of frame f (the whole of k_describe's work; also a role of the pipelined launch,
-// k_pipe.hip).  smem: the patches (DescLds::kPatches bytes), wtab: the weight words.  One workgroup barrier (behind the weight table).
+// One workgroup = eight keypoint slots [8 chunk, 8 chunk + 8) of frame f.  smem: the patches (DescLds::kPatches bytes), wtab: the weight words.
+// One workgroup barrier (behind the weight table).  A wave whose level lies outside [levelLo, levelHi) belongs to another launch and leaves.
 template <bool PB>
 __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, int nlevels,
                                               const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
@@ -148,7 +148,7 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
                                               Keypoint* __restrict__ outK, uint8_t* __restrict__ outD, int capacity,
                                               int* __restrict__ nOut, int* __restrict__ monoOut,
                                               Keypoint* __restrict__ outLevelK, int* __restrict__ outLevelCounts, int fewWaves,
-                                              uint8_t* smem, unsigned (*wtab)[16][PB ? 12 : 8], int chunk, int f) {
+                                              uint8_t* smem, unsigned (*wtab)[16][PB ? 12 : 8], int chunk, int f, int levelLo, int levelHi) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
     DSTAMP(0);
     if constexpr (PB) {   // weight words of row |v| = a over the re-aligned tile row: byte t = 4 j + b <-> u = t - 22
@@ -208,6 +208,7 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
         if (slot0 == 0 && outLevelCounts && lane < nlevels) outLevelCounts[f * nlevels + lane] = levelCount[f * nlevels + lane];
     }
     if (slot0 == 0 && lane == 0) { nOut[f] = total; monoOut[f] = total - totalLap; }      // monoIndex after the loop (:1161)
+    if (level < levelLo || level >= levelHi) return;      // (wave-uniform: the other launch of a blur split by level describes this level)
     const int i = slot - selOff;
     const bool active = slot < selPerFrame && i < levelN;
     if (__ballot(active) == 0) return;

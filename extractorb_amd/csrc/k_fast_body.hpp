@@ -1,5 +1,5 @@
 // k_fast_body.hpp - the FAST cell's arithmetic and the one-cell-per-wave body as device functions: k_fast.hip launches it as a kernel of its
-// own (and has the workgroup-per-cell form of single frames), k_pipe.hip runs it as one role of the pipelined launch.  See k_fast.hip for the
+// own (and has the workgroup-per-cell form of single frames).  See k_fast.hip for the
 // algorithm.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -168,7 +168,7 @@ struct FastLds {
     static constexpr int kScoreOff = (kTiles + 15) & ~15, kCodeOff = (kScoreOff + kScores + 15) & ~15, kBytes = kCodeOff + kCodes;
 };
 
-// One cell on one wave (the whole of k_fast's work; also a role of the pipelined launch, k_pipe.hip).  smem / scoreS / codeL: the workgroup's
+// One cell on one wave (the whole of k_fast's work).  smem / scoreS / codeL: the workgroup's
 // three LDS arrays (FastLds), chunk: the workgroup's group of four cells, f: the frame.  No workgroup barrier.
 template <int TS, int ROWS>
 __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int nCells, const LevelGeom* __restrict__ lv,

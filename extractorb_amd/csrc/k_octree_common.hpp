@@ -1,5 +1,5 @@
 // k_octree_common.hpp - helpers of the quad-tree kernel body (k_octree_body.inc): k_octree.hip compiles the body as kernels of three workgroup
-// sizes, k_pipe.hip as one role of the pipelined launch.  See k_octree.hip for the algorithm.
+// sizes.  See k_octree.hip for the algorithm.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -16,7 +16,6 @@
 #include <stdint.h>
 
 #include "orbx_device.hpp"
-#include "k_blur_body.hpp"      // blurRun: a region of k_pyr_cols<.., BLUR> blurs what it owns of a level out of its LDS rectangle
 
 namespace orbx {
 
@@ -320,20 +319,15 @@ __device__ __forceinline__ void chainStep(const uint8_t* S, uint8_t* D, const Ch
 // writing the owned bordered bytes to HBM.  The first TD of the T threads do the former, the rest the latter, side by side (one after the
 // other in every thread, a 40-px region's level took 1.0 us, of which 0.36 the write).  TD == T: every thread does both (more frames than
 // the chip has room for at once: no thread should idle).
-// BLUR: the region also blurs the pixels it owns of every level (7x7 sigma 2, ORBextractor.cc:1126-1127) out of the same rectangle, which then
-// carries the blur's halo (orbx_geometry.hpp: buildCols(px, blur): a dword left and right as VIRTUAL columns where that leaves the level, three
-// rows up and down mirrored by index) for the finest `blurLevels` levels — the halo compounds down the chain, so the coarse levels, few pixels,
-// stay with k_blur: most of its read of the pyramid and of its 6-in-38 halo rows from HBM are gone.  TB of the T threads take blur items
-// (4 columns x a run of rows), the writing role's threads first.
-template <bool PACKED, int T, int TD, bool BLUR = false, int TB = T>
+template <bool PACKED, int T, int TD>
 __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __restrict__ cols, const ColLevels* __restrict__ lvp, int nlevels,
                                                             const ResizeX* __restrict__ colCoef, int coefSlot,
-                                                            uint8_t* __restrict__ pyr, uint8_t* __restrict__ blurred, int blurLevels, int blurMinRun, int bufEvenBytes, int f0, int nFrames) {
+                                                            uint8_t* __restrict__ pyr, int bufEvenBytes, int f0, int nFrames) {
     static_assert(TD <= T && TD % 64 == 0 && (T - TD) % 64 == 0, "roles are whole waves");
     extern __shared__ __align__(16) uint8_t lds[];
     __shared__ __align__(16) ResizeX coef[kChainCoefMax];
     // what writing a level needs, fetched with the up-front loads: read per level from memory, every level would start with an L2 round trip
-    struct LevelOut { ColOwn own; int w, h, stride, blurStride; long long off, blurOff; };
+    struct LevelOut { ColOwn own; int w, h, stride; long long off; };
     __shared__ LevelOut outOf[kMaxLevels];
     int t, fr;
     if (!xcdChunkFrame(nFrames, t, fr)) return;
@@ -342,8 +336,7 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
     const ColLevels& lv = *lvp;
     const int top = nlevels - 1;
     LevelOut myOut{};
-    if (tid < nlevels) myOut = LevelOut{pc.own[tid], lv.w[tid], lv.h[tid], lv.pyrStride[tid], lv.blurStride[tid], lv.pyrOff[tid] + (long long)f * lv.pyrFrameBytes[tid],
-                                        lv.blurOff[tid] + (long long)f * lv.blurFrameBytes[tid]};
+    if (tid < nlevels) myOut = LevelOut{pc.own[tid], lv.w[tid], lv.h[tid], lv.pyrStride[tid], lv.pyrOff[tid] + (long long)f * lv.pyrFrameBytes[tid]};
     CSTAMP(0);
     CSPAN_BEGIN;
     auto bufOf = [&](int j) { return lds + ((j & 1) ? bufEvenBytes : 0); };      // level j's rectangle lives in buffer j & 1 (an LDS offset, never a generic pointer)
@@ -371,9 +364,9 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
             const uint8_t* q = src + ((unsigned)__mul24(row, img.stride) + 4u * (unsigned)c);
             const int x = r.x0 + 4 * c;
             if (img.aligned && x >= 0 && x + 3 < img.readableCols) w[i] = *(const unsigned*)q;
-            else {                                                          // a row's last dword, a virtual column (BLUR), or an unaligned image: no byte outside the row is read
+            else {                                                          // a row's last dword or an unaligned image: no byte outside the row is read
 #pragma unroll
-                for (int b = 0; b < 4; b++) w[i] |= (unsigned)q[reflect101(x + b, img.readableCols) - x] << (8 * b);      // (column v < 0 is column -v, v >= w is 2 (w - 1) - v)
+                for (int b = 0; b < 4; b++) w[i] |= (unsigned)q[reflect101(x + b, img.readableCols) - x] << (8 * b);
             }
             }
         }
@@ -477,38 +470,6 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
             }
         }
         }
-        if (BLUR && j < blurLevels) {
-            // ---- the blur of the owned pixels: column groups [g0, g1) x rows [y0, y1) of the border-less level, dealt as (group, run of rows)
-            //      items over TB threads, the writing role's first (they have the shorter job) ----
-            const LevelOut lo = outOf[j];
-            const int g0 = max((int)lo.own.dw0 - kPadL / 4, 0), g1 = min((int)lo.own.dw1 - kPadL / 4, (lo.w + 3) >> 2);
-            const int y0 = max((int)lo.own.r0 - kEdge, 0), y1 = min((int)lo.own.r1 - kEdge, lo.h);
-            const int G = g1 - g0, H = y1 - y0;
-            if (G > 0 && H > 0) {                                        // workgroup-uniform
-                constexpr int TWr = T - TD;                              // (0 when every thread does both jobs)
-                const int btid = (j == top || TWr == 0) ? tid : (tid >= TD ? tid - TD : tid + TWr);
-                const float rG = __frcp_rn((float)G);
-                // runs per column group: as many as TB threads allow, but runs of at least blurMinRun rows - a run re-does the horizontal pass of
-                // six halo rows, and on an issue-bound chip idle threads are free while repeated arithmetic is not
-                const int nb = min(max((int)(((float)TB + 0.5f) * rG), 1), max((int)(((float)H + 0.5f) * __frcp_rn((float)blurMinRun)), 1));
-                int per = (int)(((float)(H + nb - 1) + 0.5f) * __frcp_rn((float)nb));
-                per = (per + 1) & ~1;                                    // (even: a run's rows pair up)
-                const int blk = (int)(((float)btid + 0.5f) * rG), grp = btid - blk * G;
-                const int yb = y0 + blk * per, nOut = min(per, y1 - yb);
-                if (btid < TB && nOut > 0) {
-                    const int h = lo.h;
-                    const uint8_t* scol = S + (4 * (g0 + grp) - 4 - rs.x0);      // pixel x0 - 4 of rectangle row 0 (a multiple of 4, as rs.x0 is)
-                    uint8_t* dcol = blurred + lo.blurOff + 4 * (g0 + grp);
-                    const int bstride = lo.blurStride;
-                    blurRun(nOut,
-                            [&](int i, unsigned& d0, unsigned& d1, unsigned& d2) {
-                                const unsigned* row = (const unsigned*)(scol + __mul24(reflect101(yb - 3 + min(i, nOut + 5), h) - rs.y0, ss));
-                                d0 = row[0]; d1 = row[1]; d2 = row[2];
-                            },
-                            [&](int r, unsigned word) { *(unsigned*)(dcol + (long long)(yb + r) * bstride) = word; });
-                }
-            }
-        }
         __syncthreads();
         CSTAMP(j + 2);
     };
@@ -519,31 +480,21 @@ __global__ __launch_bounds__(T) void k_pyr_cols(SrcView img, const PyrColumn* __
     CSPAN_END(0);
 }
 
-// variant: 0 = 768 threads (512 derive), 1 = 512 (256 derive), 2 = 512 (every thread both jobs), 3 = 256 (both jobs), 4 = 768 (256 derive),
-// 5 = 1024 (256 derive), 6 = 1024 (512 derive).  blur != nullptr: the regions carry the blur's halo and write the blurred levels too.
+// shape: 1 = 512 threads (256 derive + 256 write: every launch that fills the chip), 4 = 768 (256 + 512) and 6 = 1024 (512 + 512): while every
+// workgroup has a CU to itself (orbx_api.cpp: colsShape).  Rounds 3-5 carried four more shapes (every thread both jobs at 256 / 512 threads,
+// 768 = 512 + 256, 1024 = 256 + 768) that never won at any batch size (docs/history/r04.md); removed in round 6.
 void launchPyrCols(hipStream_t st, const uint8_t* img, long long stride, long long frameStride, int imgW, const PyrColumn* cols, int nCols,
-                   const ColLevels* lv, int nlevels, const ResizeX* colCoef, int coefSlot, uint8_t* pyr, uint8_t* blur, int blurLevels, int ldsBytes, int bufEvenBytes,
-                   bool packed, int variant, int f0, int B) {
+                   const ColLevels* lv, int nlevels, const ResizeX* colCoef, int coefSlot, uint8_t* pyr, int ldsBytes, int bufEvenBytes,
+                   bool packed, int shape, int f0, int B) {
     SrcView sv;
     sv.p = img; sv.stride = (int)stride; sv.frame = frameStride; sv.readableCols = imgW;
     sv.aligned = (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)frameStride) & 3) == 0;
-    // (measured, 512 x 640x480, three levels inside: runs of >= 8 rows 617 us, 16: 668, 24: 680, 32: 770 - few long runs leave most of a workgroup at the
-    // level's barrier)
-    constexpr int blurMinRun = 8;
-#define ORBX_COLS_LAUNCH(P, T, TD) do { \
-        if (blur) hipLaunchKernelGGL((k_pyr_cols<P, T, TD, true>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, \
-                                     pyr, blur, blurLevels, blurMinRun, bufEvenBytes, f0, B); \
-        else hipLaunchKernelGGL((k_pyr_cols<P, T, TD, false>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, \
-                                pyr, blur, 0, blurMinRun, bufEvenBytes, f0, B); \
-    } while (0)
+#define ORBX_COLS_LAUNCH(P, T, TD) hipLaunchKernelGGL((k_pyr_cols<P, T, TD>), xcdGrid(nCols, B), dim3(T), (size_t)ldsBytes, st, sv, cols, lv, nlevels, colCoef, coefSlot, \
+                                                  pyr, bufEvenBytes, f0, B)
     (void)packed;      // (the host only takes this form when the taps of every column quad fit the packed step's 8-byte window)
-    if (variant == 0) ORBX_COLS_LAUNCH(true, 768, 512);
-    else if (variant == 1) ORBX_COLS_LAUNCH(true, 512, 256);
-    else if (variant == 2) ORBX_COLS_LAUNCH(true, 512, 512);
-    else if (variant == 4) ORBX_COLS_LAUNCH(true, 768, 256);
-    else if (variant == 5) ORBX_COLS_LAUNCH(true, 1024, 256);
-    else if (variant == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
-    else ORBX_COLS_LAUNCH(true, 256, 256);
+    if (shape == 6) ORBX_COLS_LAUNCH(true, 1024, 512);
+    else if (shape == 4) ORBX_COLS_LAUNCH(true, 768, 256);
+    else ORBX_COLS_LAUNCH(true, 512, 256);
 #undef ORBX_COLS_LAUNCH
 }
 

@@ -17,11 +17,15 @@ const char* const kSlotNames[ORBX_NUM_KERNELS] = {"k_pyr_first", "k_resize", "k_
 thread_local std::string g_createError;
 
 namespace {
+// The automatic split level of the per-keypoint blur (installGeometry): k_blur takes the levels whose patches hold more than kSplitRatioNum /
+// kSplitRatioDen of the level's pixels.  0 / 1 = never split on its own (ORBX_BLUR_SPLIT=L still pins a level).
+constexpr int kSplitRatioNum = 0, kSplitRatioDen = 1;
+
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,
                    h->d_levelLap, h->d_lap, h->d_lv, h->d_cells, h->d_rx, h->d_ry, h->d_xq, h->d_cols, h->d_colLevels, h->d_colCoef, h->d_foot, h->d_tiles, h->d_laneItem, h->d_out,
                    h->d_octArena, h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_bowWord, h->d_bowNode, h->d_bowWeight, h->d_rowOff, h->d_sadDist,
-                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth, h->d_clock, h->d_roles};
+                   h->d_nMatched, h->d_rowList, h->d_uRight, h->d_depth, h->d_clock};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
@@ -44,7 +48,7 @@ void freeAll(orbx_handle* h) {
 // block is reused by the next geometry change, which starts by waiting for this stream.
 int installGeometry(orbx_handle* h, int rows, int cols) {
     FrameGeom g;
-    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->colPx, h->blurInLevels);
+    std::string why = makeFrameGeom(h->tabs, rows, cols, g, h->colPx);
     if (!why.empty()) return fail(h, why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED, why);
     layoutArenas(g, h->maxB);
     const LevelGeom& last = g.lv[g.nlevels - 1];
@@ -64,7 +68,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         std::memcpy(image.data() + at, src, bytes);
         ups.push_back(Upload{dst, at, bytes});
     };
-    size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {}, xqOff[kMaxLevels] = {}, footOff[kMaxLevels] = {}, colsOff[8] = {}, colCoefOff[8] = {};
+    size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {}, xqOff[kMaxLevels] = {}, footOff[kMaxLevels] = {}, colsOff[4] = {}, colCoefOff[4] = {};
     size_t xo = 0, yo = 0;
     for (int l = 1; l < g.nlevels; l++) {
         rxOff[l] = xo; ryOff[l] = yo;
@@ -107,13 +111,12 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     }
     {
         size_t n = 0, nc = 0;
-        for (std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
-        for (FrameGeom::ColumnSet& cs : *sets) {
+        for (FrameGeom::ColumnSet& cs : g.colSets) {
             if (n + cs.columns.size() > h->colsCap || nc + cs.coef.size() > h->colCoefCap) cs.fit = false;      // (a region size far below the default ones: the other forms serve)
             if (!cs.fit) continue;
             stage(h->d_cols + n, cs.columns.data(), sizeof(PyrColumn) * cs.columns.size());
             stage(h->d_colCoef + nc, cs.coef.data(), sizeof(ResizeX) * cs.coef.size());
-            const size_t slot = (&cs - sets->data()) + (sets == &g.colSetsBlur ? 4 : 0);      // (at most four cuts per geometry: kColPx)
+            const size_t slot = &cs - g.colSets.data();      // (at most four cuts per geometry: kColPx)
             colsOff[slot] = n;
             colCoefOff[slot] = nc;
             n += cs.columns.size();
@@ -124,22 +127,31 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         for (int l = 0; l < g.nlevels; l++) {
             c.w[l] = g.lv[l].w; c.h[l] = g.lv[l].h; c.pyrStride[l] = g.lv[l].pyrStride; c.rxOff[l] = g.lv[l].rxOff; c.ryOff[l] = g.lv[l].ryOff;
             c.pyrOff[l] = g.lv[l].pyrOff; c.pyrFrameBytes[l] = g.lv[l].pyrFrameBytes;
-            c.blurStride[l] = g.lv[l].blurStride; c.blurOff[l] = g.lv[l].blurOff; c.blurFrameBytes[l] = g.lv[l].blurFrameBytes;
         }
         stage(h->d_colLevels, &c, sizeof(c));
     }
+    // The blur split by level (round 6): where the blur is done per keypoint (k_describe<PB>), the patches of a coarse level hold more pixels than the
+    // level itself - quota x 37 x 36 (the disc of the 43 x 37 horizontal pass + the 37 x 37 vertical one) against w x h; 640x480 x 1000: 0.94 of the
+    // level's pixels at level 0, 1.63 at level 3, 3.4 at level 7 - so from the first level whose patches exceed kSplitRatio x its pixels on, k_blur
+    // blurs the level (table [2] below) and k_describe reads the blurred level.  ORBX_BLUR_SPLIT=L pins the level, 0 turns the split off.
+    int splitLevel = 0;
+    if (h->blurSplit > 0) splitLevel = h->blurSplit;
+    else if (h->blurSplit < 0 && kSplitRatioNum > 0)
+        for (int l = 1; l < g.nlevels && !splitLevel; l++)
+            if ((long long)g.lv[l].quota * 37 * 36 * kSplitRatioDen > (long long)kSplitRatioNum * g.lv[l].w * g.lv[l].h) splitLevel = l;
+    if (splitLevel >= g.nlevels) splitLevel = 0;
     int nBlurLanes[3] = {0, 0, 0};
     size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
-    {   // blur tables for both row-block sizes
+    {   // blur tables for both row-block sizes, and the 32-row blocks of the levels from splitLevel on
         std::vector<BlurItem> tiles;
         std::vector<unsigned short> laneItem;
         const int blockRows[3] = {kBlurBlockRows, kBlurBlockRowsSmall, kBlurBlockRows};
         for (int v = 0; v < 3; v++) {
             const size_t t0 = tiles.size(), l0 = laneItem.size();
             int lanes = 0;
-            if (v == 2 && h->blurInLevels >= g.nlevels) { nBlurLanes[v] = 0; blurItemOff[v] = t0; blurLaneOff[v] = l0; continue; }      // (nothing left for k_blur)
+            if (v == 2 && splitLevel == 0) { nBlurLanes[v] = 0; blurItemOff[v] = t0; blurLaneOff[v] = l0; continue; }
             for (int l = 0; l < g.nlevels; l++) {
-                if (v == 2 && l < h->blurInLevels) continue;               // the region-major pyramid blurs the finest levels itself
+                if (v == 2 && l < splitLevel) continue;               // the finest levels are blurred per keypoint
                 for (int y0 = 0; y0 < g.lv[l].h; y0 += blockRows[v]) {
                     laneItem.insert(laneItem.end(), (size_t)(g.lv[l].w + 3) / 4, (unsigned short)(tiles.size() - t0));
                     tiles.push_back(BlurItem{lanes, 0, (short)l, (short)y0});
@@ -154,39 +166,6 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         stage(h->d_tiles, tiles.data(), sizeof(BlurItem) * tiles.size());
         stage(h->d_laneItem, laneItem.data(), sizeof(unsigned short) * laneItem.size());
     }
-    // ---- role tables of the pipelined launch (k_pipe.hip): for every set of roles a pipeline step can hold, the order in which a frame's
-    //      workgroups are dispatched: the quad-tree levels first (the longest chains of barriers start earliest, level 0 = the heaviest first),
-    //      then FAST chunks, keypoint groups and blur blocks interleaved evenly, so that every CU holds a mix of issue-bound and
-    //      latency-bound workgroups for the whole launch ----
-    std::vector<PipeRole> roleTab;
-    size_t roleOff[16] = {};
-    int roleCount[16] = {};
-    {
-        const int fastChunks = ((int)g.cells.size() + 3) / 4, descGroups = (g.selPerFrame + 7) / 8, blurBlocks = (nBlurLanes[0] + 255) / 256;
-        for (int mask = 1; mask < 16; mask++) {
-            roleOff[mask] = roleTab.size();
-            if (mask & (1 << kPipeO))
-                for (int l = 0; l < g.nlevels; l++) roleTab.push_back(PipeRole{(unsigned short)kPipeO, (unsigned short)l});
-            const int roles3[3] = {kPipeF, kPipeD, kPipeB};
-            const int want[3] = {mask & (1 << kPipeF) ? fastChunks : 0, mask & (1 << kPipeD) ? descGroups : 0, mask & (1 << kPipeB) ? blurBlocks : 0};
-            int done[3] = {0, 0, 0};
-            for (int k = want[0] + want[1] + want[2]; k > 0; k--) {
-                int best = -1;
-                for (int r = 0; r < 3; r++)      // the role with the largest share of its items still to come (ties: FAST first)
-                    if (done[r] < want[r] && (best < 0 || (long long)(want[r] - done[r]) * want[best] > (long long)(want[best] - done[best]) * want[r])) best = r;
-                roleTab.push_back(PipeRole{(unsigned short)roles3[best], (unsigned short)done[best]});
-                done[best]++;
-            }
-            roleCount[mask] = (int)(roleTab.size() - roleOff[mask]);
-            if (fastChunks > 65535 || descGroups > 65535 || blurBlocks > 65535 || roleCount[mask] > 65535) {      // (no pipelined form for this geometry)
-                roleCount[mask] = 0;
-                roleTab.resize(roleOff[mask]);
-            }
-        }
-    }
-    const size_t roleAt = (image.size() + 15) & ~(size_t)15;      // (the tables ride in the same staging block; their device block is sized below)
-    image.resize(roleAt + roleTab.size() * sizeof(PipeRole));
-    if (!roleTab.empty()) std::memcpy(image.data() + roleAt, roleTab.data(), roleTab.size() * sizeof(PipeRole));
     // ---- pass 2: the uploads, in stream order ----
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // the device tables and the staging block may still be in use by queued work
     h->geom = FrameGeom();                          // a failure below must not leave half-written tables looking valid
@@ -199,20 +178,12 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
         HIP_TRY(h, hipHostMalloc(&h->h_tab, want));
         h->hTabBytes = want;
     }
-    if (roleTab.size() > h->rolesCap) {      // (after the wait above: nothing queued reads the old tables)
-        if (h->d_roles) (void)hipFree(h->d_roles);
-        h->d_roles = nullptr; h->rolesCap = 0;
-        const size_t want = roleTab.size() + roleTab.size() / 4 + 64;
-        HIP_TRY(h, hipMalloc(&h->d_roles, want * sizeof(PipeRole)));
-        h->rolesCap = want;
-    }
     std::memcpy(h->h_tab, image.data(), image.size());
     for (const Upload& u : ups) HIP_TRY(h, hipMemcpyAsync(u.dst, h->h_tab + u.at, u.bytes, hipMemcpyHostToDevice, h->stream));
-    if (!roleTab.empty()) HIP_TRY(h, hipMemcpyAsync(h->d_roles, h->h_tab + roleAt, roleTab.size() * sizeof(PipeRole), hipMemcpyHostToDevice, h->stream));
     for (int l = 0; l < kMaxLevels; l++) { h->rxOff[l] = rxOff[l]; h->ryOff[l] = ryOff[l]; h->xqOff[l] = xqOff[l]; h->footOff[l] = footOff[l]; }
-    for (int i = 0; i < 8; i++) { h->colsOff[i] = colsOff[i]; h->colCoefOff[i] = colCoefOff[i]; }
+    for (int i = 0; i < 4; i++) { h->colsOff[i] = colsOff[i]; h->colCoefOff[i] = colCoefOff[i]; }
+    h->splitLevel = splitLevel;
     for (int v = 0; v < 3; v++) { h->nBlurLanes[v] = nBlurLanes[v]; h->blurItemOff[v] = blurItemOff[v]; h->blurLaneOff[v] = blurLaneOff[v]; }
-    for (int m = 0; m < 16; m++) { h->roleOff[m] = roleOff[m]; h->roleCount[m] = roleCount[m]; }
     {
         const long long px = (long long)g.lv[0].w * g.lv[0].h;
         int T = px <= 500000 ? 256 : (px <= 1200000 ? 512 : 1024);   // measured: 640x480 -> 256, 1280x720 -> 512, 1920x1080 -> 1024 (512 equal)
@@ -285,9 +256,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // levels exist (or are owed to the FAST launch: blurOwed) and are used.
     const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
     const long long patchPx4 = (long long)h->nfeatures * 43 * 37 * 4;      // 4 x the patches' pixels of horizontal pass
-    const bool patchBlur = !(stages & kStageFront) ? h->lastBlurForm == 3
-                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (patchPx4 <= 5LL * g.sumPixels || (bigBatch && patchPx4 <= 7LL * g.sumPixels)) &&
-                                                 h->pipeMode <= 0));      // (the pipelined form deals the blur's rows to its launches)
+    const bool patchBlur = !(stages & kStageFront) ? (h->lastBlurForm == 3 || h->lastBlurForm == 5)
+                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (patchPx4 <= 5LL * g.sumPixels || (bigBatch && patchPx4 <= 7LL * g.sumPixels))));
+    // ... split by level: levels >= splitL are blurred by k_blur and described from the blurred level (installGeometry: splitLevel)
+    const int splitL = !patchBlur ? 0 : (!(stages & kStageFront) ? (h->lastBlurForm == 5 ? h->lastSplitLevel : 0)
+                                                                   : (h->splitLevel > 0 && h->splitLevel < g.nlevels && h->nBlurLanes[2] > 0 ? h->splitLevel : 0));
     auto pollute = [&](hipStream_t st) { if (h->ldsPollute >= 0) launchLdsPollute(st, h->numCUs, h->ldsPollute, h->d_sink); };
     // Overlap inside one call (round 4): the blurred levels are read by k_description only, the LAST launch, so the blur of a large batch runs on
     // a side stream beside FAST and the quad-tree: pyramid -> {blur | FAST -> quad-tree} -> description.  k_blur is the one HBM-bound kernel of the
@@ -296,21 +269,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // 999-1007; 128 x 1080p 3094-3136 (halves) -> 3021-3029; 128 frames of 640x480 and fewer: no difference.  A low-priority side stream only starts
     // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time).  (Round 2's two
     // half-batches side by side - removed in round 4 - are the "halves" figures above; profiles/r02_split_sweep.md.)
-    // The pipelined form (round 5; k_pipe.hip): the stages behind the pyramid as ONE launch per pipeline step over chunks of the batch - step t
-    // holds the FAST cells and blur rows of chunk t, the quad-tree levels of chunk t - 1 and the keypoints of chunk t - 2, interleaved workgroup
-    // by workgroup, every dependency pointing to an earlier launch.  Built as round 4's verdict asked, bit-exact, and MEASURED SLOWER than the
-    // launch DAG below (512 x 640x480: 1813-1824 us against 1700-1709; DESIGN.md 4k has the timeline and the reason: the step already runs at
-    // 0.90 of the SUM of its kernels' issue times, a workgroup of the mixed launch reserves the union of the roles' LDS - six per CU instead of
-    // FAST's eight - and every wave slot a latency-bound role holds is one FAST cannot hide its own latencies with), so nothing selects it by
-    // default: ORBX_PIPE=1 takes it for every full call of frames up to half a megapixel (the quad-tree role is the 256-thread body).
-    const bool pipeOK = (stages & kStageFront) && (stages & kStageBack) && !h->profiling && !patchBlur && !h->d_octArena && h->octThreads[0] == 256 &&
-                        pipeCanRun(g.maxRoiW, g.maxRoiH) && h->roleCount[15] > 0 && !h->resizeBytewise;
-    const bool pipe = pipeOK && h->pipeMode > 0;
-    const bool blurSide = !pipe && h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
+    const bool blurSide = h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
     bool blurJoin[2] = {false, false};
     int blurF0[2] = {0, 0}, blurBn[2] = {0, 0};
     auto front = [&](hipStream_t st, int f0, int Bn) {
-        int blurInside = 0;      // > 0: the region-major pyramid launch has written that many of the finest blurred levels as well
         // The pyramid region by region: one workgroup takes a region of the image through every level (k_pyr_cols; the coarsest cut that still
         // gives the chip ~3/4 workgroup per CU, else the finest).  Frames up to half a megapixel: for every batch size (512 frames of 640x480:
         // 2016 -> 1979 us per call against one launch per level, whose tiles are poorly filled on such small levels); larger frames: while the
@@ -328,12 +290,6 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         };
         if (h->pyrCols != 0 && g.colsPacked && !h->resizeBytewise) {     // (its steps are the packed ones: the regions carry quad records)
             cs = pickCut(g.colSets);
-            // ORBX_BLUR_IN_COLS=1: the regions also blur what they own of the finest levels before they move on (bit-exact; slower than k_blur
-            // beside FAST: DESIGN.md §4)
-            if (cs && h->blurInCols > 0 && !patchBlur && !pipe) {
-                const FrameGeom::ColumnSet* cb = pickCut(g.colSetsBlur);
-                if (cb && cb->px == cs->px) cs = cb;
-            }
         }
         const bool smallFrame = (long long)g.rows * g.cols <= 512 * 1024;
         if (cs && h->pyrCols < 0 && !smallFrame && (long long)cs->columns.size() * Bn > 12LL * h->numCUs) cs = nullptr;
@@ -343,15 +299,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // workgroup shape (launchPyrCols): while every workgroup has a CU to itself, more threads shorten its levels - 1024 (512 derive, 512
             // write) for the fine cuts, 768 (256 + 512) for the coarse ones, whose levels write more than they derive; else 512 (256 + 256).
             // One frame 40.9 -> 39.8 us, two 45.8 -> 44.6, four 58.3 -> 55.7, eight 71.5 -> 67.1; from 32 frames on the small shape wins
-            const int colsShape = (long long)cs->columns.size() * Bn <= h->numCUs ? (cs->px <= 56 ? 6 : 4) : 1;
+            const int colsShape = h->colsShape > 0 ? h->colsShape : ((long long)cs->columns.size() * Bn <= h->numCUs ? (cs->px <= 56 ? 6 : 4) : 1);
             Prof p(h, S_RESIZE, st);
             h->lastKernel[S_RESIZE] = "k_pyr_cols";
             pollute(st);
-            const size_t slot = cs->blurLevels ? 4 + (cs - g.colSetsBlur.data()) : (cs - g.colSets.data());
+            const size_t slot = cs - g.colSets.data();
             launchPyrCols(st, d_imgs, stride, frameStride, g.lv[0].w, h->d_cols + h->colsOff[slot], (int)cs->columns.size(), h->d_colLevels, g.nlevels,
-                          h->d_colCoef + h->colCoefOff[slot], cs->coefSlot, h->d_pyr, cs->blurLevels ? h->d_blur : nullptr, cs->blurLevels, cs->ldsBytes, cs->evenBytes,
-                          g.colsPacked && !h->resizeBytewise, h->colsVariant >= 0 ? h->colsVariant : colsShape, f0, Bn);
-            blurInside = cs->blurLevels;
+                          h->d_colCoef + h->colCoefOff[slot], cs->coefSlot, h->d_pyr, cs->ldsBytes, cs->evenBytes,
+                          g.colsPacked && !h->resizeBytewise, colsShape, f0, Bn);
         } else {
             {   // level 0 (bordered copy) and level 1 (resized straight from the caller's image) in one launch
                 Prof p(h, S_LEVEL0, st);
@@ -370,24 +325,14 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
         // blur: throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks), which in
         // unprofiled small batches rides in the FAST launch (back) instead of being a launch of its own
-        h->lastBlurForm = pipe ? 4 : (patchBlur ? 3 : (blurInside ? 2 : (blurRidesWithFast(Bn) ? 1 : 0)));
-        h->blurOwed = !pipe && !patchBlur && !blurInside && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
-        if (pipe) {
-            // (the blur rows are a role of the pipelined launches below)
-        } else if (patchBlur) {
-            // (k_describe blurs per keypoint: no blurred level is written)
-        } else if (blurInside) {
-            if (h->nBlurLanes[2] > 0) {      // the coarse levels the regions do not blur
-                Prof p(h, S_BLUR, st);
-                pollute(st);
-                launchBlur(st, h->d_tiles + h->blurItemOff[2], h->d_laneItem + h->blurLaneOff[2], h->nBlurLanes[2], kBlurBlockRows, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
-            }
-        } else if (!blurRidesWithFast(Bn)) {
+        h->lastBlurForm = patchBlur ? (splitL ? 5 : 3) : (blurRidesWithFast(Bn) ? 1 : 0);
+        h->lastSplitLevel = splitL;
+        h->blurOwed = !patchBlur && blurRidesWithFast(Bn);      // (the back part of this call - or orbx_compute_keypoints_octree later - brings the blur)
+        // the blurred levels are only read by k_describe, the last launch: a big batch blurs on the internal stream, beside k_fast and the
+        // quad-tree (pyramid -> {blur, FAST -> quad-tree} -> description)
+        auto blurLaunch = [&](int v, int blockRows) {
             Prof p(h, S_BLUR, st);
-            const int v = blurVariant(Bn);
             pollute(st);
-            // the blurred levels are only read by k_describe, the last launch: with ORBX_BLUR_ASYNC=1 an unsplit batch blurs on the internal
-            // stream, beside k_fast and the quad-tree (pyramid -> {blur, FAST -> quad-tree} -> description)
             hipStream_t bs = st;
             const int half = f0 ? 1 : 0;
             if (blurSide) {
@@ -395,9 +340,15 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                 (void)hipStreamWaitEvent(h->aux2, h->evPyr[half], 0);
                 bs = h->aux2;
             }
-            launchBlur(bs, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows,
-                       h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
+            launchBlur(bs, h->d_tiles + h->blurItemOff[v], h->d_laneItem + h->blurLaneOff[v], h->nBlurLanes[v], blockRows, h->d_lv, h->d_pyr, h->d_blur, f0, Bn);
             if (blurSide) { (void)hipEventRecord(h->evBlur[half], h->aux2); blurJoin[half] = true; blurF0[half] = f0; blurBn[half] = Bn; }
+        };
+        if (patchBlur) {
+            if (splitL) blurLaunch(2, kBlurBlockRows);      // the coarse levels; levels < splitL: k_describe blurs per keypoint, no blurred level is written
+        } else if (!blurRidesWithFast(Bn)) {
+            // throughput form (32-row blocks) once the grid fills the chip, else the short-chain form (8-row blocks)
+            const int v = blurVariant(Bn);
+            blurLaunch(v, v == 1 ? kBlurBlockRowsSmall : kBlurBlockRows);
         }
     };
     bool injected = false;
@@ -463,13 +414,26 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                          h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
             h->leafDirty = false;
         }
-        for (int i = 0; i < 2; i++)      // every blur still on the side stream that covers frames of this part
-            if (blurJoin[i] && blurF0[i] < f0 + Bn && f0 < blurF0[i] + blurBn[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0);
+        auto joinBlur = [&]() {
+            for (int i = 0; i < 2; i++)      // every blur still on the side stream that covers frames of this part
+                if (blurJoin[i] && blurF0[i] < f0 + Bn && f0 < blurF0[i] + blurBn[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0);
+        };
         {
             Prof p(h, S_DESCRIBE, st);
-            pollute(st);
-            launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
-                           h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, patchBlur, f0, Bn);
+            auto describe = [&](bool pb, int l0, int l1) {      // the keypoints of levels [l0, l1): their slots are [selOff(l0), selOff(l1))
+                pollute(st);
+                launchDescribe(st, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount,
+                               h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, pb, l0, l1,
+                               g.lv[l0].selOff, l1 < g.nlevels ? g.lv[l1].selOff : g.selPerFrame, f0, Bn);
+            };
+            if (splitL) {
+                describe(true, 0, splitL);      // (needs no blurred level: in front of the join)
+                joinBlur();
+                describe(false, splitL, g.nlevels);
+            } else {
+                joinBlur();
+                describe(patchBlur, 0, g.nlevels);
+            }
         }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) { backFast(st, f0, Bn); backTail(st, f0, Bn); };
@@ -487,29 +451,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // whole-batch pyramid would leave the blur to the FIRST half's FAST launch only — found by the batch-shape fuzz)
     const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 3 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
                          !h->profiling && B >= 2 && bigBatch && doFront && doBack && !blurRidesWithFast(B);
-    if (pipe) {
-        front(st, 0, B);      // the pyramid of the whole batch (k_pyr_cols; the blur is a role of the steps)
-        const int Bc = h->pipeChunk, C = (B + Bc - 1) / Bc;
-        const size_t ldsBytes = pipeLdsBytes(h->octM, h->octP, h->octR, h->octXT);
-        PipeArgs a{};
-        a.lv = h->d_lv; a.nlevels = g.nlevels; a.pyr = h->d_pyr; a.blur = h->d_blur;
-        a.cells = h->d_cells; a.nCells = (int)g.cells.size(); a.iniTh = h->iniTh; a.minTh = h->minTh; a.candSeg = h->d_candSeg; a.cellCount = h->d_cellCount;
-        a.blurItems = h->d_tiles + h->blurItemOff[0]; a.laneItem = h->d_laneItem + h->blurLaneOff[0]; a.nBlurLanes = h->nBlurLanes[0];
-        a.cellOff = h->d_cellOff; a.candPos = h->d_candPos; a.candCount = h->d_candCount; a.nodeOf = h->d_nodeOf; a.sel = h->d_sel; a.selPerFrame = g.selPerFrame;
-        a.levelCount = h->d_levelCount; a.levelLap = h->d_levelLap; a.lapArea = h->d_lap; a.M = h->octM; a.P = h->octP; a.R = h->octR; a.XT = h->octXT;
-        a.outK = d_kps; a.outD = d_desc; a.capacity = capacity; a.nOut = d_nOut; a.monoOut = d_monoOut; a.outLevelK = d_levelK; a.outLevelCounts = d_levelCounts;
-        auto chunkOf = [&](int c, int& f0, int& n) { f0 = c * Bc; n = c >= 0 && c < C ? std::min(Bc, B - f0) : 0; if (n == 0) f0 = 0; };
-        for (int t = 0; t < C + 2; t++) {
-            chunkOf(t, a.fF0, a.fFn);
-            a.bF0 = a.fF0; a.bFn = a.fFn;
-            chunkOf(t - 1, a.oF0, a.oFn);
-            chunkOf(t - 2, a.dF0, a.dFn);
-            const int mask = (a.fFn ? (1 << kPipeF) | (1 << kPipeB) : 0) | (a.oFn ? 1 << kPipeO : 0) | (a.dFn ? 1 << kPipeD : 0);
-            a.roles = h->d_roles + h->roleOff[mask];
-            pollute(st);
-            launchPipe(st, a, h->roleCount[mask], std::max(a.fFn, std::max(a.oFn, a.dFn)), ldsBytes);
-        }
-    } else if (stagger) {
+    if (stagger) {
         struct Join {
             orbx_handle* h; hipStream_t st; bool armed = false;
             ~Join() { if (armed) { (void)hipEventRecord(h->evJoin, h->aux); (void)hipStreamWaitEvent(st, h->evJoin, 0); } }
@@ -666,7 +608,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
         h->policy += std::string(h->policy.empty() ? "" : " ") + (name + 5) + "=" + std::to_string(v) + (e ? "(env)" : "");
         return v;
     };
-    h->blurInLevels = std::max(1, std::min(envInt("ORBX_BLUR_IN_LEVELS", 5), (int)kMaxLevels));
     std::string why = makeFrameGeom(h->tabs, max_height, max_width, h->maxGeom);
     if (!why.empty()) { h->err = "orbx_create: " + why; return bail(why.find("small") != std::string::npos ? ORBX_ERR_IMAGE_TOO_SMALL : ORBX_ERR_UNSUPPORTED); }
     layoutArenas(h->maxGeom, max_batch);
@@ -750,11 +691,11 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->pyrCols = envInt("ORBX_PYR_COLS", -1);
     h->colPx = envInt("ORBX_PYR_COL_PX", 0);
     h->fastWide = envInt("ORBX_FAST_WIDE", -1);
-    h->colsVariant = envInt("ORBX_PYR_COLS_VARIANT", -1);
-    h->blurInCols = envInt("ORBX_BLUR_IN_COLS", 0);
     h->patchBlur = envInt("ORBX_PATCH_BLUR", -1);
+    h->blurSplit = envInt("ORBX_BLUR_SPLIT", -1);
+    h->colsShape = g_aids.colsShape == 1 || g_aids.colsShape == 4 || g_aids.colsShape == 6 ? g_aids.colsShape : -1;
     h->colsCap = 0;
-    for (int px : kColPx) h->colsCap += 2 * (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);      // (every cut with and without the blur's halo)
+    for (int px : kColPx) h->colsCap += (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);
     h->colCoefCap = (h->colsCap + h->colsCap / 8 + 16) * (size_t)kChainCoefMax * 5 / 8;      // (a region's list is 0.4 - 0.8 of the kernel's limit; a geometry past this keeps the tile forms)
     h->colsCap = roomy(h->colsCap);
     CREATE_ALLOC(h->d_colCoef, sizeof(ResizeX) * h->colCoefCap);
@@ -774,8 +715,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = envInt("ORBX_SPLIT", 1);
-    h->pipeMode = envInt("ORBX_PIPE", 0);
-    h->pipeChunk = std::max(1, envInt("ORBX_PIPE_CHUNK", 128));
     h->fuseSmall = envInt("ORBX_FUSE_SMALL", 1) != 0;
     {
         const char* e = getenv("ORBX_SPLIT_MIN_MPX");
@@ -787,8 +726,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->policy += std::string(" RESIZE_BYTEWISE=") + (h->resizeBytewise ? "1(env)" : "0") + " OCT_ROOMY=" + (h->octRoomyForced ? "1(env)" : "0");
     h->octThreadsForced = envInt("ORBX_OCT_THREADS", 0);   // tuning switch: 256, 512 or 1024
     if (g_aids.ldsPollute >= 0) h->ldsPollute = g_aids.ldsPollute & 255;
-    if (poison >= 0 || h->ldsPollute >= 0 || h->testFailAfterFast)
-        h->policy += " test_aids=poison:" + std::to_string(poison) + ",lds_pollute:" + std::to_string(h->ldsPollute) + ",fail_after_fast:" + std::to_string((int)h->testFailAfterFast);
+    if (poison >= 0 || h->ldsPollute >= 0 || h->testFailAfterFast || h->colsShape > 0)
+        h->policy += " test_aids=poison:" + std::to_string(poison) + ",lds_pollute:" + std::to_string(h->ldsPollute) + ",fail_after_fast:" + std::to_string((int)h->testFailAfterFast) +
+                     ",pyr_cols_shape:" + std::to_string(h->colsShape);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;

@@ -18,6 +18,7 @@ int orbx_debug_set_option(const char* name, int value) {
     if (n == "poison") g_aids.poison = value;
     else if (n == "lds_pollute") g_aids.ldsPollute = value;
     else if (n == "fail_after_fast") g_aids.failAfterFast = value;
+    else if (n == "pyr_cols_shape") g_aids.colsShape = value;
     else return ORBX_ERR_BAD_ARGUMENT;
     return ORBX_OK;
 }
@@ -112,7 +113,8 @@ int orbx_debug_get_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, p
     HIP_TRY(h, hipSetDevice(h->device));
     const LevelGeom& L = h->geom.lv[level];
     if (dst_stride < L.w) return fail(h, ORBX_ERR_BAD_ARGUMENT, "dst_stride too small");
-    if (h->lastBlurForm == 3) return fail(h, ORBX_ERR_UNSUPPORTED, "the last call blurred per keypoint inside k_describe: no blurred level exists (ORBX_PATCH_BLUR=0 keeps k_blur)");
+    if (h->lastBlurForm == 3 || (h->lastBlurForm == 5 && level < h->lastSplitLevel))
+        return fail(h, ORBX_ERR_UNSUPPORTED, "the last call blurred this level per keypoint inside k_describe: no blurred level exists (ORBX_PATCH_BLUR=0 keeps k_blur)");
     HIP_TRY(h, hipMemcpy2DAsync(dst, dst_stride, h->d_blur + L.blurOff + (long long)frame * L.blurFrameBytes, L.blurStride, L.w,
                                 L.h, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -113,25 +113,6 @@ __device__ __forceinline__ unsigned leafTableEntry(const LeafTables& lt, int f, 
 }
 #endif
 
-// ---- the pipelined launch (k_pipe.hip): one launch per pipeline step, its workgroups dealt four roles by a host-made table ----
-enum { kPipeF = 0, kPipeB = 1, kPipeO = 2, kPipeD = 3 };      // FAST cells / blur rows of chunk t, quad-tree levels of chunk t - 1, keypoints of chunk t - 2
-struct PipeRole { unsigned short role, index; };               // one workgroup of a frame's share of the launch: which body, which of its items
-#ifdef __HIPCC__      // (the argument block names HIP vector types: the host-only checkers under tests/cpp include this header with g++)
-struct PipeArgs {
-    const PipeRole* roles;               // [gridDim.y]: the interleaved deal (orbx_api.cpp: pipeRoleTable)
-    const LevelGeom* lv; int nlevels;
-    const uint8_t* pyr; uint8_t* blur;
-    // F: frames [fF0, fF0 + fFn)
-    const CellDesc* cells; int nCells, iniTh, minTh; unsigned* candSeg; unsigned* cellCount; int fF0, fFn;
-    // B: frames [bF0, bF0 + bFn)
-    const BlurItem* blurItems; const unsigned short* laneItem; int nBlurLanes, bF0, bFn;
-    // O: frames [oF0, oF0 + oFn)
-    int* cellOff; unsigned* candPos; unsigned* candCount; unsigned short* nodeOf; uint2* sel; int selPerFrame;
-    int* levelCount; int* levelLap; const int* lapArea; int M, P, R, XT, oF0, oFn;
-    // D: frames [dF0, dF0 + dFn)
-    Keypoint* outK; uint8_t* outD; int capacity; int* nOut; int* monoOut; Keypoint* outLevelK; int* outLevelCounts; int dF0, dFn;
-};
-#endif
 
 constexpr int kBlurBlockRows = 32;    // output rows one lane of k_blur walks (plus a 6-row halo)
 #ifndef ORBX_BLUR_SMALL_ROWS
@@ -192,8 +173,6 @@ struct ColLevels {      // what the kernel needs of the level tables, by value (
     int nlevels, pad;
     int w[kMaxLevels], h[kMaxLevels], pyrStride[kMaxLevels], rxOff[kMaxLevels], ryOff[kMaxLevels];
     long long pyrOff[kMaxLevels], pyrFrameBytes[kMaxLevels];
-    int blurStride[kMaxLevels];
-    long long blurOff[kMaxLevels], blurFrameBytes[kMaxLevels];      // the blurred levels (k_pyr_cols<.., BLUR> writes them too)
 };
 
 #ifdef __HIPCC__

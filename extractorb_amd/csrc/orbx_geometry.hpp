@@ -121,7 +121,6 @@ struct FrameGeom {
     // more frames: large regions, less overlap)
     struct ColumnSet {
         int px = 0, RX = 0, RY = 0;
-        int blurLevels = 0;                  // > 0: the regions also hold what the 7x7 blur of their owned pixels of levels 0 .. blurLevels-1 reads (k_pyr_cols<.., BLUR>)
         std::vector<PyrColumn> columns;
         bool fit = false;
         int ldsBytes = 0, evenBytes = 0;
@@ -129,7 +128,6 @@ struct FrameGeom {
         std::vector<ResizeX> coef;           // columns.size() * coefSlot
     };
     std::vector<ColumnSet> colSets;          // finest first
-    std::vector<ColumnSet> colSetsBlur;      // the same cuts with the blur's halo: the pyramid launch also writes the blurred levels (ORBextractor.cc:1126-1127)
     bool colsPacked = false;
 };
 constexpr int kColPx[] = {40, 56, 80, 112};
@@ -141,8 +139,7 @@ constexpr int kColEdgeNum = ORBX_COL_EDGE_NUM, kColEdgeDen = ORBX_COL_EDGE_DEN; 
 
 // Returns an empty string on success, else the reason the geometry is unsupported.
 // colPx: side (level-0 pixels) of the regions of the region-major pyramid (0: the sizes of kColPx)
-// blurInLevels: the cuts of colSetsBlur carry the blur's halo for that many of the finest levels
-inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, int colPx = 0, int blurInLevels = kMaxLevels) {
+inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, FrameGeom& g, int colPx = 0) {
     g = FrameGeom();
     g.rows = rows; g.cols = cols; g.nlevels = t.nlevels;
     for (int l = 0; l < t.nlevels; l++) {
@@ -300,18 +297,8 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
     if (t.nlevels >= 2) {
         auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
         const int top = t.nlevels - 1;
-        // blur: a region also blurs the pixels it owns of every level (7x7, REFLECT_101 of the level itself: the reference blurs a border-less
-        // clone, :1126-1127) out of the rectangle it holds.  A lane of the blur reads the three aligned dwords x0 - 4 .. x0 + 7 of rows y - 3 .. y + 3
-        // of its four columns, so the rectangle grows by a dword left and right and three rows up and down; where that leaves the level it holds
-        // VIRTUAL columns: column v < 0 is column -v, column v >= w is column 2 (w - 1) - v — the resize step derives them like any other column
-        // (a quad record whose taps are the mirrored column's), the level-0 load mirrors them, so the blur never special-cases an edge.  Rows are
-        // mirrored by index when they are read.
-        // The halo compounds down the chain (level l's rectangle must hold the taps of level l + 1's, halo included: ~ x1.2 per level), so it is
-        // carried for the finest `nblur` levels only - most of the pixels, little of the compounding; k_blur keeps the coarse ones.
-        auto buildCols = [&](const int px, const int nblur, const bool evenCut) {
+        auto buildCols = [&](const int px, const bool evenCut) {
         FrameGeom::ColumnSet cs;
-        cs.blurLevels = std::min(nblur, t.nlevels);
-        const bool anyBlur = nblur > 0;
         const int RX = std::max(1, (cols + px / 2) / px), RY = std::max(1, (rows + px / 2) / px);
         cs.px = px; cs.RX = RX; cs.RY = RY;
         const int edgeNum = px <= 56 && !evenCut ? kColEdgeNum : 1, edgeDen = px <= 56 && !evenCut ? kColEdgeDen : 1;
@@ -362,15 +349,6 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                         }
                         for (int y = y0; y <= y1; y++) { ny0 = std::min(ny0, (int)std::min(Y[y].sx0, Y[y].sx1)); ny1 = std::max(ny1, (int)std::max(Y[y].sx0, Y[y].sx1)); }
                     }
-                    const bool blur = l < nblur;
-                    if (blur) {      // what the blur of the owned pixels reads: column groups [g0, g1), rows [by0, by1) of the border-less level
-                        const int g0 = std::max(dwA - kPadL / 4, 0), g1 = std::min(dwB - kPadL / 4, (L.w + 3) / 4);
-                        const int by0 = std::max(rA - kEdge, 0), by1 = std::min(rB - kEdge, L.h);
-                        if (g1 > g0 && by1 > by0) {
-                            nx0 = std::min(nx0, 4 * g0 - 4); nx1 = std::max(nx1, 4 * g1 + 3);
-                            for (int y = by0 - 3; y < by1 + 3; y++) { const int v = refl(y, L.h); ny0 = std::min(ny0, v); ny1 = std::max(ny1, v); }
-                        }
-                    }
                     if (nx1 < nx0 || ny1 < ny0) { nx0 = nx1 = 0; ny0 = ny1 = 0; }      // (a region that owns nothing of this level and feeds nothing)
                     nx0 &= ~3;                                // aligned dwords of the owned bytes are aligned dwords of the LDS rectangle
                     int w = nx1 - nx0 + 1;
@@ -381,7 +359,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                     if (w > kChainMaxW || (l == 0 && bytes > kChainMaxW * kChainMaxH0)) fits = false;
                     if (l & 1) maxOdd = std::max(maxOdd, bytes); else maxEven = std::max(maxEven, bytes);
                     if (l >= 1) coefs += 6 * ((w + 3) >> 2) + 2 * hh;      // 8-byte units: quad records (six each), row records (two each)
-                    x0 = nx0; x1 = anyBlur ? nx0 + w - 1 : std::min(nx0 + w - 1, L.w - 1); y0 = ny0; y1 = ny1;      // (blur: virtual columns are derived too)
+                    x0 = nx0; x1 = std::min(nx0 + w - 1, L.w - 1); y0 = ny0; y1 = ny1;
                     if (l == 0) x1 = nx1;
                 }
                 if (coefs > kChainCoefMax) fits = false;
@@ -401,7 +379,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
                         QuadRec qr{};
                         int c0[4], c1[4], lo = 1 << 30;
                         for (int k = 0; k < 4; k++) {
-                            const ResizeX& cx = g.rx[l][refl(r.x0 + std::min(x4 + k, r.w - 1), g.lv[l].w)];      // (a virtual column takes the taps of the column it mirrors)
+                            const ResizeX& cx = g.rx[l][refl(r.x0 + std::min(x4 + k, r.w - 1), g.lv[l].w)];
                             c0[k] = cx.sx0 - rs.x0; c1[k] = cx.sx1 - rs.x0;
                             qr.wt[k] = (unsigned)(unsigned short)cx.a0 | ((unsigned)(unsigned short)cx.a1 << 16);
                             lo = std::min(lo, std::min(c0[k], c1[k]));
@@ -429,13 +407,13 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         };
         // (a fine cut whose narrower outer regions make an inner region's records outgrow the kernel's staging - many levels at a small scale
         // factor - is rebuilt evenly)
-        auto buildFit = [&](const int px, const int nblur) {
-            FrameGeom::ColumnSet cs = buildCols(px, nblur, false);
-            if (!cs.fit && px <= 56 && kColEdgeNum != kColEdgeDen) cs = buildCols(px, nblur, true);
+        auto buildFit = [&](const int px) {
+            FrameGeom::ColumnSet cs = buildCols(px, false);
+            if (!cs.fit && px <= 56 && kColEdgeNum != kColEdgeDen) cs = buildCols(px, true);
             return cs;
         };
-        if (colPx > 0) { g.colSets.push_back(buildFit(colPx, 0)); g.colSetsBlur.push_back(buildFit(colPx, std::max(blurInLevels, 1))); }
-        else for (int px : kColPx) { g.colSets.push_back(buildFit(px, 0)); g.colSetsBlur.push_back(buildFit(px, std::max(blurInLevels, 1))); }
+        if (colPx > 0) g.colSets.push_back(buildFit(colPx));
+        else for (int px : kColPx) g.colSets.push_back(buildFit(px));
         bool packed = true;      // the packed horizontal pass: the 8 taps of any four adjacent columns (region columns start anywhere) within 8 source bytes
         for (int l = 1; l <= top && packed; l++) {
             const std::vector<ResizeX>& X = g.rx[l];

@@ -27,7 +27,7 @@ struct BowMatchParams { float nnRatio; int thLow, checkOrientation, capacity, kf
 size_t bowMatchLdsBytes(int capacity, bool stageDesc);
 void launchSearchBow(hipStream_t, const uint32_t*, const uint32_t*, const int*, const uint8_t*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const BowMatchParams&, int*, int*, int);
 void launchLdsPollute(hipStream_t, int, int, unsigned*);
-void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, uint8_t*, int, int, int, bool, int, int, int);
+void launchPyrCols(hipStream_t, const uint8_t*, long long, long long, int, const PyrColumn*, int, const ColLevels*, int, const ResizeX*, int, uint8_t*, int, int, bool, int, int, int);
 void launchBlur(hipStream_t, const BlurItem*, const unsigned short*, int, int, const LevelGeom*, const uint8_t*, uint8_t*, int, int);
 void launchFast(hipStream_t, const CellDesc*, int, const LevelGeom*, int, const uint8_t*, int, int, unsigned*, unsigned*,
                 int, int, int, int, const BlurItem*, const unsigned short*, int, uint8_t*, LeafTables, bool);
@@ -36,7 +36,7 @@ size_t octreeLdsBytes(int M, int P, int R, int XT);
 void launchOctree(hipStream_t, const LevelGeom*, int, const CellDesc*, int, const unsigned*, const unsigned*, int*, unsigned*,
                   unsigned*, unsigned short*, uint2*, int, int*, int*, const int*, int, int, int, int, const int*, bool, int, int, uint8_t*, LeafTables);
 void launchDescribe(hipStream_t, const LevelGeom*, int, const uint8_t*, const uint8_t*, const uint2*, int, const int*,
-                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, bool, int, int);
+                    const int*, Keypoint*, uint8_t*, int, int*, int*, Keypoint*, int*, bool, int, int, int, int, int, int);
 bool checkUmax(const int* umax16);
 hipError_t runPackedSelfTest(hipStream_t, unsigned*, unsigned*);
 struct StereoParams {
@@ -84,9 +84,6 @@ void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const i
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 void launchClockProbe(hipStream_t, unsigned long long*, int, int, unsigned);
-size_t pipeLdsBytes(int M, int P, int R, int XT);
-bool pipeCanRun(int maxRoiW, int maxRoiH);
-void launchPipe(hipStream_t, const PipeArgs&, int itemsPerFrame, int frames, size_t ldsBytes);
 }  // namespace orbx
 
 using namespace orbx;
@@ -101,6 +98,7 @@ static inline double nowSec() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts)
 struct TestAids {
     int poison = -1;          // "poison": byte every device allocation of orbx_create is filled with (no kernel may depend on what hipMalloc returns)
     int ldsPollute = -1;      // "lds_pollute": byte every CU's LDS is filled with in front of every kernel
+    int colsShape = -1;       // "pyr_cols_shape": pins the workgroup shape of k_pyr_cols (1, 4, 6) so that the parity tests reach every one
     int failAfterFast = 0;    // "fail_after_fast": the next handle's first call with leaf tables returns between k_fast and k_octree (one shot)
 };
 extern TestAids g_aids;
@@ -139,25 +137,25 @@ struct orbx_handle {
     QuadRec* d_xq = nullptr;            // per level: the tile resize's dword-column records (FrameGeom::xq)
     size_t xqCap = 0, xqOff[kMaxLevels] = {};
     PyrColumn* d_cols = nullptr;        // regions of the region-major pyramid (k_pyr_cols)
-    size_t colsCap = 0, colsOff[8] = {};   // first column of each cut of the geometry in d_cols
+    size_t colsCap = 0, colsOff[4] = {};   // first column of each cut of the geometry in d_cols
     ResizeX* d_colCoef = nullptr;       // the regions' coefficient lists, cut after cut
-    size_t colCoefCap = 0, colCoefOff[8] = {};
+    size_t colCoefCap = 0, colCoefOff[4] = {};
     ColLevels* d_colLevels = nullptr;
     int pyrCols = -1;                   // ORBX_PYR_COLS: 1 = the region-major pyramid for every batch it fits, 0 = never, default: the smallest batches
     int colPx = 0;                      // ORBX_PYR_COL_PX: side of its regions in level-0 pixels (0: default)
     int fastWide = -1;                  // ORBX_FAST_WIDE: 1 = a workgroup per FAST cell (k_fast_wide) whatever the batch, 0 = never, default: while a call holds few cells
     int patchBlur = -1;                 // ORBX_PATCH_BLUR: 1 = k_describe blurs each keypoint's patch itself (no blurred levels), 0 = never, default: by features per pixel (enqueueBatch)
-    int blurInCols = 0;                 // ORBX_BLUR_IN_COLS=1: the region-major pyramid also blurs (k_pyr_cols<.., BLUR>) whenever it is taken (opt-in: slower)
-    int colsVariant = -1;               // ORBX_PYR_COLS_VARIANT: workgroup shape of k_pyr_cols (launchPyrCols; default: by the grid size)
+    int blurSplit = -1;                 // ORBX_BLUR_SPLIT=L: where the blur is per keypoint, only levels < L are (k_describe<PB>); levels >= L are blurred by k_blur and
+                                        // described from the blurred level (the patches of the coarse levels hold more pixels than the levels); 0 = no split; default: enqueueBatch
+    int colsShape = -1;                 // test aid "pyr_cols_shape": workgroup shape of k_pyr_cols (launchPyrCols: 1, 4 or 6; default: by the grid size)
     TileFoot* d_foot = nullptr;
     size_t footCap = 0, footOff[kMaxLevels] = {};
     BlurItem* d_tiles = nullptr;   // row-block items of the blur kernel: [0] blocks of kBlurBlockRows rows, [1] of kBlurBlockRowsSmall rows
     unsigned short* d_laneItem = nullptr;   // item of every lane of the blur grid, both tables
     size_t laneCap = 0;
-    int nBlurLanes[3] = {0, 0, 0};     // [0]: 32-row blocks of every level, [1]: 8-row blocks (small batches), [2]: 32-row blocks of the levels k_pyr_cols<.., BLUR> leaves (>= blurInLevels)
+    int nBlurLanes[3] = {0, 0, 0};     // [0]: 32-row blocks of every level, [1]: 8-row blocks (small batches), [2]: 32-row blocks of the levels >= splitLevel (the blur split by level)
     size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
-    int blurInLevels = 5;              // ORBX_BLUR_IN_LEVELS: the finest levels the region-major pyramid blurs itself when it carries the blur (the halo compounds
-                                       // down the chain: 640x480, 112-px regions, derived pixels +3 % for 3 levels = 70 % of the blur's pixels, +9 % for 5 = 89 %, +30 % for all 8)
+    int splitLevel = 0;                // the level table [2] starts at (installGeometry; 0: no such table)
     size_t rxOff[kMaxLevels] = {}, ryOff[kMaxLevels] = {};
     size_t octArenaSlice = 0;      // > 0: node arrays of the quad-tree live in d_octArena (too large for LDS)
     uint8_t* d_octArena = nullptr;
@@ -192,7 +190,7 @@ struct orbx_handle {
     bool blurOwed = false;             // the pyramid part of a call left the blur to the FAST launch that follows
     bool testFailAfterFast = false;    // test aid "fail_after_fast" (orbx_debug_set_option)
     bool leafDirty = false;            // k_fast has filled the leaf tables and k_octree has not been enqueued to clear them
-    int lastPyrForm = -1, lastPyrCut = 0, lastBlurForm = -1;      // orbx_debug_last_forms
+    int lastPyrForm = -1, lastPyrCut = 0, lastBlurForm = -1, lastSplitLevel = 0;      // orbx_debug_last_forms
     std::string lastKernel[ORBX_NUM_KERNELS];                      // the kernel (rocprofv3's name, without template arguments) that last ran in each profile slot
     int lastB = 0;
     int lastHostB = 0;           // frames whose results the handle itself holds (the result slab: h->dev / h->host): set by the host-buffer path only
@@ -224,12 +222,6 @@ struct orbx_handle {
     int *d_rowOff = nullptr, *d_sadDist = nullptr, *d_nMatched = nullptr;
     unsigned short* d_rowList = nullptr;
     float *d_uRight = nullptr, *d_depth = nullptr;
-    // the pipelined launch (k_pipe.hip; enqueueBatch): role tables of the current geometry, one per set of roles a pipeline step can hold
-    PipeRole* d_roles = nullptr;
-    size_t rolesCap = 0, roleOff[16] = {};
-    int roleCount[16] = {};
-    int pipeMode = 0;                  // ORBX_PIPE=1: every full call of frames up to half a megapixel runs pipelined (opt-in: measured slower)
-    int pipeChunk = 128;               // ORBX_PIPE_CHUNK: frames per pipeline step
     // clock probe (orbx_debug_clock_probe: bench.py's sustained-load figure), allocated on first use
     hipStream_t probeStream = nullptr;
     unsigned long long* d_clock = nullptr;

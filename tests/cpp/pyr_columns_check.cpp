@@ -5,16 +5,12 @@
 //     owned bytes of each level with the clamp / REFLECT_101 mapping of copyMakeBorder (:1213-1215) — assembles exactly the pyramid that a
 //     plain level-by-level resize of whole levels with the same tables gives, and never reads outside a rectangle it holds;
 //  3. the limits the kernel relies on (x0 % 4 == 0, widths, coefficient count, LDS bytes);
-//  4. for the cuts that carry the blur's halo (colSetsBlur: k_pyr_cols<.., BLUR>): rectangles may hold VIRTUAL columns (v < 0 is column -v,
-//     v >= w is column 2 (w - 1) - v), loaded / derived like any other; the replay blurs every region's owned pixels out of its rectangle
-//     exactly as the kernel reads it (three aligned dwords x0 - 4 .. x0 + 7, rows mirrored by index) and the assembled blurred levels equal a
-//     plain 7x7 blur (taps 18 34 49 55 49 34 18, REFLECT_101, ORBextractor.cc:1126-1127) of the whole levels, every pixel written exactly once.
-//  5. the WRITING role's thread dealing as the kernel computes it (k_pyramid.hip: doLevel) - the interior dword columns dealt dword by dword
+//  4. the WRITING role's thread dealing as the kernel computes it (k_pyramid.hip: doLevel) - the interior dword columns dealt dword by dword
 //     or walked column-wise in three runs (top mirror, interior, bottom mirror), the frame's columns byte by byte, all through float
 //     reciprocals - replayed for every writer count the launch shapes use (256 / 512 / 768 / 1024 threads): every owned (row, dword) is
 //     written by exactly one thread, from the source row copyMakeBorder's REFLECT_101 names (round 5; DESIGN.md 4j: the one miscompare of
 //     a soak was a bordered level 0 of 1014 x 432, w % 4 == 2, whose cause was never found - this closes the host-side candidates);
-//  6. a hash of every table the kernel reads (printed; tests/test_pyramid_columns.py runs the checker under two MALLOC_PERTURB_ values and
+//  5. a hash of every table the kernel reads (printed; tests/test_pyramid_columns.py runs the checker under two MALLOC_PERTURB_ values and
 //     a dirtied heap and expects the same hash: no uninitialised byte reaches the tables).
 // usage: pyr_columns_check <cols> <rows> <nlevels> <scaleFactor>      prints "ok ..." and exits 0, or the first violation and exits 1
 #include <cstdio>
@@ -32,17 +28,6 @@ static int refl(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) 
 static unsigned resizePx(int p00, int p01, int p10, int p11, const ResizeX& cx, const ResizeX& cy) {
     const int h0 = p00 * cx.a0 + p01 * cx.a1, h1 = p10 * cx.a0 + p11 * cx.a1;
     return (unsigned)((((cy.a0 * (h0 >> 4)) >> 16) + ((cy.a1 * (h1 >> 4)) >> 16) + 2) >> 2);
-}
-static uint8_t blurPx(const uint8_t* img, int w, int h, int x, int y) {
-    static const int K[7] = {18, 34, 49, 55, 49, 34, 18};
-    unsigned acc = 0;
-    for (int r = -3; r <= 3; r++) {
-        unsigned rs = 0;
-        for (int c = -3; c <= 3; c++) rs += K[c + 3] * img[(size_t)refl(y + r, h) * w + refl(x + c, w)];
-        acc += K[r + 3] * rs;
-    }
-    const unsigned v = (acc + 32768) >> 16;
-    return (uint8_t)(v > 255 ? 255 : v);
 }
 #define FAIL(...) do { printf(__VA_ARGS__); printf("\n"); return 1; } while (0)
 
@@ -115,15 +100,13 @@ int main(int argc, char** argv) {
     const float sf = (float)atof(argv[4]);
     ScaleTables t = makeScaleTables(1000, sf, nlevels);
     FrameGeom g;
-    const int blurIn = argc > 5 ? atoi(argv[5]) : 5;
-    const std::string why = makeFrameGeom(t, rows, cols, g, 0, blurIn);
+    const std::string why = makeFrameGeom(t, rows, cols, g, 0);
     if (!why.empty()) { printf("rejected: %s\n", why.c_str()); return 0; }
     layoutArenas(g, 1);
     hashBytes(g.lv, sizeof(LevelGeom) * g.nlevels);
     hashVec(g.cells);
     for (int l = 0; l < nlevels; l++) { hashVec(g.rx[l]); hashVec(g.ry[l]); hashVec(g.foot[l]); hashVec(g.xq[l]); }
-    for (const std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
-        for (const FrameGeom::ColumnSet& cs : *sets) { hashVec(cs.columns); hashVec(cs.coef); }
+    for (const FrameGeom::ColumnSet& cs : g.colSets) { hashVec(cs.columns); hashVec(cs.coef); }
     // the image and the whole levels, resized level by level
     std::vector<std::vector<uint8_t>> lvl(nlevels);
     lvl[0].resize((size_t)cols * rows);
@@ -164,24 +147,17 @@ int main(int argc, char** argv) {
             }
     }
     int checked = 0;
-    for (const std::vector<FrameGeom::ColumnSet>* sets : {&g.colSets, &g.colSetsBlur})
-    for (const FrameGeom::ColumnSet& cs : *sets) {
-        if ((cs.blurLevels > 0) != (sets == &g.colSetsBlur)) FAIL("px %d: blur flag", cs.px);
+    for (const FrameGeom::ColumnSet& cs : g.colSets) {
         if (!cs.fit || !g.colsPacked) continue;      // (the kernel's steps are the packed ones: without packed taps the host never takes this form)
         if ((int)cs.columns.size() != cs.RX * cs.RY) FAIL("px %d: %zu regions for a %d x %d cut", cs.px, cs.columns.size(), cs.RX, cs.RY);
         if (cs.ldsBytes > 64 * 1024) FAIL("px %d: %d bytes of LDS", cs.px, cs.ldsBytes);
         std::vector<std::vector<int>> written(nlevels);      // per level: how often each (row, dword) was written
         std::vector<std::vector<uint8_t>> out(nlevels);
         std::vector<int> nd(nlevels);
-        std::vector<std::vector<int>> bwritten(nlevels);     // per level: how often each blurred (row, column group) was written
-        std::vector<std::vector<uint8_t>> bout(nlevels);
         for (int l = 0; l < nlevels; l++) {
             nd[l] = (kPadL - kEdge + g.lv[l].w + 2 * kEdge + 3) / 4;
             written[l].assign((size_t)nd[l] * g.lv[l].pyrRows, 0);
             out[l].assign((size_t)nd[l] * 4 * g.lv[l].pyrRows, 0);
-            const int ng = (g.lv[l].w + 3) / 4;
-            bwritten[l].assign((size_t)ng * g.lv[l].h, 0);
-            bout[l].assign((size_t)ng * 4 * g.lv[l].h, 0);
         }
         for (size_t ci = 0; ci < cs.columns.size(); ci++) {
             const PyrColumn& c = cs.columns[ci];
@@ -205,7 +181,7 @@ int main(int argc, char** argv) {
                 const ChainRegion r = c.region[l];
                 const int w = g.lv[l].w, h = g.lv[l].h;
                 if (r.x0 & 3) FAIL("px %d region %zu level %d: x0 %d not a multiple of 4", cs.px, ci, l, r.x0);
-                if (r.w < 1 || r.h < 1 || r.w > kChainMaxW || (r.x0 < 0 && !(cs.blurLevels > l && r.x0 == -4)) || r.y0 < 0 || r.y0 + r.h > h || (cs.blurLevels > l && r.x0 + r.w > ((w + 3) & ~3) + 4) || (cs.blurLevels <= l && l > 0 && r.x0 + r.w > w)) FAIL("px %d region %zu level %d: rectangle %d,%d %dx%d outside the %dx%d level", cs.px, ci, l, r.x0, r.y0, r.w, r.h, w, h);
+                if (r.w < 1 || r.h < 1 || r.w > kChainMaxW || r.x0 < 0 || r.y0 < 0 || r.y0 + r.h > h || (l > 0 && r.x0 + r.w > w)) FAIL("px %d region %zu level %d: rectangle %d,%d %dx%d outside the %dx%d level", cs.px, ci, l, r.x0, r.y0, r.w, r.h, w, h);
                 const int stride = (r.w + 3) & ~3;
                 if ((l & 1 ? cs.ldsBytes - cs.evenBytes - 32 : cs.evenBytes) < stride * r.h) FAIL("px %d region %zu level %d: %d bytes do not fit its LDS buffer", cs.px, ci, l, stride * r.h);
                 if (l == 0) {
@@ -239,35 +215,6 @@ int main(int argc, char** argv) {
                             out[l][((size_t)row * nd[l] + dw) * 4 + k] = cur[(size_t)(iy - r.y0) * stride + (ix - r.x0)];
                         }
                     }
-                // the blur of the owned pixels out of `cur`, read as the kernel reads it
-                if (l < cs.blurLevels) {
-                    const int g0 = std::max(o.dw0 - kPadL / 4, 0), g1 = std::min(o.dw1 - kPadL / 4, (w + 3) / 4);
-                    const int y0 = std::max(o.r0 - kEdge, 0), y1 = std::min(o.r1 - kEdge, h);
-                    static const int K[7] = {18, 34, 49, 55, 49, 34, 18};
-                    for (int gq = g0; gq < g1; gq++)
-                        for (int y = y0; y < y1; y++) {
-                            bwritten[l][(size_t)y * ((w + 3) / 4) + gq]++;
-                            for (int k = 0; k < 4; k++) {
-                                unsigned acc = 0;
-                                for (int rr = -3; rr <= 3; rr++) {
-                                    const int iy = refl(y + rr, h);
-                                    if (iy < r.y0 || iy >= r.y0 + r.h) FAIL("px %d region %zu level %d: blur row %d outside the held rectangle", cs.px, ci, l, iy);
-                                    unsigned rsum = 0;
-                                    for (int c = -3; c <= 3; c++) {
-                                        const int v = 4 * gq + k + c;      // virtual column, read as is
-                                        if (v < 4 * gq - 4 || v > 4 * gq + 7 || v < r.x0 || v >= r.x0 + r.w) FAIL("px %d region %zu level %d: blur column %d outside the held rectangle", cs.px, ci, l, v);
-                                        rsum += K[c + 3] * cur[(size_t)(iy - r.y0) * stride + (v - r.x0)];
-                                    }
-                                    acc += K[rr + 3] * rsum;
-                                }
-                                const unsigned vv = (acc + 32768) >> 16;
-                                bout[l][((size_t)y * ((w + 3) / 4) + gq) * 4 + k] = (uint8_t)(vv > 255 ? 255 : vv);
-                            }
-                        }
-                    // the three aligned dwords of the outermost groups lie inside the rectangle too (values of columns the sums weight 0 or that feed
-                    // only the padding pixels of a level whose width is no multiple of 4)
-                    if (g1 > g0 && y1 > y0 && (4 * g0 - 4 < r.x0 || 4 * g1 + 3 >= r.x0 + r.w)) FAIL("px %d region %zu level %d: blur dwords outside the held rectangle", cs.px, ci, l);
-                }
                 // the next level's rectangle out of `cur`, with the region's own coefficient list
                 if (l + 1 < nlevels) {
                     const ChainRegion d = c.region[l + 1];
@@ -301,7 +248,7 @@ int main(int argc, char** argv) {
                             const ResizeX gx = g.rx[l + 1][refl(d.x0 + x, g.lv[l + 1].w)], gy = g.ry[l + 1][d.y0 + y];      // (a virtual column is derived with the taps of the column it mirrors)
                             if (cx.sx0 != gx.sx0 || cx.sx1 != gx.sx1 || cx.a0 != gx.a0 || cx.a1 != gx.a1 || cy.sx0 != gy.sx0 || cy.sx1 != gy.sx1 || cy.a0 != gy.a0 || cy.a1 != gy.a1)
                                 FAIL("px %d region %zu level %d: coefficient list differs from the level tables at (%d, %d)", cs.px, ci, l + 1, x, y);
-                            if (cs.blurLevels <= l + 1 && d.x0 + x >= g.lv[l + 1].w) continue;      // (padding columns of an aligned start are never shown)
+                            if (d.x0 + x >= g.lv[l + 1].w) continue;      // (padding columns of an aligned start are never shown)
                             const int xs[2] = {cx.sx0, cx.sx1}, ys[2] = {cy.sx0, cy.sx1};
                             int p[2][2];
                             for (int a = 0; a < 2; a++)
@@ -330,17 +277,6 @@ int main(int argc, char** argv) {
                     }
                 }
         }
-            for (int l = 0; l < cs.blurLevels; l++) {
-                const int w = g.lv[l].w, h = g.lv[l].h, ng = (w + 3) / 4;
-                for (int y = 0; y < h; y++)
-                    for (int gq = 0; gq < ng; gq++) {
-                        if (bwritten[l][(size_t)y * ng + gq] != 1) FAIL("px %d level %d: blurred group (%d, %d) written %d times", cs.px, l, y, gq, bwritten[l][(size_t)y * ng + gq]);
-                        for (int k = 0; k < 4 && 4 * gq + k < w; k++) {
-                            const uint8_t want = blurPx(lvl[l].data(), w, h, 4 * gq + k, y);
-                            if (bout[l][((size_t)y * ng + gq) * 4 + k] != want) FAIL("px %d level %d: blurred pixel (%d, %d) is %d, the whole-level blur has %d", cs.px, l, 4 * gq + k, y, bout[l][((size_t)y * ng + gq) * 4 + k], want);
-                        }
-                    }
-            }
         checked++;
     }
     printf("ok %dx%d %d levels scale %.2f hash %016llx: %d cuts\n", cols, rows, nlevels, sf, g_hash, checked);

@@ -67,7 +67,7 @@ def test_handle_owned_memory_is_only_touched_in_stream_order():
     assert "hipDeviceSynchronize" not in code
     assert "hipMemcpyToSymbol" not in code
     # ... and the kernel files upload nothing outside diagnostic builds (the description's tables are static initialisers)
-    for f in ("k_describe.hip", "k_describe_body.hpp", "k_fast_body.hpp", "k_pipe.hip", "k_octree.hip", "k_pyramid.hip", "k_blur.hip", "k_stereo.hip", "k_match.hip", "k_bow.hip"):
+    for f in ("k_describe.hip", "k_describe_body.hpp", "k_fast_body.hpp", "k_octree.hip", "k_pyramid.hip", "k_blur.hip", "k_stereo.hip", "k_match.hip", "k_bow.hip"):
         text = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "extractorb_amd", "csrc", f)).read())
         text = re.sub(r"#if defined\(ORBX_FAST_CLOCK\).*?#else", "", text, flags=re.S)      # (the stamped diagnostic build of k_fast: tools/fast_clock.py)
         assert "hipMemcpyToSymbol" not in text and not re.findall(r"\bhipMem(?:cpy|set)\s*\(", text), f

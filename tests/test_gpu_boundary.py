@@ -225,6 +225,6 @@ def test_clock_probe_and_policy_string():
     with pytest.raises(X.OrbxError):
         ex.clock_probe(64)
     pol = ex.policy()
-    for key in ("SPLIT=1", "PIPE=0", "PIPE_CHUNK=128", "PATCH_BLUR=-1", "LEAF_FRAMES=128", "ZERO_COPY=1"):
+    for key in ("SPLIT=1", "PATCH_BLUR=-1", "BLUR_SPLIT=-1", "LEAF_FRAMES=128", "ZERO_COPY=1"):
         assert key in pol, pol
     assert "(env)" not in pol and "test_aids" not in pol, pol

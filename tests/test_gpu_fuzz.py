@@ -1,6 +1,6 @@
 """Bounded, seeded randomised parity sweep under -m gpu: tools/fuzz_parity.py's generator (random image sizes, feature counts,
 level counts, scale factors 1.1-2.0, thresholds, lapping areas, content), every stage and the final arrays against the oracle,
-under each kernel-variant switch.  The totals are written to gpurun_out/r05_fuzz_parity.json on the GPU box (copied to
+under each kernel-variant switch.  The totals are written to gpurun_out/r06_fuzz_parity.json on the GPU box (copied to
 profiles/r02_fuzz_parity.md)."""
 import json
 import os
@@ -34,9 +34,11 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            ({"ORBX_LEAF_FRAMES": "0"}, 8, 115), ({"ORBX_LEAF_FRAMES": "0", "ORBX_OCT_THREADS": "512", "ORBX_OCT_ROOMY": "1"}, 8, 103),
            # ... and the leaf tables with poisoned allocations (they must be zero between calls whatever hipMalloc returned)
            ({"aid:poison": "77", "ORBX_OCT_THREADS": "256", "ORBX_OCT_ROOMY": "1"}, 8, 116),
-           # round 4: the region-major pyramid that also blurs (the finest five levels, and all of them), the copy-back form of the one-frame host call
-           ({"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1"}, 8, 124),
-           ({"ORBX_PYR_COLS": "1", "ORBX_PYR_COL_PX": "80", "ORBX_BLUR_IN_COLS": "1", "ORBX_BLUR_IN_LEVELS": "8", "aid:lds_pollute": "99"}, 8, 125),
+           # round 6: the blur per keypoint split by level (k_describe<PB> below the split, k_blur + the plain description from it on), every workgroup
+           # shape of the region-major pyramid pinned in turn; the copy-back form of the one-frame host call
+           ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "3", "aid:pyr_cols_shape": "4"}, 8, 124),
+           ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "1", "ORBX_PYR_COL_PX": "80", "aid:pyr_cols_shape": "6", "aid:lds_pollute": "99"}, 8, 125),
+           ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "5", "aid:pyr_cols_shape": "1", "aid:poison": "119"}, 8, 127),
            ({"ORBX_ZERO_COPY": "0", "aid:poison": "33"}, 8, 126)]
 _totals = []
 
@@ -53,7 +55,7 @@ def test_seeded_fuzz_sweep(env, n, seed, monkeypatch):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        json.dump(_totals, open(os.path.join(out, "r05_fuzz_parity.json"), "w"), indent=1)
+        json.dump(_totals, open(os.path.join(out, "r06_fuzz_parity.json"), "w"), indent=1)
     except OSError:
         pass
 
@@ -67,13 +69,13 @@ def test_seeded_batch_shape_sweep():
 
 
 @pytest.mark.parametrize("env", [{"ORBX_SPLIT_MIN_MPX": "0"}, {"ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3"},
-                                 {"ORBX_PYR_COLS": "1", "ORBX_BLUR_IN_COLS": "1", "ORBX_SPLIT_MIN_MPX": "0"},
-                                 # round 5: the pipelined launches (k_pipe) for every batch shape the form admits, chunks of 5 and of 32 frames, the first with polluted LDS
-                                 {"ORBX_PIPE": "1", "ORBX_PIPE_CHUNK": "5", "aid:lds_pollute": "119"}, {"ORBX_PIPE": "1", "ORBX_PIPE_CHUNK": "32", "aid:poison": "201"}],
-                         ids=["blur-aside", "staggered-tails", "blur-in-regions", "pipelined-5", "pipelined-32"])
+                                 # round 6: the blur split by level under both overlaps (k_blur of the coarse levels aside, two description launches per half)
+                                 {"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "3", "ORBX_SPLIT_MIN_MPX": "0", "aid:lds_pollute": "119"},
+                                 {"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "2", "ORBX_SPLIT_MIN_MPX": "0", "ORBX_SPLIT": "3", "aid:poison": "201"}],
+                         ids=["blur-aside", "staggered-tails", "split-blur-aside", "split-staggered"])
 def test_seeded_batch_shape_sweep_under_the_overlap_policies(env, monkeypatch):
     """The same sweep with every batch counted as large (ORBX_SPLIT_MIN_MPX=0), so that the overlap forms of large batches - the blur on its side
-    stream (the default), staggered tails - and the blurring pyramid meet every batch shape, not only the benchmark's."""
+    stream (the default), staggered tails - and the blur split by level meet every batch shape, not only the benchmark's."""
     import fuzz_batches
     import helpers
     helpers.apply_switches(env, monkeypatch)

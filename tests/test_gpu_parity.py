@@ -264,7 +264,7 @@ def test_device_path_with_padded_rows_and_frames():
         assert d_lc[f].cpu().numpy().tolist() == [len(o.level_keypoints(l)) for l in range(8)]
 
 
-@pytest.mark.parametrize("form", ["default", "ORBX_PYR_COLS=0", "ORBX_PYR_COLS=1,ORBX_PYR_COL_PX=112", "ORBX_PYR_COLS=1,ORBX_BLUR_IN_COLS=1"])
+@pytest.mark.parametrize("form", ["default", "ORBX_PYR_COLS=0", "ORBX_PYR_COLS=1,ORBX_PYR_COL_PX=112", "ORBX_PATCH_BLUR=1,ORBX_BLUR_SPLIT=3"])
 @pytest.mark.parametrize("B,offset,stride", [(1, 1, 643), (2, 3, 641), (3, 2, 650), (1, 0, 640)])
 def test_device_path_with_unaligned_pointer_and_stride(B, offset, stride, form, monkeypatch):
     """cv::Mat ROIs handed over on the device: a base pointer and a row step that are not multiples of 4 (every pyramid form stages
@@ -329,59 +329,6 @@ def test_fast_on_dense_natural_and_sparse_content():
             assert_same_result(out[f][:3], want, "%s frame %d" % (variant, f))
 
 
-@pytest.mark.parametrize("B,chunk", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 4), (9, 16), (24, 8)])
-def test_pipelined_launches_give_the_serial_result(B, chunk, monkeypatch):
-    """Round 5: the stages behind the pyramid as one launch per pipeline step (k_pipe.hip) - FAST cells + blur rows of chunk t, quad-tree levels
-    of chunk t - 1, keypoints of chunk t - 2 in one grid - forced for small batches with chunks that do and do not divide the batch (a short
-    last chunk, a chunk larger than the batch, one-frame chunks): every frame's final arrays, per-level keypoints and blurred levels against the
-    oracle, and byte for byte against the serial launches of the same extractor parameters."""
-    parts = [("noise", 21, (B + 2) // 3), ("natural", 22, (B + 1) // 3), ("sparse", 23, B // 3)]
-    frames = np.concatenate([synth.frames(v, seed, n, 480, 640) for v, seed, n in parts if n > 0])[:B]
-    assert len(frames) == B
-    lap = [(0, 1000) if f % 2 == 0 else (100 + 7 * f, 400) for f in range(B)]
-    monkeypatch.setenv("ORBX_PIPE", "0")
-    serial = X.ORBextractor(1000, max_batch=B).extract_batch(frames, lap)
-    monkeypatch.setenv("ORBX_PIPE", "1")
-    monkeypatch.setenv("ORBX_PIPE_CHUNK", str(chunk))
-    ex = X.ORBextractor(1000, max_batch=B)
-    assert "PIPE=1(env)" in ex.policy() and "PIPE_CHUNK=%d(env)" % chunk in ex.policy()
-    out = ex.extract_batch(frames, lap)
-    assert ex.last_forms()[2] == 4, ex.last_forms()          # the blur rows rode in the pipelined launches
-    for f in range(B):
-        assert_same_result(out[f][:3], serial[f][:3], "pipelined vs serial, frame %d" % f)
-        assert all(a.tobytes() == b.tobytes() for a, b in zip(out[f][3], serial[f][3])), "per-level keypoints, frame %d" % f
-    for f in sorted({0, B // 2, B - 1}):
-        o, want = oracle_run(frames[f], 1000, lap[f])
-        assert_same_result(out[f][:3], want, "pipelined vs oracle, frame %d" % f)
-        for l in (0, 3, 7):
-            assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "blurred level %d of frame %d" % (l, f)
-    again = ex.extract_batch(frames[::-1].copy(), lap[::-1])          # the same handle again (what bench.py's timed steps do)
-    for f in range(B):
-        assert_same_result(again[B - 1 - f][:3], out[f][:3], "second call, frame %d" % f)
-
-
-def test_pipelined_launches_on_a_large_batch_with_the_default_chunk(monkeypatch):
-    """256 frames of 640x480 x 1000 features as two pipeline chunks of 128 (ORBX_PIPE=1; the form is opt-in: it measured slower than the launch
-    DAG): first / last frames of each chunk against the oracle; without the switch the same batch takes the serial forms and
-    gives the same bytes."""
-    B = 256
-    base = synth.frames("noise", 0, 16, 480, 640)
-    frames = np.concatenate([base] * (B // 16))
-    frames[127] = synth.frames("textured", 1, 1, 480, 640)[0]
-    frames[128] = synth.frames("natural", 2, 1, 480, 640)[0]
-    ref = X.ORBextractor(1000, max_batch=B)
-    want = ref.extract_batch(frames)
-    assert ref.last_forms()[2] == 3, ref.last_forms()          # the default of large batches: the blur per keypoint inside k_describe
-    monkeypatch.setenv("ORBX_PIPE", "1")
-    ex = X.ORBextractor(1000, max_batch=B)
-    out = ex.extract_batch(frames)
-    assert ex.last_forms()[2] == 4, ex.last_forms()
-    for f in (0, 127, 128, 255):
-        assert_same_result(out[f][:3], oracle_run(frames[f])[1], "256 frames pipelined, frame %d" % f)
-    for f in range(B):
-        assert_same_result(out[f][:3], want[f][:3], "pipelined vs default, frame %d" % f)
-
-
 def test_async_host_api_with_two_handles_and_pinned_input():
     """orbx_extract_batch_begin / _end called directly (the test was lost with the prefilter variant): two handles in flight, a
     second begin on a busy handle and an end without a begin are errors, and every branch of the upload - pinned memory copied as it lies,
@@ -429,14 +376,17 @@ def test_async_host_api_with_two_handles_and_pinned_input():
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
                                           ("ORBX_RESIZE_BYTEWISE", "1"), ("ORBX_PYR_COLS", "0"), ("ORBX_PYR_COLS,ORBX_RESIZE_BYTEWISE", "0,1")] +
-                                         [("ORBX_PYR_COLS_VARIANT", str(v)) for v in range(7)] +     # every workgroup shape of k_pyr_cols
+                                         [("aid:pyr_cols_shape", str(v)) for v in (1, 4, 6)] +     # every workgroup shape of k_pyr_cols
                                          [("ORBX_FAST_WIDE", "0"), ("ORBX_FAST_WIDE", "1")])      # FAST: a wave / a workgroup per cell
 def test_tuning_switches_do_not_change_results(switch, value, monkeypatch):
     # the quad-tree kernel exists in three workgroup sizes, the resize kernel in a packed and a byte-gather form, and the pyramid is one
     # launch region by region (k_pyr_cols) or one launch per level; the host picks by batch size / image area / tap geometry, and every
     # choice must give the reference result
     for sw, v in zip(switch.split(","), value.split(",")):
-        monkeypatch.setenv(sw, v)
+        if sw.startswith("aid:"):
+            X.debug_set_option(sw[4:], int(v))      # (test aids are not environment variables; conftest.py resets them after the test)
+        else:
+            monkeypatch.setenv(sw, v)
     for shape, nf, variant in (((480, 640), 1000, "noise"), ((333, 517), 700, "textured"), ((480, 640), 1200, "natural")):
         img = synth.frames(variant, 21, 1, *shape)[0]
         o, want = oracle_run(img, nf)
@@ -563,46 +513,6 @@ def test_region_major_pyramid_every_cut(px, monkeypatch):
             assert np.array_equal(ex.image_pyramid_level(l, frame=f, bordered=True), o.level(l, bordered=True)), "frame %d level %d" % (f, l)
 
 
-@pytest.mark.parametrize("px,nb", [(40, 5), (56, 3), (80, 5), (112, 5), (80, 8), (112, 2), (56, 8)])
-def test_region_major_pyramid_with_the_blur_inside(px, nb, monkeypatch):
-    """k_pyr_cols<.., BLUR>: the regions also blur what they own of the finest `nb` levels (7x7 sigma 2 of the border-less level, REFLECT_101:
-    ORBextractor.cc:1126-1127) out of rectangles that carry the blur's halo as virtual columns / mirrored rows; k_blur keeps the coarse levels.
-    Every blurred level, every bordered level and the final arrays against the oracle, for every cut, several level counts, odd shapes, a
-    batch, and every workgroup shape of the kernel (the blur's items are dealt over its roles)."""
-    monkeypatch.setenv("ORBX_PYR_COLS", "1")
-    monkeypatch.setenv("ORBX_PYR_COL_PX", str(px))
-    monkeypatch.setenv("ORBX_BLUR_IN_COLS", "1")
-    monkeypatch.setenv("ORBX_BLUR_IN_LEVELS", str(nb))
-    took = 0
-    for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "noise", {}),
-                                   ((480, 640), 900, "natural", dict(nlevels=12, sf=1.1)), ((241, 322), 300, "textured", dict(nlevels=2, sf=1.2)),
-                                   ((482, 643), 800, "noise", {})):
-        nlevels, sf = kw.get("nlevels", 8), kw.get("sf", 1.2)
-        img = synth.frames(variant, 53, 1, *shape)[0]
-        o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
-        ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
-        mono, k, d, lvl = ex(img, None, (0, 0))
-        took += ex.last_forms()[2] == 2
-        for l in range(nlevels):
-            if not len(o.level_keypoints(l)):      # (the reference - and the oracle - only blur levels that hold keypoints, :1122-1127)
-                continue
-            assert np.array_equal(ex.debug_blurred(l), o.blurred(l)), "px %d nb %d %s %s: blurred level %d (forms %s)" % (px, nb, shape, kw, l, ex.last_forms())
-        check_stages(ex, o, lvl, nlevels)
-        assert_same_result((mono, k, d), want, "px %d nb %d %s %s" % (px, nb, shape, kw))
-    assert took >= 3, "the cut with the blur's halo was taken %d times only" % took      # (a cut whose records do not fit falls back to k_blur: still exact, but then this test tests nothing)
-    frames = synth.frames("noise", 54, 5, 480, 640)
-    for shape_variant in ("", "0", "1", "2", "3", "4", "5", "6"):
-        if shape_variant:
-            monkeypatch.setenv("ORBX_PYR_COLS_VARIANT", shape_variant)
-        ex = X.ORBextractor(1000, max_batch=5)
-        out = ex.extract_batch(frames)
-        for f in (0, 4):
-            o, want = oracle_run(frames[f], 1000)
-            assert_same_result(out[f][:3], want, "px %d nb %d shape %s batch frame %d" % (px, nb, shape_variant, f))
-            for l in range(8):
-                assert np.array_equal(ex.debug_blurred(l, frame=f), o.blurred(l)), "shape %s frame %d blurred level %d" % (shape_variant, f, l)
-
-
 def test_wide_frame_with_tiny_quotas_keeps_the_first_pass_nodes():
     """A 922 x 200 frame has five to six quad-tree roots per level (nIni = round(width / height), ORBextractor.cc:548); with 55 features the
     per-level quotas are 5 .. 14, so what a level keeps is set by the unconditional first pass (up to four nodes per root), not by quota + 3
@@ -648,6 +558,73 @@ def test_patch_blur_inside_the_description(pyr_cols, monkeypatch):
     for f in (0, 4, 8):
         o, want = oracle_run(frames[f], 1200, (0, 0))
         assert_same_result(out[f][:3], want, "patch blur batch frame %d" % f)
+
+
+@pytest.mark.parametrize("split", [1, 2, 3, 4, 5, 7])
+def test_patch_blur_split_by_level(split, monkeypatch):
+    """Round 6: the blur per keypoint on the levels below the split, k_blur + the description from the blurred level on the levels from the split
+    on (ORBextractor.cc:1122-1132 blurs a level, then describes its keypoints: both forms compute that level's blurred pixels with the same
+    arithmetic).  Forced at every split level: final arrays and per-level keypoints against the oracle, the blurred levels that exist against
+    the oracle's, the ones that do not refused; levels without keypoints, two levels (no level to split off), twelve levels, odd shapes, a
+    batch with per-frame lapping areas, a second call on the same handle, and a back-only pass (orbx_compute_keypoints_octree) after a split call."""
+    monkeypatch.setenv("ORBX_PATCH_BLUR", "1")
+    monkeypatch.setenv("ORBX_BLUR_SPLIT", str(split))
+    for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "natural", {}),
+                                   ((480, 640), 900, "natural", dict(nlevels=12, sf=1.1)), ((241, 322), 300, "sparse", dict(nlevels=2, sf=1.2)),
+                                   ((482, 643), 1500, "noise", {})):
+        nlevels, sf = kw.get("nlevels", 8), kw.get("sf", 1.2)
+        img = synth.frames(variant, 61, 1, *shape)[0]
+        o, want = oracle_run(img, nf, (0, 0), nlevels, sf)
+        ex = X.ORBextractor(nf, sf, nlevels, 20, 7, max_width=shape[1], max_height=shape[0])
+        assert "BLUR_SPLIT=%d(env)" % split in ex.policy()
+        mono, k, d, lvl = ex(img, None, (0, 0))
+        active = split < nlevels
+        assert ex.last_forms()[2] == (5 if active else 3), (ex.last_forms(), split, nlevels)
+        for l in range(nlevels):
+            if active and l >= split:
+                if len(o.level_keypoints(l)):      # (the oracle, like the reference, only blurs levels that hold keypoints, :1122-1127)
+                    assert np.array_equal(ex.debug_blurred(l), o.blurred(l)), "split %d %s %s: blurred level %d" % (split, shape, kw, l)
+            else:
+                with pytest.raises(X.OrbxError):
+                    ex.debug_blurred(l)            # blurred per keypoint: no such level exists, and the library says so
+        check_stages(ex, o, lvl, nlevels)
+        assert_same_result((mono, k, d), want, "split %d %s %s" % (split, shape, kw))
+        mono2, k2, d2, lvl2 = ex(img, None, (0, 0))      # the same handle again
+        assert_same_result((mono2, k2, d2), want, "split %d %s %s, second call" % (split, shape, kw))
+    B = 9
+    frames = np.concatenate([synth.frames("noise", 62, 4, 480, 640), synth.frames("natural", 63, 3, 480, 640), synth.frames("sparse", 64, 2, 480, 640)])
+    lap = [(0, 1000) if f % 2 == 0 else (100 + 7 * f, 400) for f in range(B)]
+    ex = X.ORBextractor(1200, max_batch=B)
+    out = ex.extract_batch(frames, lap)
+    assert ex.last_forms()[2] == 5
+    for f in range(B):
+        o, want = oracle_run(frames[f], 1200, lap[f])
+        assert_same_result(out[f][:3], want, "split %d batch frame %d" % (split, f))
+        assert [len(a) for a in out[f][3]] == [len(o.level_keypoints(l)) for l in range(8)]
+
+
+def test_patch_blur_split_in_a_large_batch_with_every_overlap(monkeypatch):
+    """The split inside the launch DAG of large batches: k_blur of the coarse levels on the side stream beside FAST + quad-tree, the fine levels'
+    description in front of the join, staggered tails (two halves, each with its own two description launches); 300 frames of 320x240 count
+    as a large batch with ORBX_SPLIT_MIN_MPX=0.  Every frame against the serial single-frame result, frames spread over the batch against the oracle."""
+    monkeypatch.setenv("ORBX_PATCH_BLUR", "1")
+    monkeypatch.setenv("ORBX_BLUR_SPLIT", "3")
+    B = 301
+    frames = np.concatenate([synth.frames("noise", 71, 150, 240, 320), synth.frames("natural", 72, B - 150, 240, 320)])
+    results = {}
+    for mode in ("0", "1", "3"):
+        monkeypatch.setenv("ORBX_SPLIT", mode)
+        monkeypatch.setenv("ORBX_SPLIT_MIN_MPX", "0")
+        ex = X.ORBextractor(500, max_width=320, max_height=240, max_batch=B)
+        results[mode] = ex.extract_batch(frames)
+        assert ex.last_forms()[2] == 5, ex.last_forms()
+    for f in range(B):
+        for mode in ("1", "3"):
+            a, b = results[mode][f], results["0"][f]
+            assert a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]), "ORBX_SPLIT=%s frame %d differs from the serial launches" % (mode, f)
+    for f in (0, 1, 149, 150, 151, 299, 300):
+        o, want = oracle_run(frames[f], 500)
+        assert_same_result(results["3"][f][:3], want, "frame %d" % f)
 
 
 def test_fast_with_a_workgroup_per_cell_in_batches(monkeypatch):

@@ -26,7 +26,7 @@ def test_the_library_holds_the_kernels_of_the_hot_path(current):
         assert k in names, k
     for prefix in ("k_fast<", "k_fast_wide<", "k_pyr_cols<", "k_blur<", "k_resize<", "k_pyr_first<"):
         assert any(n.startswith(prefix) for n in names), prefix
-    assert len(names) >= 50
+    assert len(names) >= 38
 
 
 def test_no_flat_memory_instructions_on_the_extraction_path(current):
@@ -37,7 +37,7 @@ def test_no_flat_memory_instructions_on_the_extraction_path(current):
     for k in KT.FLAT_ALLOWED & set(current):
         assert current[k]["scratch_bytes"] == 0 and current[k]["sgpr_spill"] == 0, (k, current[k])
     for k, v in current.items():
-        if k.startswith(("k_octree", "k_fast", "k_pyr_", "k_blur", "k_resize", "k_describe", "k_pipe")):
+        if k.startswith(("k_octree", "k_fast", "k_pyr_", "k_blur", "k_resize", "k_describe")):
             assert v.get("flat", 0) == 0, (k, v)
 
 
@@ -48,9 +48,8 @@ def test_scratch_and_spills_stay_within_the_checked_in_table(current):
 
 
 def test_only_the_queued_quadtree_variants_use_scratch(current):
-    """Every kernel but the register-starved quad-tree variants - and the pipelined launch, which holds the quad-tree's body as one of its roles
-    (k_pipe, opt-in) - is scratch-free; those hold their spills in scratch with DS (not FLAT) node accesses."""
+    """Every kernel but the register-starved quad-tree variants is scratch-free; those hold their spills in scratch with DS (not FLAT) node accesses."""
     with_scratch = sorted(k for k, v in current.items() if v["scratch_bytes"])
-    assert all(k.startswith(("k_octree_", "k_pipe<")) for k in with_scratch), with_scratch
+    assert all(k.startswith("k_octree_") for k in with_scratch), with_scratch
     for k in with_scratch:
         assert current[k].get("flat", 0) == 0
