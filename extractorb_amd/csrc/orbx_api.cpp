@@ -18,8 +18,11 @@ thread_local std::string g_createError;
 
 namespace {
 // The automatic split level of the per-keypoint blur (installGeometry): k_blur takes the levels whose patches hold more than kSplitRatioNum /
-// kSplitRatioDen of the level's pixels.  0 / 1 = never split on its own (ORBX_BLUR_SPLIT=L still pins a level).
-constexpr int kSplitRatioNum = 0, kSplitRatioDen = 1;
+// kSplitRatioDen of the level's pixels.  Measured (round 6, A/B in one call, us per step): 512 x 640x480 x 1000 - no split 1696-1699, split at level
+// 2 (patches 1.36 of the level) 1667-1668, at 3 (1.63) 1656-1666, at 4 (1.96) 1664-1674, at 5 1674-1680, k_blur for every level 1707-1710; 128 x
+// 1080p x 2000, where the coarsest level's patches reach 0.99 of it: no split 2290, at 7 2316-2321, at 6 2318-2331, at 4 2355-2367 - so the
+// levels past 1.5.
+constexpr int kSplitRatioNum = 3, kSplitRatioDen = 2;
 
 void freeAll(orbx_handle* h) {
     void* dev[] = {h->d_input, h->d_pyr, h->d_blur, h->d_candPos, h->d_candSeg, h->d_cellCount, h->d_cellOff, h->d_nodeOf, h->d_candCount, h->d_sink, h->d_sel, h->d_levelCount,

@@ -62,6 +62,8 @@ int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_
     return ORBX_OK;
 }
 
+int orbx_debug_last_split_level(const orbx_handle* h) { return h && h->lastBlurForm == 5 ? h->lastSplitLevel : 0; }
+
 int orbx_debug_num_candidates(orbx_handle* h, int frame, int level, int* n) {
     if (!h || !n) return ORBX_ERR_BAD_ARGUMENT;
     if (h->geom.nlevels == 0 || frame < 0 || frame >= h->lastB || level < 0 || level >= h->nlevels)

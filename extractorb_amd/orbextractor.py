@@ -132,6 +132,7 @@ def load_library():
     L.orbx_compute_keypoints_octree.argtypes = [vp, vp, C.c_int, vp]
     L.orbx_fetch_pyramid.argtypes = [vp, C.c_int, C.POINTER(vp), vp, vp, vp, vp]
     L.orbx_debug_last_forms.argtypes = [vp, ip, ip, ip]
+    L.orbx_debug_last_split_level.argtypes = [vp]
     L.orbx_debug_set_option.argtypes = [C.c_char_p, C.c_int]
     L.orbx_debug_clock_probe.argtypes = [vp, C.c_int]
     L.orbx_debug_clock_read.argtypes = [vp, C.c_int, vp]
@@ -210,6 +211,7 @@ def debug_reset_options():
     debug_set_option("poison", -1)
     debug_set_option("lds_pollute", -1)
     debug_set_option("fail_after_fast", 0)
+    debug_set_option("pyr_cols_shape", -1)
 
 
 # ---- handle-free host helpers (no GPU needed) -------------------------------------------------------------
@@ -598,6 +600,11 @@ class ORBextractor:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self._L.orbx_debug_last_forms(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def blurred_level_exists(self, level):
+        """whether the last call left a blurred image of `level` (it did not where the blur ran per keypoint inside k_describe)"""
+        form = self.last_forms()[2]
+        return form not in (3, 5) or (form == 5 and level >= self._L.orbx_debug_last_split_level(self._h))
 
     # ---- introspection for tests/bench ----
     def debug_candidates(self, level, frame=0):

@@ -372,15 +372,18 @@ int orbx_debug_search_rounds(int* out4);
 
 /* Which launch forms the last call took (results never depend on them; the parity tests assert the form they mean to cover and the
  * published timings name theirs): pyramid_form 0 = k_pyr_cols (region-major, *pyramid_cut_px = side of its regions), 1 = k_pyr_first +
- * one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the FAST launch, 2 = inside k_pyr_cols (k_blur keeps the coarse levels), 3 = per
- * keypoint inside k_describe (no blurred level exists: orbx_debug_get_blurred has nothing to show), 4 = blur rows dealt to the pipelined
- * launches (k_pipe: large batches; the FAST cells, quad-tree levels and keypoints of successive chunks of the batch share each launch). */
+ * one k_resize per level; blur_form 0 = k_blur, 1 = lanes of the FAST launch, 3 = per keypoint inside k_describe (no blurred level exists:
+ * orbx_debug_get_blurred has nothing to show), 5 = split by level: per keypoint below orbx_debug_last_split_level(), k_blur from that level on
+ * (only those blurred levels exist).  (2 and 4 named forms that rounds 4 / 5 measured slower and round 6 removed.) */
 int orbx_debug_last_forms(const orbx_handle* h, int* pyramid_form, int* pyramid_cut_px, int* blur_form);
+/* the first level the last call blurred with k_blur when its blur form was 5; 0 otherwise */
+int orbx_debug_last_split_level(const orbx_handle* h);
 
 /* Test aids.  They cannot be set from the environment: a test calls this BEFORE orbx_create and the handles created afterwards carry the
  * setting.  name = "poison" (byte every device allocation of orbx_create is filled with; -1 = off), "lds_pollute" (byte every CU's LDS is
  * filled with in front of every kernel; -1 = off), "fail_after_fast" (1: the next handle's first small-batch call returns ORBX_ERR_HIP
- * between the FAST and the quad-tree launch, once).  Unknown name: ORBX_ERR_BAD_ARGUMENT. */
+ * between the FAST and the quad-tree launch, once), "pyr_cols_shape" (1, 4 or 6: pins the workgroup shape of k_pyr_cols; -1 = by the grid
+ * size).  Unknown name: ORBX_ERR_BAD_ARGUMENT. */
 int orbx_debug_set_option(const char* name, int value);
 
 /* The launch-policy switches as orbx_create read them, "NAME=value" separated by blanks, "(env)" behind a value that came from an ORBX_<NAME>

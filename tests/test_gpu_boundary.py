@@ -189,7 +189,10 @@ def test_the_benchmarks_own_batch_shapes(shape, nf, B):
     for f in picks:
         o, want = oracle_run(frames[f], nf)
         assert_same_result(out[f][:3], want, "%s x %d frame %d (forms %s)" % (shape, B, f, ex.last_forms()))
-    assert ex.last_forms()[2] == 3, ex.last_forms()      # the blur per keypoint inside k_describe: 1080p x 2000 (features per pixel), 512 x 640x480 x 1000 (round 5: large batches, level with k_blur in time, 40 % fewer HBM bytes)
+    # the blur per keypoint inside k_describe: 1080p x 2000 on every level (form 3: the coarsest level's patches hold 0.99 of its pixels); 512 x 640x480 x
+    # 1000 split by level (form 5, round 6: levels 0-2 per keypoint, k_blur for levels 3-7, whose patches hold 1.6-3.4 x the level's pixels)
+    assert ex.last_forms()[2] == (5 if shape == (480, 640) else 3), ex.last_forms()
+    assert X.load_library().orbx_debug_last_split_level(ex._h) == (3 if shape == (480, 640) else 0)
     out2 = ex.extract_batch(frames[::-1].copy())          # the same handle again: what the timed steps of bench.py do
     assert_same_result(out2[B - 1][:3], out[0][:3], "second call")
 

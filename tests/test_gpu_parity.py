@@ -21,8 +21,10 @@ def oracle_run(img, nf=1000, lap=(0, 1000), nlevels=8, sf=1.2, ini=20, mn=7):
 def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
     """Every stage boundary of one frame against the oracle.  The first mismatch raises with a replay file (helpers.dump_failure) that holds
     the inputs, the ORBX_* switches and, for EVERY level, both sides' candidates and kept keypoints — not only the arrays that differed."""
-    def fail(msg):
-        both = {}
+    def fail(msg, **failed):
+        # `failed`: the arrays that FAILED the comparison, as they were read then (ADVICE round 5: the loop below reads the device again for the
+        # dump; if the two reads differ the fault was transient, and the dump shows it)
+        both = {"failed_" + k: v for k, v in failed.items()}
         for l in range(nlevels):
             both["gpu_candidates_%d" % l], both["oracle_candidates_%d" % l] = ex.debug_candidates(l, frame), o.candidates(l)
             both["gpu_level_keys_%d" % l], both["oracle_level_keys_%d" % l] = lvl_gpu[l], o.level_keypoints(l)
@@ -30,20 +32,23 @@ def check_stages(ex, o, lvl_gpu, nlevels=8, frame=0):
         fail_with_dump(msg, frame=frame, quotas=o.features_per_level, **both)
 
     for l in range(nlevels):
-        if not np.array_equal(ex.image_pyramid_level(l, frame), o.level(l)):
-            fail("pyramid level %d" % l)
-        if not np.array_equal(ex.image_pyramid_level(l, frame, bordered=True), o.level(l, bordered=True)):
-            fail("border %d" % l)
-        if len(o.level_keypoints(l)) and ex.last_forms()[2] != 3:      # the reference only blurs levels that hold keypoints (:1122-1127); form 3 blurs per keypoint: no blurred level exists
-            if not np.array_equal(ex.debug_blurred(l, frame), o.blurred(l)):
-                fail("blur level %d" % l)
+        got = ex.image_pyramid_level(l, frame)
+        if not np.array_equal(got, o.level(l)):
+            fail("pyramid level %d" % l, gpu_interior=got, oracle_interior=o.level(l))
+        got = ex.image_pyramid_level(l, frame, bordered=True)
+        if not np.array_equal(got, o.level(l, bordered=True)):
+            fail("border %d" % l, gpu_bordered=got, oracle_bordered=o.level(l, bordered=True))
+        if len(o.level_keypoints(l)) and ex.blurred_level_exists(l):      # the reference only blurs levels that hold keypoints (:1122-1127); where the blur ran per keypoint no blurred level exists
+            got = ex.debug_blurred(l, frame)
+            if not np.array_equal(got, o.blurred(l)):
+                fail("blur level %d" % l, gpu_blurred=got, oracle_blurred=o.blurred(l))
         # k_fast's per-cell segments, read segment by segment, ARE vToDistributeKeys in the reference's order (cell row,
         # cell column, then raster order inside the cell, ORBextractor.cc:797-864): compared without sorting
         cg, co = ex.debug_candidates(l, frame), o.candidates(l)
         if cg.tobytes() != co.tobytes():
-            fail("FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co)))
+            fail("FAST candidates level %d (%d vs %d)" % (l, len(cg), len(co)), gpu_candidates=cg, oracle_candidates=co)
         if lvl_gpu[l].tobytes() != o.level_keypoints(l).tobytes():
-            fail("quad-tree/orientation level %d" % l)
+            fail("quad-tree/orientation level %d" % l, gpu_level_keys=lvl_gpu[l], oracle_level_keys=o.level_keypoints(l))
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
@@ -532,6 +537,7 @@ def test_patch_blur_inside_the_description(pyr_cols, monkeypatch):
     37 x 37 patch is blurred out of its raw 43 x 43 tile of the bordered pyramid.  Final arrays and per-level keypoints against the oracle:
     keypoints on the FAST rectangle's rim (their patches reach 2 px into the REFLECT_101 frame), odd shapes, many and few levels, batches."""
     monkeypatch.setenv("ORBX_PATCH_BLUR", "1")
+    monkeypatch.setenv("ORBX_BLUR_SPLIT", "0")      # (every level per keypoint; the split by level has its own test below)
     monkeypatch.setenv("ORBX_PYR_COLS", pyr_cols)
     rim = 0
     for shape, nf, variant, kw in (((480, 640), 1000, "noise", {}), ((333, 517), 700, "textured", {}), ((1080, 1920), 2000, "natural", {}),
@@ -591,6 +597,10 @@ def test_patch_blur_split_by_level(split, monkeypatch):
         assert_same_result((mono, k, d), want, "split %d %s %s" % (split, shape, kw))
         mono2, k2, d2, lvl2 = ex(img, None, (0, 0))      # the same handle again
         assert_same_result((mono2, k2, d2), want, "split %d %s %s, second call" % (split, shape, kw))
+        # a back-only pass describes from what the call in front of it left: the same split (levels below it have no blurred image)
+        again = ex.ComputeKeyPointsOctTree()
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(again, lvl)), "split %d %s %s: ComputeKeyPointsOctTree after a split call" % (split, shape, kw)
+        assert ex.last_forms()[2] == (5 if active else 3)
     B = 9
     frames = np.concatenate([synth.frames("noise", 62, 4, 480, 640), synth.frames("natural", 63, 3, 480, 640), synth.frames("sparse", 64, 2, 480, 640)])
     lap = [(0, 1000) if f % 2 == 0 else (100 + 7 * f, 400) for f in range(B)]
