@@ -583,61 +583,110 @@ def main():
             if bow:
                 compute_bow(ex, base)
 
-        ex.profile(True)
-        profiled_step()          # the profiled form can launch kernels the timed form never did (unsplit, unfused): load them untimed
-        ex.profile(True)         # (resets the slots)
-        psteps = max(3, min(args.steps, 20))
-        for _ in range(psteps):
-            profiled_step()
-        prof = ex.profile_read()
-        ex.profile(False)
-        kern = {k: v for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
-        per_step_ms = {k: v[0] / psteps for k, v in kern.items()}
-        dominant = max(per_step_ms, key=per_step_ms.get)
-        dom_avg_ms = kern[dominant][0] / kern[dominant][1]            # average duration of ONE launch
-        n_mean = float(n_host.mean())
-        b_alg = ex.algorithmic_bytes(rows, cols, int(round(n_mean)))   # P0 + 2*S + 60*n_out per frame
-        achieved = b_alg * B / (dom_avg_ms * 1e-3) / 1e9               # GB/s: algorithmic bytes of one launch / its duration
-        # PMC-derived figures of the dominant kernel (profiles/traffic.json, profiles/valu.json: rocprofv3 --pmc passes of this
-        # workload, published by tools/publish_profiles.py).  Each (workload, batch) entry carries the hash of the kernel
-        # sources it was measured on; counters of another build are not this kernel's: null.
-        src_hash = X.source_hash()
-        default_variant = variant == WORKLOADS[args.workload]["variant"]   # the PMC files were collected on the default variant
+        def event_profile(e_, run, psteps_):
+            """per-kernel durations of `run` on handle e_ (HIP events on its stream, serial launches): ms per step by kernel, the dominant
+            kernel and the average duration of ONE of its launches"""
+            e_.profile(True)
+            run()                # the profiled form can launch kernels the timed form never did (unsplit, unfused): load them untimed
+            e_.profile(True)     # (resets the slots)
+            for _ in range(psteps_):
+                run()
+            prof_ = e_.profile_read()
+            e_.profile(False)
+            kern_ = {k: v for k, v in prof_.items() if k.startswith("k_") and v[1] > 0}
+            per_ = {k: v[0] / psteps_ for k, v in kern_.items()}
+            dom_ = max(per_, key=per_.get)
+            return per_, dom_, kern_[dom_][0] / kern_[dom_][1]
 
-        def pmc_entry(name):
+        # PMC-derived figures of a kernel (profiles/traffic.json, profiles/valu.json: rocprofv3 --pmc passes of the workload, published by
+        # tools/publish_profiles.py).  Each (workload, batch) entry carries the hash of the kernel sources it was measured on; counters of
+        # another build are not this kernel's: null.
+        src_hash = X.source_hash()
+
+        def pmc_entry(name, workload_, batch_, default_variant_=True):
             path = os.path.join(ROOT, "profiles", name)
-            if not (os.path.exists(path) and default_variant) or os.environ.get("ORBX_LIBRARY"):
+            if not (os.path.exists(path) and default_variant_) or os.environ.get("ORBX_LIBRARY"):
                 return None          # (counters belong to the in-tree build; another .so is another kernel)
             try:
-                e = json.load(open(path)).get(args.workload, {}).get(str(B), {})
+                e = json.load(open(path)).get(workload_, {}).get(str(batch_), {})
             except Exception:
                 return None
             return e if e.get("_source_hash") == src_hash else None
 
-        traffic = None
-        te = pmc_entry("traffic.json")
-        if te:
-            traffic = te.get(dominant)
-        valu = None
-        ve = pmc_entry("valu.json")
-        if ve and ve.get(dominant):
-            vj = ve[dominant]
-            g_instr = vj["SQ_INSTS_VALU"] / (dom_avg_ms * 1e-3) / 1e9
-            full = float(vj.get("full_rate_share", 0.0))          # static ISA census: share of 2-cycle-class instructions
-            valu = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
-                        peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
-                        measured_ceiling_ginstr_s=round(VALU_MEASURED_GINSTR, 1), frac_of_measured_ceiling=round(g_instr / VALU_MEASURED_GINSTR, 4),
-                        full_rate_share=round(full, 3), frac_lower=round(g_instr * (1 - full / 2) / VALU_PEAK_GINSTR, 4),
-                        note="issue-slot occupancy of the dominant kernel: frac prices every instruction at the 4-cycle class "
-                             "(upper bound); frac_lower prices its full-rate share at 2 cycles, where the share is a STATIC census of "
-                             "the kernel's ISA (every instruction counted once, tools/valu_census.py), not a dynamic mix: an estimate; "
-                             "frac_of_measured_ceiling prices the half-rate class at its measured 4.14 cycles and k_fast's measured 2.375 GHz "
-                             "(profiles/r03_valu_issue_rate.md)")
-        roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                        algorithmic_bytes_per_frame=b_alg, frames_per_launch=B, kernel_avg_ms=round(dom_avg_ms, 4),
-                        path_achieved=round(fps / N * b_alg / 1e9, 2), path_frac=round(fps / N * b_alg / 1e9 / HBM_PEAK_GBS, 5),
-                        kernel_ms_per_step={k: round(v, 4) for k, v in sorted(per_step_ms.items())}, valu_issue=valu)
+        def roofline_block(workload_, batch_, per_, dom_, dom_ms_, b_alg_, fps_per_gpu_, default_variant_=True):
+            """the contract's roofline object for one workload: algorithmic bytes of one launch of the dominant kernel / its live-measured
+            duration against the HBM peak; counter traffic and the vector-issue occupancy where profiles/ holds counters of THIS build"""
+            achieved_ = b_alg_ * batch_ / (dom_ms_ * 1e-3) / 1e9               # GB/s: algorithmic bytes of one launch / its duration
+            te = pmc_entry("traffic.json", workload_, batch_, default_variant_)
+            ve = pmc_entry("valu.json", workload_, batch_, default_variant_)
+            valu_ = None
+            if ve and ve.get(dom_):
+                vj = ve[dom_]
+                g_instr = vj["SQ_INSTS_VALU"] / (dom_ms_ * 1e-3) / 1e9
+                full = float(vj.get("full_rate_share", 0.0))          # static ISA census: share of 2-cycle-class instructions
+                valu_ = dict(wave_instr_per_launch=vj["SQ_INSTS_VALU"], achieved_ginstr_s=round(g_instr, 1),
+                             peak_ginstr_s=round(VALU_PEAK_GINSTR, 1), frac=round(g_instr / VALU_PEAK_GINSTR, 4),
+                             measured_ceiling_ginstr_s=round(VALU_MEASURED_GINSTR, 1), frac_of_measured_ceiling=round(g_instr / VALU_MEASURED_GINSTR, 4),
+                             full_rate_share=round(full, 3), frac_lower=round(g_instr * (1 - full / 2) / VALU_PEAK_GINSTR, 4),
+                             note="issue-slot occupancy of the dominant kernel: frac prices every instruction at the 4-cycle class "
+                                  "(upper bound); frac_lower prices its full-rate share at 2 cycles, where the share is a STATIC census of "
+                                  "the kernel's ISA (every instruction counted once, tools/valu_census.py), not a dynamic mix: an estimate; "
+                                  "frac_of_measured_ceiling prices the half-rate class at its measured 4.14 cycles and k_fast's measured 2.375 GHz "
+                                  "(profiles/r03_valu_issue_rate.md)")
+            path_traffic = None
+            if te:      # every kernel of the step, per frame: the whole path's counter traffic beside its algorithmic bytes
+                path_traffic = round(sum(v for k, v in te.items() if k in per_) / batch_)
+            return dict(bound="hbm", kernel=dom_, achieved=round(achieved_, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved_ / HBM_PEAK_GBS, 5), traffic=te.get(dom_) if te else None,
+                        algorithmic_bytes_per_frame=b_alg_, frames_per_launch=batch_, kernel_avg_ms=round(dom_ms_, 4),
+                        path_achieved=round(fps_per_gpu_ * b_alg_ / 1e9, 2), path_frac=round(fps_per_gpu_ * b_alg_ / 1e9 / HBM_PEAK_GBS, 5),
+                        path_traffic_bytes_per_frame=path_traffic,
+                        kernel_ms_per_step={k: round(v, 4) for k, v in sorted(per_.items())}, valu_issue=valu_)
+
+        psteps = max(3, min(args.steps, 20))
+        per_step_ms, dominant, dom_avg_ms = event_profile(ex, profiled_step, psteps)
+        n_mean = float(n_host.mean())
+        b_alg = ex.algorithmic_bytes(rows, cols, int(round(n_mean)))   # P0 + 2*S + 60*n_out per frame (SURVEY.md §8d)
+        default_variant = variant == WORKLOADS[args.workload]["variant"]   # the PMC files were collected on the default variant
+        roofline = roofline_block(args.workload, B, per_step_ms, dominant, dom_avg_ms, b_alg, fps / N, default_variant)
+        valu = roofline["valu_issue"]
+
+        def cgroup_cpu_share():
+            """CPUs the box's cgroup grants this job (a GPU box may show every core of the host - 256 - while the job gets 16 per GPU)"""
+            share_ = None
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+                if q != "max":
+                    share_ = max(1, int(round(int(q) / int(per))))
+            except Exception:
+                try:                                                                             # cgroup v1
+                    q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if q > 0:
+                        share_ = max(1, int(round(q / per)))
+                except Exception:
+                    pass
+            try:
+                share_ = min(share_ or 1 << 30, len(os.sched_getaffinity(0)))
+            except Exception:
+                pass
+            return share_
+
+        def cpu_baseline_small(O_, rows_, cols_, nf_, lapping_, variant_, frames_per_thread, n_single, per_unit=1, unit="frames/s"):
+            """the oracle on the box's CPU share (one extractor per thread) and on one thread, a bounded sample: the secondary workloads' baseline"""
+            ncpu_ = os.cpu_count() or 1
+            th = min(ncpu_, cgroup_cpu_share() or 16)
+            base_ = synth.frames(variant_, 0, 8, rows_, cols_)
+            smp = max(16, frames_per_thread * th)
+            cf_ = np.concatenate([base_] * ((smp + 7) // 8))[:smp]
+            sec_, _ = O_.time_frames(cf_, nf_, 1.2, 8, 20, 7, lapping_, nthreads=th)
+            sec1_, _ = O_.time_frames(base_[:n_single], nf_, 1.2, 8, 20, 7, lapping_, nthreads=1)
+            return dict(value=round(smp / sec_ / per_unit, 2), unit=unit, cores=ncpu_, cgroup_cpu_share=cgroup_cpu_share(), threads=th, kind="port",
+                        single_thread_value=round(n_single / sec1_ / per_unit, 2),
+                        sample="%d %s frames %dx%d x %d features, one oracle extractor per thread, %d threads, %.1f s wall (single thread: %d frames, %.1f s); "
+                               "scalar C++ -O3 restatement of ORBextractor.cc + OpenCV primitives (not OpenCV's SIMD build)"
+                               % (smp, variant_, cols_, rows_, nf_, th, sec_, n_single, sec1_))
+
         cpu = None
         if N == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -646,23 +695,7 @@ def main():
             # cgroup grants the job a CPU share (16 per GPU on this pool): threads beyond the share only add switching.  So the baseline is
             # timed twice — all visible cores, and the cgroup's share (or 16) — and the better rate is the reported one; both are in `runs`.
             ncpu = os.cpu_count() or 1
-            share = None
-            try:
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
-                if q != "max":
-                    share = max(1, int(round(int(q) / int(per))))
-            except Exception:
-                try:                                                                             # cgroup v1
-                    q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    if q > 0:
-                        share = max(1, int(round(q / per)))
-                except Exception:
-                    pass
-            try:
-                share = min(share or 1 << 30, len(os.sched_getaffinity(0)))
-            except Exception:
-                pass
+            share = cgroup_cpu_share()
             small = rows * cols <= 640 * 480
             counts = [args.cpu_threads] if args.cpu_threads else sorted({ncpu, min(ncpu, share or 16)})
             cf0 = synth.frames(variant, 0, 64 if small else 8, rows, cols)
@@ -750,9 +783,9 @@ def main():
                 valu["frac_at_measured_clock"] = round(valu["achieved_ginstr_s"] / (1024 * clk / 4.0), 4)
                 valu["frac_of_measured_ceiling_at_measured_clock"] = round(valu["achieved_ginstr_s"] / (1024 * clk / 4.14), 4)
         if N == 1 and args.workload == "mono640" and not args.no_extras and not distributed:
-            if not args.no_verify:
+            if not (args.no_verify and args.no_cpu_baseline):
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib as O      # the checker (hd1080_verified); never the product path
+                import oracle_lib as O      # the checker (hd1080 / stereo640: verified + cpu_baseline); never the product path
             # (a) PCIe-inclusive rate (SURVEY.md §8d "end-to-end"): pinned host frames in, host arrays out, two handles used alternately
             #     so one batch's transfers overlap the other's kernels.  Never `value`.
             Bh = min(B, 64)
@@ -772,6 +805,32 @@ def main():
             extras["host_to_host_fps"] = round(Bh * reps / dt, 1)
             extras["host_to_host_note"] = ("pinned host frames -> H2D -> whole path -> D2H of keypoints+descriptors, %d frames per call, "
                                            "two handles alternating (PCIe-inclusive; not `value`)" % Bh)
+            # ... and what the input copy alone can do on this box: the same 64-frame slab as a bare pinned hipMemcpyAsync, two streams alternating,
+            # nothing else running.  host_to_host_fps x frame bytes against it says whether the host-fed rate is the link's or the pipeline's
+            # 
+            nbytes_in = Bh * rows * cols
+            tpin = [torch.empty(nbytes_in, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            tdst = [torch.empty(nbytes_in, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            cstreams = [torch.cuda.Stream() for _ in range(2)]
+            def copy_round(n_):
+                for i in range(n_):
+                    with torch.cuda.stream(cstreams[i & 1]):
+                        tdst[i & 1].copy_(tpin[i & 1], non_blocking=True)
+            copy_round(4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            copy_round(64)
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t1
+            peak_gbps = 64 * nbytes_in / dtc / 1e9
+            in_gbps = extras["host_to_host_fps"] * rows * cols / 1e9
+            extras["h2d_copy_peak_gbps"] = round(peak_gbps, 2)
+            extras["host_to_host_input_gbps"] = round(in_gbps, 2)
+            extras["host_to_host_frac_of_copy_peak"] = round(in_gbps / peak_gbps, 3)
+            extras["h2d_copy_note"] = ("h2d_copy_peak_gbps: %d frames (%.1f MB) per copy, pinned host -> HBM, hipMemcpyAsync on two streams alternating, 64 copies, nothing "
+                                       "else running; host_to_host_input_gbps = host_to_host_fps x %d B of input per frame (the result slab travels the other "
+                                       "way on the full-duplex link)" % (Bh, nbytes_in / 1e6, rows * cols))
+            del tpin, tdst
             for a in pin:
                 X.pinned_free(a)
             del hx
@@ -797,9 +856,19 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             n2 = float(s2[l2["n"]:l2["n"] + 4 * B2].cpu().numpy().view(np.int32).mean())
-            extras["hd1080_fps"] = round(B2 * 10 / dt, 1)
+            fps2 = B2 * 10 / dt
+            balg2 = e2.algorithmic_bytes(w2["rows"], w2["cols"], int(round(n2)))
+            extras["hd1080_fps"] = round(fps2, 1)
             extras["hd1080_note"] = "1920x1080 x 2000 features (BASELINE.json configs[2]), %d noise frames per call, device-resident, %.0f keypoints per frame" % (B2, n2)
-            extras["hd1080_path_frac"] = round(B2 * 10 / dt * e2.algorithmic_bytes(w2["rows"], w2["cols"], int(round(n2))) / 1e9 / HBM_PEAK_GBS, 5)
+            extras["hd1080_path_frac"] = round(fps2 * balg2 / 1e9 / HBM_PEAK_GBS, 5)
+            # the full report north_star asks for at 1920x1080: the dominant kernel's roofline from a live event profile of
+            # the same calls (+ counters of this build from profiles/), and the CPU restatement timed beside it on this box's cores
+            per2, dom2, dom2_ms = event_profile(e2, run2, 5)
+            hd = dict(fps=round(fps2, 1), ms_per_step=round(dt / 10 * 1e3, 4), frames_per_step=B2, mean_keypoints_per_frame=round(n2, 1),
+                      workload="hd1080: " + w2["desc"], roofline=roofline_block("hd1080", B2, per2, dom2, dom2_ms, balg2, fps2))
+            if not args.no_cpu_baseline:
+                hd["cpu_baseline"] = cpu_baseline_small(O, w2["rows"], w2["cols"], w2["nfeatures"], w2["lapping"], "noise", 2, 2)
+            extras["hd1080"] = hd
             if not args.no_verify:      # the slab of the last timed call against the oracle: first / middle / last frame
                 h2n = s2[l2["n"]:l2["n"] + 4 * B2].cpu().numpy().view(np.int32); h2m = s2[l2["mono"]:l2["mono"] + 4 * B2].cpu().numpy().view(np.int32)
                 o2 = O.Oracle(w2["nfeatures"], 1.2, 8, 20, 7)
@@ -812,6 +881,7 @@ def main():
                     if not (n == len(wk) and int(h2m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
                         bad2.append(f)
                 extras["hd1080_verified"] = dict(frames=[0, B2 // 2, B2 - 1], against="oracle (CPU restatement)", bit_exact=not bad2, mismatching_frames=bad2)
+                hd["verified"] = extras["hd1080_verified"]
                 if bad2:
                     bad.append(("hd1080", bad2))
                     print("bench.py: hd1080 RESULTS DIFFER FROM THE ORACLE on frames %s" % bad2, file=sys.stderr, flush=True)
@@ -904,6 +974,52 @@ def main():
             extras["stereo_pair_us"] = round(dt * 1e6, 1)
             extras["stereo_pair_note"] = "two 640x480 frames (a stereo pair) x 1200 features per call, device-resident, back to back (median of 6 runs of 50 calls): %.0f pairs/s" % (1 / dt)
             del es
+            # (d') BASELINE.json configs[3] as a stream: 256 L+R pairs per step (the frames per step of `--workload stereo640`), per PAIR: rate, the
+            # dominant kernel's roofline (algorithmic bytes of a pair = 2 eyes), the CPU restatement beside it, one pair checked against the oracle
+            B3 = ws["batch"]
+            f3 = torch.from_numpy(synth.frames("noise", 0, 16, ws["rows"], ws["cols"])).cuda().repeat(B3 // 16, 1, 1).contiguous()
+            e3 = X.ORBextractor(ws["nfeatures"], 1.2, 8, 20, 7, max_width=ws["cols"], max_height=ws["rows"], max_batch=B3, device=local_rank)
+            e3.set_stream(stream.cuda_stream)
+            cap3 = min(e3.capacity, ws["nfeatures"] + 24)
+            l3 = sharding.slab_layout(B3, cap3)
+            s3 = torch.zeros(l3["bytes"], dtype=torch.uint8, device="cuda")
+            b3 = s3.data_ptr()
+            run3 = lambda: e3.extract_batch_device(f3, B3, ws["rows"], ws["cols"], b3 + l3["keypoints"], b3 + l3["descriptors"], b3 + l3["n"], b3 + l3["mono"],
+                                                   cap3, lapping=ws["lapping"])
+            for _ in range(3):
+                run3()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                run3()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            h3n = s3[l3["n"]:l3["n"] + 4 * B3].cpu().numpy().view(np.int32); h3m = s3[l3["mono"]:l3["mono"] + 4 * B3].cpu().numpy().view(np.int32)
+            n3 = float(h3n.mean())
+            fps3 = B3 * 10 / dt3
+            balg3 = e3.algorithmic_bytes(ws["rows"], ws["cols"], int(round(n3)))
+            per3, dom3, dom3_ms = event_profile(e3, run3, 5)
+            st = dict(pairs_per_sec=round(fps3 / 2, 1), eyes_per_sec=round(fps3, 1), ms_per_step=round(dt3 / 10 * 1e3, 4), pairs_per_step=B3 // 2,
+                      mean_keypoints_per_eye=round(n3, 1), algorithmic_bytes_per_pair=2 * balg3, workload="stereo640: " + ws["desc"],
+                      roofline=roofline_block("stereo640", B3, per3, dom3, dom3_ms, balg3, fps3))
+            if not args.no_cpu_baseline:
+                st["cpu_baseline"] = cpu_baseline_small(O, ws["rows"], ws["cols"], ws["nfeatures"], ws["lapping"], "noise", 4, 8, per_unit=2, unit="pairs/s")
+            if not args.no_verify:
+                o3 = O.Oracle(ws["nfeatures"], 1.2, 8, 20, 7)
+                bad3 = []
+                for f in (0, 1, B3 - 2, B3 - 1):      # the first and the last pair of the last timed step
+                    wm, wk, wd = o3.extract(f3[f].cpu().numpy(), ws["lapping"])
+                    n = int(h3n[f])
+                    gk = s3[l3["keypoints"] + f * cap3 * 28: l3["keypoints"] + f * cap3 * 28 + n * 28].cpu().numpy().tobytes() if 0 <= n <= cap3 else b""
+                    gd = s3[l3["descriptors"] + f * cap3 * 32: l3["descriptors"] + f * cap3 * 32 + n * 32].cpu().numpy().tobytes() if 0 <= n <= cap3 else b""
+                    if not (n == len(wk) and int(h3m[f]) == wm and gk == wk.tobytes() and gd == wd.tobytes()):
+                        bad3.append(f)
+                st["verified"] = dict(frames=[0, 1, B3 - 2, B3 - 1], against="oracle (CPU restatement)", bit_exact=not bad3, mismatching_frames=bad3)
+                if bad3:
+                    bad.append(("stereo640", bad3))
+                    print("bench.py: stereo640 RESULTS DIFFER FROM THE ORACLE on frames %s" % bad3, file=sys.stderr, flush=True)
+            extras["stereo640"] = st
+            del e3
         result = {
             "metric": "frames/sec (ORB extract, %dx%dx8-level x%d feat)" % (cols, rows, nf),
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,

@@ -12,8 +12,12 @@
 namespace orbx {
 
 __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* __restrict__ out, int slot, int nWgs, unsigned ticks) {
-    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    // The two counters are read in the SAME order at both ends (shader clock, then real time): each read is a scalar-memory round trip, and with
+    // the same order the two windows are shifted against each other by one round trip at both ends instead of one containing the other (ADVICE
+    // round 5: real time read first at the start and last at the end made the real-time window two round trips longer than the shader-clock
+    // one, i.e. the clock came out low by ~2 latencies per 50 us).  The residual is the DIFFERENCE of two round-trip latencies, not their sum.
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long r1 = r0;
     for (int i = 0; i < (1 << 20) && r1 - r0 < (unsigned long long)ticks; i++) {
         __builtin_amdgcn_s_sleep(32);

@@ -390,9 +390,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // them all be resident finishes a level soonest (640x480, one frame: 73 us with 1024 threads, 104 us with 256)
             int octT[kMaxLevels];
             // (the "resident" variants are compiled for 4 waves per SIMD = 128 VGPRs, no scratch: 1024 threads per CU-SIMD set)
-            // (... the 1024-thread one; the 512- and 256-thread resident variants are compiled for 3 waves per SIMD - no scratch -: 768 threads per CU)
-            const long long slots = 1024LL * h->numCUs, slots3 = 768LL * h->numCUs, wgs = (long long)Bn * g.nlevels;   // threads resident at once at 4 / 3 waves per SIMD
-            int residentT = wgs * 1024 <= slots ? 1024 : (wgs * 512 <= slots3 ? 512 : (wgs * 256 <= slots3 ? 256 : 0));
+            // (... the 1024-thread one; the 512- and 256-thread resident variants are compiled for 3 waves per SIMD - no scratch -: a CU then holds
+            // THREE 256-thread workgroups (one wave per SIMD each) but only ONE of 512 threads (two waves per SIMD each: a second would need four) -
+            // counted as 768 threads per CU, a third of the "resident" 512-thread workgroups queued)
+            const long long wgs = (long long)Bn * g.nlevels;
+            // one 1024-thread workgroup per CU (the 512-thread build is reached from here through `need` below, also one per CU), else three of 256
+            int residentT = wgs <= h->numCUs ? 1024 : (wgs * 256 <= 768LL * h->numCUs ? 256 : 0);
             if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
             // ... but with the first sweep done by k_fast (leaf tables) what is left of a level is a chain of barriers over a list of at most
             // quota + 3 nodes: when 256 threads still give every node of the list its own thread (the short pass forms) the small workgroup
