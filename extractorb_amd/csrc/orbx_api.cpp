@@ -35,7 +35,7 @@ void freeAll(orbx_handle* h) {
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->aux2) (void)hipStreamDestroy(h->aux2);
     if (h->probeStream) { (void)hipStreamSynchronize(h->probeStream); (void)hipStreamDestroy(h->probeStream); }
-    for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); }
+    for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); if (h->evUp[i]) (void)hipEventDestroy(h->evUp[i]); }
     void* host[] = {h->h_lap, h->h_out, h->h_in, h->h_pyr, h->h_tab};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -488,8 +488,45 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
 // (orbx_host_alloc) is copied asynchronously as it lies; a few frames of pageable input are first gathered row by row in the handle's pinned
 // staging (a hipMemcpyAsync from pageable memory stages inside the runtime and waits: 640x480 ~40 us against ~3 + ~15 here), which also turns a
 // strided cv::Mat into one copy; larger pageable batches are left to the runtime.
+// One input-copy queue per device, shared by every handle on it (batches of two or more frames).  The host-to-device link is ONE resource: two
+// handles that copy their inputs at the same time each get half of it and then compute at the same time - the ping-pong of two handles locks
+// into that in-phase state (both copy, both compute: 2.6 ms per 256 frames) as easily as into the anti-phase one (one copies while the other
+// computes: 1.5 ms), round 6, profiles/r06_host_path.md.  Through one queue the copies run one after the other at the full rate, so the
+// handles' kernels start staggered by a copy time and the anti-phase order is the only one there is.
+hipStream_t sharedUploadStream(int device) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); streams[device] = nullptr; }
+    return streams[device];      // (lives as long as the process: handles come and go)
+}
+
+// Measured (two handles alternating, 640x480, frames/s; own stream + result DMA at _begin -> this policy): 8 frames per call 56 k -> 105 k, 64: 91 k ->
+// 163 k, 256: 98-124 k -> 173 k, 512: 111 k -> 174 k; the bare copy runs at 55 GB/s = 180 k frames/s.  Small copies keep the handle's own stream
+// (the two event hops cost more than they order: 8 frames 105 k against 97 k) and bring their results back with a copy kernel instead (k_copy.hip).
+bool usesSharedUpload(const orbx_handle* h, int B, int rows, int cols) {
+    const long long limit = h->sharedUploadBytes >= 0 ? h->sharedUploadBytes : 16LL << 20;
+    return B >= 2 && (long long)B * rows * cols >= limit;
+}
+
 int uploadFrames(orbx_handle* h, int B, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride, ptrdiff_t frame_stride) {
-    hipStream_t st = h->stream;
+    hipStream_t own = h->stream;
+    hipStream_t st = own;
+    if (usesSharedUpload(h, B, rows, cols)) {
+        if (hipStream_t up = sharedUploadStream(h->device)) {
+            st = up;
+            if (hipStreamQuery(own) != hipSuccess) {      // work still queued on the handle's stream may read d_input: the copy waits for it
+                (void)hipGetLastError();
+                HIP_TRY(h, hipEventRecord(h->evUp[0], own));
+                HIP_TRY(h, hipStreamWaitEvent(st, h->evUp[0], 0));
+            }
+        }
+    }
+    struct Rejoin {      // the handle's stream continues behind the copy (on every return path)
+        orbx_handle* h; hipStream_t own, st;
+        ~Rejoin() { if (st != own) { (void)hipEventRecord(h->evUp[1], st); (void)hipStreamWaitEvent(own, h->evUp[1], 0); } }
+    } rejoin{h, own, st};
     const size_t tight = (size_t)rows * cols, total = tight * B;
     bool pinned = false;
     const double ta = g_hostTiming ? nowSec() : 0;
@@ -699,6 +736,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->fastWide = envInt("ORBX_FAST_WIDE", -1);
     h->patchBlur = envInt("ORBX_PATCH_BLUR", -1);
     h->blurSplit = envInt("ORBX_BLUR_SPLIT", -1);
+    h->sharedUploadBytes = g_aids.sharedUploadBytes;
     h->colsShape = g_aids.colsShape == 1 || g_aids.colsShape == 4 || g_aids.colsShape == 6 ? g_aids.colsShape : -1;
     h->colsCap = 0;
     for (int px : kColPx) h->colsCap += (size_t)((max_width + px / 2) / px + 1) * ((max_height + px / 2) / px + 1);
@@ -718,6 +756,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));      // (default priority: a low-priority blur only starts when everything else is done - 1928 -> 2022 us; high = default)
     for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming)); }
+    for (int i = 0; i < 2; i++) CREATE_TRY(hipEventCreateWithFlags(&h->evUp[i], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = envInt("ORBX_SPLIT", 1);
@@ -732,9 +771,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     h->policy += std::string(" RESIZE_BYTEWISE=") + (h->resizeBytewise ? "1(env)" : "0") + " OCT_ROOMY=" + (h->octRoomyForced ? "1(env)" : "0");
     h->octThreadsForced = envInt("ORBX_OCT_THREADS", 0);   // tuning switch: 256, 512 or 1024
     if (g_aids.ldsPollute >= 0) h->ldsPollute = g_aids.ldsPollute & 255;
-    if (poison >= 0 || h->ldsPollute >= 0 || h->testFailAfterFast || h->colsShape > 0)
+    if (poison >= 0 || h->ldsPollute >= 0 || h->testFailAfterFast || h->colsShape > 0 || h->sharedUploadBytes >= 0)
         h->policy += " test_aids=poison:" + std::to_string(poison) + ",lds_pollute:" + std::to_string(h->ldsPollute) + ",fail_after_fast:" + std::to_string((int)h->testFailAfterFast) +
-                     ",pyr_cols_shape:" + std::to_string(h->colsShape);
+                     ",pyr_cols_shape:" + std::to_string(h->colsShape) + ",shared_upload_bytes:" + std::to_string(h->sharedUploadBytes);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->numCUs = cus;
@@ -833,7 +872,14 @@ int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, 
     rc = enqueueBatch(h, B, h->d_input, rows, cols, cols, (long long)rows * cols, lap, h->dev.k, h->dev.d, cap, h->dev.n, h->dev.mono,
                       want_levels ? h->dev.lk : nullptr, want_levels ? h->dev.lc : nullptr);
     if (rc != ORBX_OK) return rc;
-    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, want_levels ? lo.all : lo.noLevels, hipMemcpyDeviceToHost, st));
+    if (!zc) {
+        // the results: by DMA where the input went through the device's shared copy queue (large batches), else by a kernel on the handle's
+        // stream - a result DMA enqueued now would sit in the copy queue in front of the NEXT handle's input copy and hold it until this batch's
+        // kernels are done (k_copy.hip; uploadFrames)
+        const size_t bytes = want_levels ? lo.all : lo.noLevels;
+        if (usesSharedUpload(h, B, rows, cols)) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, bytes, hipMemcpyDeviceToHost, st));
+        else launchCopyOut(st, h->d_out, h->h_out, bytes, h->numCUs);
+    }
     h->pendingB = B;
     h->lastHostB = B;
     h->pendingLevels = want_levels != 0;

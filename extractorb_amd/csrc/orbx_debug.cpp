@@ -19,6 +19,7 @@ int orbx_debug_set_option(const char* name, int value) {
     else if (n == "lds_pollute") g_aids.ldsPollute = value;
     else if (n == "fail_after_fast") g_aids.failAfterFast = value;
     else if (n == "pyr_cols_shape") g_aids.colsShape = value;
+    else if (n == "shared_upload_bytes") g_aids.sharedUploadBytes = value;
     else return ORBX_ERR_BAD_ARGUMENT;
     return ORBX_OK;
 }

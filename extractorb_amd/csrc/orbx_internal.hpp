@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,7 @@ void launchStereoFromRgbd(hipStream_t, const Keypoint*, const Keypoint*, const i
 struct GrayParams { int rows, cols, channels, redFirst, aligned; long long srcStride, srcFrame, dstStride, dstFrame; };
 void launchGray(hipStream_t, const uint8_t*, uint8_t*, const GrayParams&, int);
 void launchClockProbe(hipStream_t, unsigned long long*, int, int, unsigned);
+void launchCopyOut(hipStream_t, const void*, void*, size_t, int);
 }  // namespace orbx
 
 using namespace orbx;
@@ -99,6 +101,7 @@ struct TestAids {
     int poison = -1;          // "poison": byte every device allocation of orbx_create is filled with (no kernel may depend on what hipMalloc returns)
     int ldsPollute = -1;      // "lds_pollute": byte every CU's LDS is filled with in front of every kernel
     int colsShape = -1;       // "pyr_cols_shape": pins the workgroup shape of k_pyr_cols (1, 4, 6) so that the parity tests reach every one
+    long long sharedUploadBytes = -1;      // "shared_upload_bytes": input copies of at least this size go through the device's shared copy queue (-1: 16 MiB)
     int failAfterFast = 0;    // "fail_after_fast": the next handle's first call with leaf tables returns between k_fast and k_octree (one shot)
 };
 extern TestAids g_aids;
@@ -207,6 +210,8 @@ struct orbx_handle {
     // the internal stream and the events of the two-half overlap (enqueueBatch)
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    long long sharedUploadBytes = -1;      // test aid "shared_upload_bytes" as orbx_create read it (-1: the default limit, uploadFrames)
+    hipEvent_t evUp[2] = {nullptr, nullptr};      // uploadFrames: the handle's stream -> the device's shared input-copy queue -> back
     hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
     hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
     int splitMode = 1;                 // ORBX_SPLIT: 1 (default) = large batches overlap their blur with FAST + quad-tree on a side stream (the largest also stagger

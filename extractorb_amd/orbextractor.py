@@ -212,6 +212,7 @@ def debug_reset_options():
     debug_set_option("lds_pollute", -1)
     debug_set_option("fail_after_fast", 0)
     debug_set_option("pyr_cols_shape", -1)
+    debug_set_option("shared_upload_bytes", -1)
 
 
 # ---- handle-free host helpers (no GPU needed) -------------------------------------------------------------

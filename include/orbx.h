@@ -135,7 +135,8 @@ int orbx_extract_batch(orbx_handle* h, int n_frames, const uint8_t* imgs, int ro
 /* Asynchronous host-buffer form.  _begin enqueues the H2D copy of the frames, the whole path and the D2H copy of
  * the results (into pinned staging owned by the handle) and returns without waiting; _end waits for that batch and
  * copies the results into the caller's arrays (same layout as orbx_extract_batch).  One batch in flight per handle:
- * two handles used alternately overlap the transfers of one batch with the kernels of the other.  The H2D copy is
+ * two handles used alternately overlap the transfers of one batch with the kernels of the other (input copies of 16 MiB and more go through
+ * ONE copy queue per device, shared by its handles, so that they run one after the other at the link's full rate: DESIGN.md).  The H2D copy is
  * only truly asynchronous from pinned memory (orbx_host_alloc).  want_levels != 0 also brings back the per-level
  * arrays.  orbx_extract_batch == _begin + _end. */
 int orbx_extract_batch_begin(orbx_handle* h, int n_frames, const uint8_t* imgs, int rows, int cols, ptrdiff_t stride,
@@ -383,7 +384,8 @@ int orbx_debug_last_split_level(const orbx_handle* h);
  * setting.  name = "poison" (byte every device allocation of orbx_create is filled with; -1 = off), "lds_pollute" (byte every CU's LDS is
  * filled with in front of every kernel; -1 = off), "fail_after_fast" (1: the next handle's first small-batch call returns ORBX_ERR_HIP
  * between the FAST and the quad-tree launch, once), "pyr_cols_shape" (1, 4 or 6: pins the workgroup shape of k_pyr_cols; -1 = by the grid
- * size).  Unknown name: ORBX_ERR_BAD_ARGUMENT. */
+ * size), "shared_upload_bytes" (host-buffer batches whose input is at least this large copy it through the device's shared copy queue
+ * and bring the results back by DMA, smaller ones use the handle's stream and a copy kernel; -1 = 16 MiB).  Unknown name: ORBX_ERR_BAD_ARGUMENT. */
 int orbx_debug_set_option(const char* name, int value);
 
 /* The launch-policy switches as orbx_create read them, "NAME=value" separated by blanks, "(env)" behind a value that came from an ORBX_<NAME>

@@ -334,10 +334,16 @@ def test_fast_on_dense_natural_and_sparse_content():
             assert_same_result(out[f][:3], want, "%s frame %d" % (variant, f))
 
 
-def test_async_host_api_with_two_handles_and_pinned_input():
-    """orbx_extract_batch_begin / _end called directly (the test was lost with the prefilter variant): two handles in flight, a
+@pytest.mark.parametrize("route", ["default", "shared-queue", "own-stream"])
+def test_async_host_api_with_two_handles_and_pinned_input(route):
+    """(round 6) route: input copies of 16 MiB and more go through ONE copy queue per device shared by its handles and bring their results back by DMA,
+    smaller ones stay on the handle's stream and bring them back with a copy kernel (orbx_api.cpp: uploadFrames, k_copy.hip) - "shared-queue" /
+    "own-stream" force either route for every batch of this test through the test aid `shared_upload_bytes`.
+    orbx_extract_batch_begin / _end called directly (the test was lost with the prefilter variant): two handles in flight, a
     second begin on a busy handle and an end without a begin are errors, and every branch of the upload - pinned memory copied as it lies,
     pageable memory staged through the handle's pinned block, padded rows as 2-D copies - gives the reference result."""
+    if route != "default":
+        X.debug_set_option("shared_upload_bytes", 0 if route == "shared-queue" else 1 << 30)      # (conftest.py resets the aids after the test)
     B = 3
     fa, fb = synth.frames("textured", 200, B, 480, 640), synth.frames("noise", 300, B, 480, 640)
     pa, pb = X.pinned_empty(fa.shape), X.pinned_empty(fb.shape)
@@ -376,7 +382,31 @@ def test_async_host_api_with_two_handles_and_pinned_input():
         want = oracle_run(big[f])[1]
         assert_same_result(rc[f], want, "large pageable frame %d" % f)
         assert_same_result(rw[f], want, "large pageable padded frame %d" % f)
-    X.pinned_free(pa); X.pinned_free(pb); X.pinned_free(pw)
+    # the ping-pong a host-fed stream runs (bench.py: host_to_host_fps): two handles alternating for a dozen batches whose content changes every time,
+    # every batch's every frame against the single-frame result of the same extractor parameters; the views are read before the handle is used again
+    Bp = 6
+    stream = [synth.frames("noise" if i % 2 else "natural", 500 + i, Bp, 480, 640) for i in range(6)]
+    ref = X.ORBextractor(1000, max_batch=Bp)
+    want = [ref.extract_batch(fr) for fr in stream]
+    pins = [X.pinned_empty(stream[0].shape), X.pinned_empty(stream[0].shape)]
+    hs = [X.ORBextractor(1000, max_batch=Bp), X.ORBextractor(1000, max_batch=Bp)]
+    got = [None] * len(stream)
+
+    def collect(view):      # (kps[B, cap], desc[B, cap, 32], n[B], mono[B]) views of the pinned slab -> copies, before the handle is used again
+        kps, desc, n, mono = view
+        return [(int(mono[f]), kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(Bp)]
+
+    pins[0][...] = stream[0]
+    hs[0].extract_batch_begin(pins[0])
+    for i in range(1, len(stream)):
+        pins[i & 1][...] = stream[i]
+        hs[i & 1].extract_batch_begin(pins[i & 1])
+        got[i - 1] = collect(hs[(i - 1) & 1].extract_batch_end_view())
+    got[-1] = collect(hs[(len(stream) - 1) & 1].extract_batch_end_view())
+    for i in range(len(stream)):
+        for f in range(Bp):
+            assert_same_result(got[i][f], want[i][f][:3], "%s: ping-pong batch %d frame %d" % (route, i, f))
+    X.pinned_free(pa); X.pinned_free(pb); X.pinned_free(pw); X.pinned_free(pins[0]); X.pinned_free(pins[1])
 
 
 @pytest.mark.parametrize("switch,value", [("ORBX_OCT_THREADS", "256"), ("ORBX_OCT_THREADS", "512"), ("ORBX_OCT_THREADS", "1024"),
