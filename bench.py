@@ -793,18 +793,33 @@ def main():
             pin = [X.pinned_empty((Bh, rows, cols)) for _ in range(2)]
             for a in pin:
                 a[...] = frames[:Bh]
-            hx[0].extract_batch_begin(pin[0]); hx[1].extract_batch_begin(pin[1]); hx[0].extract_batch_end(); hx[1].extract_batch_end()
+            # (the C ABI called directly through ctypes, as a C++ host would call it: the Python mirror's per-call argument handling - ~0.1 ms - is
+            # a quarter of a 64-frame batch's 0.4 ms and would be what the figure measures)
+            import ctypes as C_
+            lap_h = (C_.c_int * (2 * Bh))(*([int(wl["lapping"][0]), int(wl["lapping"][1])] * Bh))
+            vk_, vd_, vn_, vm_, vc_ = C_.c_void_p(), C_.c_void_p(), C_.c_void_p(), C_.c_void_p(), C_.c_int()
+
+            def h_begin(i):
+                rc_ = hx[i]._L.orbx_extract_batch_begin(hx[i]._h, Bh, pin[i].ctypes.data_as(C_.c_void_p), rows, cols, cols, rows * cols, lap_h, 0)
+                assert rc_ == 0, rc_
+
+            def h_end(i):
+                rc_ = hx[i]._L.orbx_extract_batch_end_view(hx[i]._h, C_.byref(vk_), C_.byref(vd_), C_.byref(vc_), C_.byref(vn_), C_.byref(vm_))
+                assert rc_ == 0, rc_
+
+            for i in range(4):      # the timed call shape, untimed
+                h_begin(i & 1); h_end(i & 1)
             reps = 64
             t1 = time.perf_counter()
-            hx[0].extract_batch_begin(pin[0], lapping=wl["lapping"])
+            h_begin(0)
             for i in range(1, reps):
-                hx[i & 1].extract_batch_begin(pin[i & 1], lapping=wl["lapping"])
-                hx[(i - 1) & 1].extract_batch_end_view()
-            hx[(reps - 1) & 1].extract_batch_end_view()
+                h_begin(i & 1)
+                h_end((i - 1) & 1)
+            h_end((reps - 1) & 1)
             dt = time.perf_counter() - t1
             extras["host_to_host_fps"] = round(Bh * reps / dt, 1)
-            extras["host_to_host_note"] = ("pinned host frames -> H2D -> whole path -> D2H of keypoints+descriptors, %d frames per call, "
-                                           "two handles alternating (PCIe-inclusive; not `value`)" % Bh)
+            extras["host_to_host_note"] = ("pinned host frames -> H2D -> whole path -> results in pinned host memory, %d frames per call, two handles alternating "
+                                           "(orbx_extract_batch_begin / _end_view through ctypes; PCIe-inclusive; not `value`)" % Bh)
             # ... and what the input copy alone can do on this box: the same 64-frame slab as a bare pinned hipMemcpyAsync, two streams alternating,
             # nothing else running.  host_to_host_fps x frame bytes against it says whether the host-fed rate is the link's or the pipeline's
             # 

@@ -19,6 +19,7 @@ struct FrameFinishParams {
     CameraParams cam;
     float minX, minY, wInv, hInv;   // mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
     int capacity;
+    int rawGrid;                    // the Nleft != -1 branch of AssignFeaturesToGrid (:404-414): the cells come from mvKeys / mvKeysRight, not from mvKeysUn
 };
 
 constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;   // FRAME_GRID_COLS/ROWS, inc/Frame.h:39-40
@@ -70,10 +71,12 @@ __global__ __launch_bounds__(1024) void k_frame_finish(const Keypoint* __restric
     __syncthreads();
     for (int i = tid; i < N; i += 1024) {
         Keypoint k = in[i];
+        const float rawX = k.x, rawY = k.y;
         if (p.cam.k1 != 0.0f) undistortPoint(p.cam, k.x, k.y, &k.x, &k.y);        // else mvKeysUn = mvKeys (:750-754)
         un[i] = k;
-        const int posX = (int)roundf(__fmul_rn(__fsub_rn(k.x, p.minX), p.wInv));   // PosInGrid (:728-729)
-        const int posY = (int)roundf(__fmul_rn(__fsub_rn(k.y, p.minY), p.hInv));
+        const float gx = p.rawGrid ? rawX : k.x, gy = p.rawGrid ? rawY : k.y;      // (:405-407: mvKeysUn, or the eye's own raw keys)
+        const int posX = (int)roundf(__fmul_rn(__fsub_rn(gx, p.minX), p.wInv));   // PosInGrid (:728-729)
+        const int posY = (int)roundf(__fmul_rn(__fsub_rn(gy, p.minY), p.hInv));
         const bool ok = !(posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows);
         const int cell = ok ? posX * kGridRows + posY : -1;
         cellOf[i] = (short)cell;

@@ -139,9 +139,15 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     // blurs the level (table [2] below) and k_describe reads the blurred level.  ORBX_BLUR_SPLIT=L pins the level, 0 turns the split off.
     int splitLevel = 0;
     if (h->blurSplit > 0) splitLevel = h->blurSplit;
-    else if (h->blurSplit < 0 && kSplitRatioNum > 0)
+    else if (h->blurSplit < 0 && kSplitRatioNum > 0) {
         for (int l = 1; l < g.nlevels && !splitLevel; l++)
             if ((long long)g.lv[l].quota * 37 * 36 * kSplitRatioDen > (long long)kSplitRatioNum * g.lv[l].w * g.lv[l].h) splitLevel = l;
+        // ... if those levels hold a quarter of the features: two more launches for the coarsest level alone cost more than its patches (128 x
+        // 1280x720 x 1500, where only level 7 - 6 % of the features - is past 1.5: 1146 us per step split, 1128 unsplit)
+        int tail = 0;
+        for (int l = splitLevel; splitLevel && l < g.nlevels; l++) tail += g.lv[l].quota;
+        if (4 * tail < h->nfeatures) splitLevel = 0;
+    }
     if (splitLevel >= g.nlevels) splitLevel = 0;
     int nBlurLanes[3] = {0, 0, 0};
     size_t blurItemOff[3] = {0, 0, 0}, blurLaneOff[3] = {0, 0, 0};
@@ -259,8 +265,12 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // levels exist (or are owed to the FAST launch: blurOwed) and are used.
     const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
     const long long patchPx4 = (long long)h->nfeatures * 43 * 37 * 4;      // 4 x the patches' pixels of horizontal pass
+    // Round 6: with the coarse levels split off to k_blur (installGeometry: splitLevel) the per-keypoint form also wins earlier and further - from
+    // 120 Mpx of pyramid per call (128 x 640x480: 468 -> 459 us; 64 frames: 232 -> 248, not taken) and up to a ratio of 2.25 (512 x 640x480 x 1200
+    // features, the stereo stream, 2.0: 1758 -> 1743 us).
+    const bool midBatch = (long long)g.sumPixels * B >= h->splitMinPixels;
     const bool patchBlur = !(stages & kStageFront) ? (h->lastBlurForm == 3 || h->lastBlurForm == 5)
-                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (patchPx4 <= 5LL * g.sumPixels || (bigBatch && patchPx4 <= 7LL * g.sumPixels))));
+                         : (h->patchBlur > 0 || (h->patchBlur < 0 && !blurRidesWithFast(B) && (patchPx4 <= 5LL * g.sumPixels || (midBatch && patchPx4 <= 9LL * g.sumPixels))));
     // ... split by level: levels >= splitL are blurred by k_blur and described from the blurred level (installGeometry: splitLevel)
     const int splitL = !patchBlur ? 0 : (!(stages & kStageFront) ? (h->lastBlurForm == 5 ? h->lastSplitLevel : 0)
                                                                    : (h->splitLevel > 0 && h->splitLevel < g.nlevels && h->nBlurLanes[2] > 0 ? h->splitLevel : 0));
@@ -413,11 +423,16 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // image area were measured with the sweep inside the kernel, where a level-0 workgroup reads ~60 k candidates
             const int queuedT = lt.hist && !h->octThreadsForced ? 256 : 0;
             for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : (queuedT ? queuedT : h->octThreads[l]);
+            // ... in its scratch-free build (three workgroups per CU instead of six) while the launch is at most four workgroups per CU: little queues
+            // behind the first round, and no spilled register is touched.  Round 6, A/B in one call (k_octree_256 -> _256r, us per launch; step): 128 x
+            // 1080p 51 -> 33 (2291-2294 -> 2271-2278), 64 x 1080p 28 -> 20, 128 x 720p 47 -> 32 (1167-1171 -> 1151-1157), 128 x 640x480 30 -> 28.5
+            // (472-473 -> 468); 256 x 640x480 equal; 512 x 640x480 112 -> 118 (1663 -> 1699: the spilling build keeps its place there, six per CU)
+            const bool roomy = residentT != 0 || h->octRoomyForced || (queuedT == 256 && wgs <= 4LL * h->numCUs);
             pollute(st);
-            h->lastKernel[S_OCTREE] = h->d_octArena ? "k_octree_1024g" : "k_octree_" + std::to_string(octT[0]) + (residentT != 0 || h->octRoomyForced ? "r" : "");
+            h->lastKernel[S_OCTREE] = h->d_octArena ? "k_octree_1024g" : "k_octree_" + std::to_string(octT[0]) + (roomy ? "r" : "");
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, residentT != 0 || h->octRoomyForced, f0, Bn, h->d_octArena, lt);
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, roomy, f0, Bn, h->d_octArena, lt);
             h->leafDirty = false;
         }
         auto joinBlur = [&]() {

@@ -46,7 +46,7 @@ struct StereoParams {
     int nlevels, capacity, rowCap;
 };
 struct CameraParams { float fx, fy, cx, cy, k1, k2, p1, p2, k3; };
-struct FrameFinishParams { CameraParams cam; float minX, minY, wInv, hInv; int capacity; };
+struct FrameFinishParams { CameraParams cam; float minX, minY, wInv, hInv; int capacity, rawGrid; };      // (k_frame.hip holds the same layout)
 void launchFrameFinish(hipStream_t, const Keypoint*, const int*, const FrameFinishParams&, Keypoint*, int*, int*, int*, int);
 void launchStereo(hipStream_t, const LevelGeom*, const uint8_t*, const Keypoint*, const uint8_t*, const int*, const StereoParams&,
                   int, int*, unsigned short*, float*, float*, int*, int*, int);

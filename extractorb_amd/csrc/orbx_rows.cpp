@@ -168,9 +168,24 @@ int orbx_gray_from_color_device(orbx_handle* h, int n_frames, const uint8_t* d_s
     return ORBX_OK;
 }
 
+static int frameFinish(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity, const orbx_camera* cam,
+                       const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off, int* d_grid_idx, int* d_n_inside, int rawGrid);
+
 int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
                              const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
                              int* d_grid_idx, int* d_n_inside) {
+    return frameFinish(h, n_frames, d_kps, d_n_out, capacity, cam, bounds4, d_kps_un, d_grid_off, d_grid_idx, d_n_inside, 0);
+}
+
+int orbx_frame_finish_two_eyes_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
+                                      const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
+                                      int* d_grid_idx, int* d_n_inside) {
+    if (n_pairs < 1 || n_pairs > (1 << 29)) return h ? fail(h, ORBX_ERR_BAD_ARGUMENT, "n_pairs < 1") : ORBX_ERR_BAD_ARGUMENT;
+    return frameFinish(h, 2 * n_pairs, d_kps, d_n_out, capacity, cam, bounds4, d_kps_un, d_grid_off, d_grid_idx, d_n_inside, 1);
+}
+
+static int frameFinish(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity, const orbx_camera* cam,
+                       const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off, int* d_grid_idx, int* d_n_inside, int rawGrid) {
     if (!h) return ORBX_ERR_BAD_ARGUMENT;
     if (!d_kps || !d_n_out || !cam || !bounds4 || !d_kps_un || !d_grid_off || !d_grid_idx || !d_n_inside || capacity < 1 ||
         n_frames < 1 || !(cam->fx > 0.f) || !(cam->fy > 0.f) || !(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2]))
@@ -183,6 +198,7 @@ int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* 
     p.wInv = 64.0f / (bounds4[1] - bounds4[0]);      // mfGridElementWidthInv  (Frame.cc:339)
     p.hInv = 48.0f / (bounds4[3] - bounds4[2]);      // mfGridElementHeightInv (Frame.cc:340)
     p.capacity = capacity;
+    p.rawGrid = rawGrid;
     {
         Prof pr(h, S_FRAME);
         launchFrameFinish(h->stream, (const Keypoint*)d_kps, d_n_out, p, (Keypoint*)d_kps_un, d_grid_off, d_grid_idx, d_n_inside, n_frames);

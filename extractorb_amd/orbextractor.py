@@ -167,6 +167,7 @@ def load_library():
     L.orbx_stereo_match_last.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int, vp]
     L.orbx_compute_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orbx_frame_finish_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.orbx_frame_finish_two_eyes_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbx_search_for_initialization_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp,
                                                         vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
     L.orbx_stereo_from_rgbd_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
@@ -442,6 +443,15 @@ class ORBextractor:
         cam = np.ascontiguousarray(cam, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
         self._check(self._L.orbx_frame_finish_device(self._h, n_frames, dp(d_kps), dp(d_n), capacity, _ptr(cam), _ptr(bounds),
                                                      dp(d_kps_un), dp(d_grid_off), dp(d_grid_idx), dp(d_n_inside)))
+
+    def frame_finish_two_eyes_device(self, n_pairs, d_kps, d_n, capacity, cam, bounds, d_kps_un, d_grid_off, d_grid_idx, d_n_inside):
+        """AssignFeaturesToGrid's Nleft != -1 branch (reference src/Frame.cc:404-414: mGrid / mGridRight from the RAW keys of frames 2p / 2p + 1)
+        + UndistortKeyPoints, on device buffers of 2 * n_pairs frames."""
+        def dp(x):
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        cam = np.ascontiguousarray(cam, np.float32); bounds = np.ascontiguousarray(bounds, np.float32)
+        self._check(self._L.orbx_frame_finish_two_eyes_device(self._h, n_pairs, dp(d_kps), dp(d_n), capacity, _ptr(cam), _ptr(bounds),
+                                                              dp(d_kps_un), dp(d_grid_off), dp(d_grid_idx), dp(d_n_inside)))
 
     def search_for_initialization_device(self, n_pairs, frames1, frames2, d_kps_un, d_desc, d_n, capacity, d_grid_off, d_grid_idx,
                                          bounds, d_prev_matched, d_matches12, d_n_matches, window=100, nnratio=0.9,

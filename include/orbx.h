@@ -224,7 +224,7 @@ typedef struct orbx_camera { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_ca
 int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float* bounds4);
 
 /* Replaces Frame::UndistortKeyPoints (src/Frame.cc:748-782) and Frame::AssignFeaturesToGrid (:383-417, the
- * Nleft == -1 case) + PosInGrid (:726-736) for n_frames frames of device-resident extraction results:
+ * Nleft == -1 case; the other one: orbx_frame_finish_two_eyes_device below) + PosInGrid (:726-736) for n_frames frames of device-resident extraction results:
  *   d_kps_un[f*capacity + i]            : mvKeysUn
  *   d_grid_off[f*(64*48+1) + x*48 + y]  : first slot of mGrid[x][y]; [.. + 64*48] = keypoints inside the grid
  *   d_grid_idx[f*capacity + slot]       : keypoint indices, increasing inside a cell (push_back order)
@@ -233,6 +233,14 @@ int orbx_compute_image_bounds(const orbx_camera* cam, int cols, int rows, float*
 int orbx_frame_finish_device(orbx_handle* h, int n_frames, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
                              const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
                              int* d_grid_idx, int* d_n_inside);
+/* The Nleft != -1 branch of Frame::AssignFeaturesToGrid (src/Frame.cc:404-414; the two-camera Frame constructor, :1045-1122, which assigns BEFORE
+ * it undistorts): for n_pairs pairs of a device-resident batch - frame 2p = the left eye (mvKeys), frame 2p + 1 = the right eye (mvKeysRight) -
+ * the cells come from each eye's RAW keypoints: the left frame's CSR is mGrid (indices i < Nleft), the right frame's is mGridRight (indices
+ * i - Nleft, i.e. the right eye's own); d_kps_un still receives UndistortKeyPoints' mvKeysUn of both eyes.  Same array layout as above, for
+ * 2 * n_pairs frames.  (The camera model, matcher twins and frustum tests of that rig are out of scope: SURVEY.md §2 #13.) */
+int orbx_frame_finish_two_eyes_device(orbx_handle* h, int n_pairs, const orbx_keypoint* d_kps, const int* d_n_out, int capacity,
+                                      const orbx_camera* cam, const float* bounds4, orbx_keypoint* d_kps_un, int* d_grid_off,
+                                      int* d_grid_idx, int* d_n_inside);
 
 /* ---- next row: monocular initialisation matching ------------------------------------------
  * Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821; caller src/Tracking.cc:2065-2066 with

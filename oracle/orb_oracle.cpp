@@ -1017,6 +1017,37 @@ int oracle_frame_finish(const void* cam_, const void* kps_, int N, const float* 
     return inside;
 }
 
+// Frame::AssignFeaturesToGrid with Nleft != -1 (src/Frame.cc:383-417, the branch :404-414 of the two-camera constructor :1045-1122, which calls it
+// BEFORE UndistortKeyPoints): kp = i < Nleft ? mvKeys[i] : mvKeysRight[i - Nleft] - the RAW keys -, left keys into mGrid with index i, right keys
+// into mGridRight with index i - Nleft.  Both grids as the CSR of oracle_frame_finish.  Returns the keypoints inside mGrid; *insideRight those inside mGridRight.
+int oracle_assign_features_two_eyes(const void* kpsLeft_, int Nleft, const void* kpsRight_, int Nright, const float* bounds, int* gridOff, int* gridIdx,
+                                    int* gridOffRight, int* gridIdxRight, int* insideRight) {
+    const KeyPoint* mvKeys = (const KeyPoint*)kpsLeft_;
+    const KeyPoint* mvKeysRight = (const KeyPoint*)kpsRight_;
+    const int COLS = 64, ROWS = 48, N = Nleft + Nright;
+    const float mnMinX = bounds[0], mnMaxX = bounds[1], mnMinY = bounds[2], mnMaxY = bounds[3];
+    const float wInv = static_cast<float>(COLS) / static_cast<float>(mnMaxX - mnMinX);
+    const float hInv = static_cast<float>(ROWS) / static_cast<float>(mnMaxY - mnMinY);
+    std::vector<std::vector<int>> mGrid(COLS * ROWS), mGridRight(COLS * ROWS);
+    int nl = 0, nr = 0;
+    for (int i = 0; i < N; i++) {
+        const KeyPoint& kp = (i < Nleft) ? mvKeys[i] : mvKeysRight[i - Nleft];                                          // :405-407
+        const int posX = (int)std::round((kp.x - mnMinX) * wInv), posY = (int)std::round((kp.y - mnMinY) * hInv);       // PosInGrid :728-729
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        if (i < Nleft) { mGrid[posX * ROWS + posY].push_back(i); nl++; }                                                // :411-412
+        else { mGridRight[posX * ROWS + posY].push_back(i - Nleft); nr++; }                                             // :413-414
+    }
+    int o = 0, orr = 0;
+    for (int cell = 0; cell < COLS * ROWS; cell++) {
+        gridOff[cell] = o; gridOffRight[cell] = orr;
+        for (int i : mGrid[cell]) gridIdx[o++] = i;
+        for (int i : mGridRight[cell]) gridIdxRight[orr++] = i;
+    }
+    gridOff[COLS * ROWS] = o; gridOffRight[COLS * ROWS] = orr;
+    *insideRight = nr;
+    return nl;
+}
+
 // ---------------------------------------------------------------------------------------------
 // "Next" row: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:706-821) with
 // Frame::GetFeaturesInArea (src/Frame.cc:655-724) and ComputeThreeMaxima (src/ORBmatcher.cc:2303-2344).

@@ -73,6 +73,8 @@ def lib():
         L.oracle_image_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
         L.oracle_frame_finish.restype = C.c_int
         L.oracle_frame_finish.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+        L.oracle_assign_features_two_eyes.restype = C.c_int
+        L.oracle_assign_features_two_eyes.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         L.oracle_search_for_initialization.restype = C.c_int
         L.oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
         L.oracle_features_in_area.restype = C.c_int
@@ -211,6 +213,18 @@ def frame_finish(cam, kps, bounds):
     n = lib().oracle_frame_finish(_ptr(np.ascontiguousarray(cam, np.float32)), _ptr(kps), len(kps),
                                   _ptr(np.ascontiguousarray(bounds, np.float32)), _ptr(un), _ptr(off), _ptr(idx))
     return un, off, idx[:n].copy()
+
+
+def assign_features_two_eyes(kps_left, kps_right, bounds):
+    """Frame::AssignFeaturesToGrid, the Nleft != -1 branch (reference src/Frame.cc:404-414): raw keys of both eyes.
+    Returns ((mGrid offsets[3073], indices), (mGridRight offsets[3073], indices relative to the right eye))."""
+    kl = np.ascontiguousarray(kps_left, KEYPOINT_DTYPE); kr = np.ascontiguousarray(kps_right, KEYPOINT_DTYPE)
+    off = np.zeros(64 * 48 + 1, np.int32); idx = np.zeros(max(len(kl), 1), np.int32)
+    offr = np.zeros(64 * 48 + 1, np.int32); idxr = np.zeros(max(len(kr), 1), np.int32)
+    nr = C.c_int()
+    nl = lib().oracle_assign_features_two_eyes(_ptr(kl), len(kl), _ptr(kr), len(kr), _ptr(np.ascontiguousarray(bounds, np.float32)),
+                                               _ptr(off), _ptr(idx), _ptr(offr), _ptr(idxr), C.byref(nr))
+    return (off, idx[:nl].copy()), (offr, idxr[:nr.value].copy())
 
 
 def features_in_area(kps_un, grid_off, grid_idx, bounds, x, y, r, min_level=-1, max_level=-1):

@@ -105,3 +105,72 @@ def test_gpu_frame_finish_equals_oracle(cam):
         assert un.tobytes() == un_o.tobytes(), "mvKeysUn differs"
         assert d_off[f].cpu().numpy().tolist() == off_o.tolist()
         assert int(d_in[f]) == len(idx_o) and d_idx[f, :len(idx_o)].cpu().numpy().tolist() == idx_o.tolist()
+
+
+def test_oracle_two_eyes_grid_against_an_independent_statement():
+    """AssignFeaturesToGrid with Nleft != -1 (reference src/Frame.cc:404-414): left keys (raw, not undistorted) into mGrid with their own indices,
+    right keys into mGridRight with indices i - Nleft.  Independent numpy statement: a stable bucket sort of each eye's raw positions."""
+    rng = np.random.default_rng(5)
+    c = O.camera(**EUROC)
+    b = O.image_bounds(c, 752, 480)
+    pl = np.stack([rng.uniform(-5, 760, 900), rng.uniform(-5, 490, 900)], 1).astype(np.float32)
+    pr = np.stack([rng.uniform(-5, 760, 700), rng.uniform(-5, 490, 700)], 1).astype(np.float32)
+    (offl, idxl), (offr, idxr) = O.assign_features_two_eyes(keys(pl), keys(pr), b)
+    wInv, hInv = np.float32(64.0) / np.float32(b[1] - b[0]), np.float32(48.0) / np.float32(b[3] - b[2])
+    for pts, off, idx in ((pl, offl, idxl), (pr, offr, idxr)):
+        px = np.floor(((pts[:, 0] - b[0]) * wInv).astype(np.float64) + 0.5).astype(int)      # round() of a non-negative product; negatives fall out either way
+        py = np.floor(((pts[:, 1] - b[2]) * hInv).astype(np.float64) + 0.5).astype(int)
+        neg = ((pts[:, 0] - b[0]) * wInv < -0.5) | ((pts[:, 1] - b[2]) * hInv < -0.5)
+        ok = ~neg & (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+        assert off[-1] == ok.sum() == len(idx)
+        cell = px * 48 + py
+        for c_ in np.unique(cell[ok]):
+            assert idx[off[c_]:off[c_ + 1]].tolist() == np.nonzero(ok & (cell == c_))[0].tolist()
+    # ... and it is NOT the Nleft == -1 grid of a distorted camera: that one buckets the undistorted keys
+    _, off_un, _ = O.frame_finish(c, keys(pl), b)
+    assert off_un.tolist() != offl.tolist()
+    # with an undistorted camera the two branches agree per eye
+    cp = O.camera(**PINHOLE)
+    bp = O.image_bounds(cp, 640, 480)
+    (o1, i1), (o2, i2) = O.assign_features_two_eyes(keys(pl), keys(pr), bp)
+    for pts, off, idx in ((pl, o1, i1), (pr, o2, i2)):
+        _, off_m, idx_m = O.frame_finish(cp, keys(pts), bp)
+        assert off_m.tolist() == off.tolist() and idx_m.tolist() == idx.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam", [EUROC, TUM1, PINHOLE])
+def test_gpu_two_eyes_grid_equals_oracle(cam):
+    """orbx_frame_finish_two_eyes_device on extracted stereo pairs (frame 2p = left, 2p + 1 = right; 1200 features per eye, lapping {0, 0}): mGrid /
+    mGridRight from the raw keys against the oracle's restatement of Frame.cc:404-414, mvKeysUn against UndistortKeyPoints - bit-exact."""
+    import torch
+    P = 2
+    B = 2 * P
+    frames = synth.frames("textured", 80, B, 480, 640)
+    ex = X.ORBextractor(1200, max_batch=B)
+    cap = ex.capacity
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_img = torch.from_numpy(frames).cuda()
+    d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_m = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img, B, 480, 640, d_k, d_d, d_n, d_m, cap, lapping=(0, 0))
+    c = X.camera(**cam)
+    bounds = X.compute_image_bounds(c, 640, 480)
+    d_un = torch.zeros_like(d_k); d_off = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_idx = torch.zeros((B, cap), dtype=torch.int32, device="cuda"); d_in = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.frame_finish_two_eyes_device(P, d_k, d_n, cap, c, bounds, d_un, d_off, d_idx, d_in)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    view = lambda t, f: t[f, :n[f]].cpu().numpy().view(np.uint8).reshape(-1, 28).copy().view(X.KEYPOINT_DTYPE).reshape(-1)
+    oc = O.camera(**cam)
+    ob = O.image_bounds(oc, 640, 480)
+    for p in range(P):
+        kl, kr = view(d_k, 2 * p), view(d_k, 2 * p + 1)
+        (offl, idxl), (offr, idxr) = O.assign_features_two_eyes(kl, kr, ob)
+        for f, off_o, idx_o, k in ((2 * p, offl, idxl, kl), (2 * p + 1, offr, idxr, kr)):
+            assert d_off[f].cpu().numpy().tolist() == off_o.tolist(), "pair %d frame %d: grid offsets" % (p, f)
+            assert int(d_in[f]) == len(idx_o) and d_idx[f, :len(idx_o)].cpu().numpy().tolist() == idx_o.tolist()
+            un_o, _, _ = O.frame_finish(oc, k, ob)
+            assert view(d_un, f).tobytes() == un_o.tobytes(), "mvKeysUn differs"
+    with pytest.raises(X.OrbxError):
+        ex.frame_finish_two_eyes_device(0, d_k, d_n, cap, c, bounds, d_un, d_off, d_idx, d_in)
