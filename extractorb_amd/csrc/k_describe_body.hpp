@@ -217,8 +217,8 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
     const uint8_t* pyrL = pyr + lv[level].pyrOff + (long long)f * lv[level].pyrFrameBytes;      // wave-uniform bases:
     const uint8_t* blurL = blur + lv[level].blurOff + (long long)f * lv[level].blurFrameBytes;   // lanes add 32-bit offsets
     const uint2 e = active ? sel[(long long)f * selPerFrame + slot] : make_uint2(0u, 0u);
-    int kx = e.x & 0xfff, ky = (e.x >> 12) & 0xfff;
-    const float response = (float)(e.x >> 24);
+    int kx = e.x & 0xffff, ky = e.x >> 16;      // (orbx_device.hpp: the selection entry)
+    const float response = (float)(e.y >> 24);
     // the quad-tree only emits points of the FAST rectangle; clamp anyway so a corrupted entry (or an idle half)
     // can never turn into an out-of-bounds gather
     kx = min(max(kx, kEdge), gw - kEdge - 1);
@@ -395,7 +395,7 @@ __device__ __forceinline__ void describeBlock(const LevelGeom* __restrict__ lv, 
     if (!active) return;
 
     // ---- placement (:1137-1158): non-lapping keys fill from the front, lapping keys from the back ----
-    const int lapRank = (int)(e.y & 0x7fffffff), isLap = (int)(e.y >> 31);
+    const int lapRank = (int)(e.y & 0x7fffff), isLap = (int)((e.y >> 23) & 1);
     const int lapBefore = lapBase + lapRank;
     const int monoBefore = (seqBase - lapBase) + (i - lapRank);
     const int at = isLap ? total - 1 - lapBefore : monoBefore;

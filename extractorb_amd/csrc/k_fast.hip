@@ -35,11 +35,11 @@ namespace orbx {
 
 // TS: LDS row stride of the pixel tile and of the score tile (bytes).  ROWS: max ROI rows.  FUSE_BLUR: chunks past tail.fastChunks run
 // blur lanes (short-chain form) instead of FAST cells.
-template <int TS, int ROWS, bool FUSE_BLUR = false>
+template <int TS, int ROWS, bool FUSE_BLUR = false, bool BIG = false>
 __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* __restrict__ cells, int nCells,
                                                const LevelGeom* __restrict__ lv, int nlevels,
                                                const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                               unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
+                                               typename CandFmt<BIG>::T* __restrict__ candSeg, unsigned* __restrict__ cellCount, int f0, int nFrames,
                                                BlurTail tail, LeafTables lt) {
     using L = FastLds<TS, ROWS>;
     __shared__ __align__(16) uint8_t smem[L::kTiles];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, ORBX_FAST_WAVES) void k_fast(const CellDesc* _
             return;
         }
     }
-    fastCell<TS, ROWS>(cells, nCells, lv, pyr, iniTh, minTh, candSeg, cellCount, lt, smem, scoreS, codeL, chunk, f0 + fr);
+    fastCell<TS, ROWS, BIG>(cells, nCells, lv, pyr, iniTh, minTh, candSeg, cellCount, lt, smem, scoreS, codeL, chunk, f0 + fr);
 }
 
 // ---- the small-batch form: one WORKGROUP (four waves) per cell.  A cell on one wave is a chain of ~1500 dependent-ish instructions and LDS
@@ -290,10 +290,19 @@ __global__ __launch_bounds__(256) void k_fast_wide(const CellDesc* __restrict__ 
 void launchFast(hipStream_t st, const CellDesc* cells, int nCells, const LevelGeom* lv, int nlevels,
                 const uint8_t* pyr, int iniTh, int minTh, unsigned* candSeg, unsigned* cellCount, int maxRoiW, int maxRoiH,
                 int f0, int B, const BlurItem* blurItems, const unsigned short* blurLaneItem, int blurLanes, uint8_t* blur,
-                LeafTables lt, bool wide) {
+                LeafTables lt, bool wide, bool big) {
     const int fastChunks = (nCells + kFastWaves - 1) / kFastWaves;
     const dim3 block(256);
     BlurTail tail{blurItems, blurLaneItem, blurLanes, blur, fastChunks};
+    if (big) {      // frames beyond 4096 px: two-dword candidates (the host keeps the blur in a launch of its own and the leaf tables off for them)
+        typedef CandFmt<true>::T* BigSeg;
+        const dim3 grid = xcdGrid(fastChunks, B);
+        if (maxRoiW <= 45 && maxRoiH <= 45)
+            hipLaunchKernelGGL((k_fast<48, 45, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, (BigSeg)candSeg, cellCount, f0, B, tail, lt);
+        else
+            hipLaunchKernelGGL((k_fast<72, 69, false, true>), grid, block, 0, st, cells, nCells, lv, nlevels, pyr, iniTh, minTh, (BigSeg)candSeg, cellCount, f0, B, tail, lt);
+        return;
+    }
     // ROI of w pixels at any dword misalignment needs (3 + w + 3) / 4 dwords
     if (wide && maxRoiW <= 45 && maxRoiH <= 45) {      // few cells: a workgroup per cell
         if (blurItems)

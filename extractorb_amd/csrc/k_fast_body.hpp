@@ -170,10 +170,11 @@ struct FastLds {
 
 // One cell on one wave (the whole of k_fast's work).  smem / scoreS / codeL: the workgroup's
 // three LDS arrays (FastLds), chunk: the workgroup's group of four cells, f: the frame.  No workgroup barrier.
-template <int TS, int ROWS>
+// BIG: the candidates are written in the two-dword format of frames beyond 4096 px (orbx_device.hpp: CandFmt).
+template <int TS, int ROWS, bool BIG = false>
 __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int nCells, const LevelGeom* __restrict__ lv,
                                          const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                         unsigned* __restrict__ candSeg, unsigned* __restrict__ cellCount, LeafTables lt,
+                                         typename CandFmt<BIG>::T* __restrict__ candSeg, unsigned* __restrict__ cellCount, LeafTables lt,
                                          uint8_t* smem, uint8_t* scoreS, uint8_t (*codeL)[2][64], int chunk, int f) {
     constexpr int kTileBytes = TS * ROWS;             // pixel tile
     constexpr int kScoreBytes = TS * (ROWS - 3);      // score tile: (ch + 2) rows <= ROWS - 4, and one more zero row for the NMS lanes past the last item
@@ -366,7 +367,7 @@ __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int
     FAST_MID(2);
     if (total == 0) return;
     unsigned base = 0;
-    unsigned* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
+    typename CandFmt<BIG>::T* outPos = candSeg + g.candOff + (long long)f * g.candCap + c.segOff;
     const unsigned segCap = (unsigned)(((cw + 1) >> 1) * ((ch + 1) >> 1));
     const int th = useIni ? iniTh : minTh;
     // Small batches: the quad-tree's first sweep is done here, by 800 waves instead of one workgroup per level (k_octree_body.inc,
@@ -396,11 +397,11 @@ __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int
             const unsigned at = base + __popcll(m & ((1ull << lane) - 1));
             if (at < segCap) {
                 const unsigned kx = (unsigned)(c.shiftX + x + 3), ky = (unsigned)(c.shiftY + y + 3);
-                const unsigned w = kx | (ky << 12) | ((unsigned)(s - 1) << 24);   // response = S - 1
+                const typename CandFmt<BIG>::T w = CandFmt<BIG>::make(kx, ky, (unsigned)(s - 1));   // response = S - 1
                 outPos[at] = w;
                 if (leaf) {
                     const int xc = xcL[x], yc = ycL[y];
-                    const unsigned val = (w & 0xff000000u) | (0xffffffu - ((unsigned)c.segOff + at));
+                    const unsigned val = CandFmt<BIG>::respKey(w) | (0xffffffu - ((unsigned)c.segOff + at));
                     if (nLeafLocal) {
                         const int li = (yc - yc0) * nxl + (xc - xc0);
                         // (LDS by type: with the tables reached through the body's pointer arguments the compiler merged this pair with the

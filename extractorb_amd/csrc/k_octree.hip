@@ -57,6 +57,9 @@ __device__ unsigned long long g_octSpans[2 * 16];      // (start, end) of frame 
 #ifndef OCT_SHORT_PHASE2
 #define OCT_SHORT_PHASE2 (OCT_W <= 4)
 #endif
+// the candidate format of a build (orbx_device.hpp: CandFmt): one dword; the three ..b builds at the end read the two-dword format of frames beyond 4096 px
+#define OCT_FMT CandFmt<false>
+#define OCT_CAND CandFmt<false>::T
 #define OCT_W 8
 #define OCT_T 1024
 #define OCT_NAME(x) x##_1024
@@ -107,6 +110,31 @@ __device__ unsigned long long g_octSpans[2 * 16];      // (start, end) of frame 
 #undef OCT_NAME
 #undef OCT_GLOBAL
 #undef OCT_W
+// ---- frames beyond 4096 px (round 6): the same body over two-dword candidates, in the three 1024-thread forms such frames take (queued,
+//      resident, HBM node arena); the host keeps the leaf tables off for them ----
+#undef OCT_FMT
+#undef OCT_CAND
+#define OCT_FMT CandFmt<true>
+#define OCT_CAND CandFmt<true>::T
+#define OCT_W 8
+#define OCT_T 1024
+#define OCT_NAME(x) x##_1024b
+#include "k_octree_body.inc"
+#undef OCT_NAME
+#undef OCT_W
+#define OCT_W 4
+#define OCT_NAME(x) x##_1024rb
+#include "k_octree_body.inc"
+#undef OCT_NAME
+#define OCT_GLOBAL 1
+#define OCT_NAME(x) x##_1024gb
+#include "k_octree_body.inc"
+#undef OCT_T
+#undef OCT_NAME
+#undef OCT_GLOBAL
+#undef OCT_W
+#undef OCT_FMT
+#undef OCT_CAND
 
 #ifdef ORBX_OCT_STAMPS
 extern "C" int orbx_debug_oct_stamps(unsigned long long* out128) {
@@ -133,8 +161,20 @@ size_t octreeLdsBytes(int M, int P, int R, int XT) {
 void launchOctree(hipStream_t st, const LevelGeom* lv, int nlevels, const CellDesc* cells, int nCellsTotal,
                   const unsigned* candSeg, const unsigned* cellCount, int* cellOff, unsigned* candPos, unsigned* candCount,
                   unsigned short* nodeOf, uint2* sel, int selPerFrame, int* levelCount, int* levelLap, const int* lapArea,
-                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B, uint8_t* nodeArena, LeafTables lt) {
+                  int M, int P, int R, int XT, const int* threadsOfLevel, bool roomy, int f0, int B, uint8_t* nodeArena, LeafTables lt, bool big) {
     const size_t bytes = octreeLdsBytes(M, P, R, XT);
+    if (big) {      // two-dword candidates: one launch, 1024 threads per (frame, level)
+        typedef CandFmt<true>::T Big;
+        if (nodeArena)
+            hipLaunchKernelGGL(k_octree_1024gb, dim3(B, nlevels), dim3(1024), 0, st, lv, nlevels, cells, nCellsTotal, (const Big*)candSeg, cellCount,
+                               cellOff, (Big*)candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT, 0, f0,
+                               nodeArena, (unsigned long long)((bytes + 255) & ~(size_t)255), lt);
+        else
+            hipLaunchKernelGGL(roomy ? k_octree_1024rb : k_octree_1024b, dim3(B, nlevels), dim3(1024), bytes, st, lv, nlevels, cells, nCellsTotal,
+                               (const Big*)candSeg, cellCount, cellOff, (Big*)candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap,
+                               lapArea, M, P, R, XT, 0, f0, (uint8_t*)nullptr, 0ull, lt);
+        return;
+    }
     if (nodeArena) {      // node arrays in HBM: one launch, 1024 threads per (frame, level)
         hipLaunchKernelGGL(k_octree_1024g, dim3(B, nlevels), dim3(1024), 0, st, lv, nlevels, cells, nCellsTotal, candSeg, cellCount,
                            cellOff, candPos, candCount, nodeOf, sel, selPerFrame, levelCount, levelLap, lapArea, M, P, R, XT, 0, f0,

@@ -58,7 +58,7 @@ int installGeometry(orbx_handle* h, int rows, int cols) {
     if ((size_t)(last.pyrOff + last.pyrFrameBytes * h->maxB) > h->pyrBytes ||
         (size_t)(last.blurOff + last.blurFrameBytes * h->maxB) > h->blurBytes ||
         (size_t)(last.candOff + (long long)last.candCap * h->maxB) > h->candEntries ||
-        (size_t)g.selPerFrame * h->maxB > h->selEntries || g.cells.size() > h->cellCap || g.maxNodes > h->octM)
+        (size_t)g.selPerFrame * h->maxB > h->selEntries || g.cells.size() > h->cellCap || g.maxNodes > h->octM || (g.big && !h->maxGeom.big))
         return fail(h, ORBX_ERR_IMAGE_TOO_LARGE, "image geometry does not fit the arenas sized at orbx_create");
     // ---- pass 1 (host only): pack every table, note where it goes.  A table that does not fit returns before anything is uploaded. ----
     struct Upload { void* dst; size_t at, bytes; };
@@ -248,7 +248,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // the launch sequence of frames [f0, f0 + Bn) on stream st, in two parts: front = pyramid + blur (HBM / latency bound),
     // back = FAST (vector-issue bound) + quad-tree (barrier-latency bound) + description
     auto blurVariant = [&](int Bn) { return (long long)h->nBlurLanes[0] * Bn >= 64LL * 2 * 4 * h->numCUs ? 0 : 1; };   // two waves per SIMD of 32-row lanes
-    auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH); };
+    auto blurRidesWithFast = [&](int Bn) { return blurVariant(Bn) == 1 && !h->profiling && h->fuseSmall && fastCanCarryBlur(g.maxRoiW, g.maxRoiH) && !g.big; };
     // Patch blur (k_describe<PB>): no blurred levels at all - every keypoint's 37 x 37 patch is blurred out of its raw 43 x 43 tile.  It pays where
     // the keypoints' patches are not a much larger job than the whole pyramid (nfeatures x 43 x 37 pixels of horizontal pass against the pyramid's
     // pixels) and the blur would be a launch of its own (not the small-batch form that rides in the FAST launch) - k_describe is bound by its sparse
@@ -368,7 +368,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // small batches: k_fast's emit does the quad-tree's first sweep (leaf counters and best keys in L2); k_octree loads and clears them
     auto leafTables = [&](int f0, int Bn) {
         LeafTables lt{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-        if (h->leafFrames && f0 + Bn <= h->leafFrames)
+        if (h->leafFrames && f0 + Bn <= h->leafFrames && !g.big)
             lt = LeafTables{h->d_leafHist, h->d_leafBest, h->d_leafCode, h->d_leafCode + (size_t)g.nlevels * h->octXT, h->octR, h->octXT, g.nlevels, h->leafFrames};
         return lt;
     };
@@ -384,11 +384,11 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             pollute(st);
             if (lt.hist) h->leafDirty = true;
             if (h->testFailAfterFast && lt.hist) { injected = true; h->testFailAfterFast = false; }      // (test aid: a call that dies between k_fast and k_octree)
-            const bool wide = h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs);
+            const bool wide = !g.big && (h->fastWide > 0 || (h->fastWide < 0 && (long long)g.cells.size() * Bn <= 4LL * h->numCUs));
             h->lastKernel[S_FAST] = wide && g.maxRoiW <= 45 && g.maxRoiH <= 45 ? "k_fast_wide" : "k_fast";
             launchFast(st, h->d_cells, (int)g.cells.size(), h->d_lv, g.nlevels, h->d_pyr, h->iniTh, h->minTh, h->d_candSeg,
                        h->d_cellCount, g.maxRoiW, g.maxRoiH, f0, Bn, carry ? h->d_tiles + h->blurItemOff[1] : nullptr,
-                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt, wide);
+                       h->d_laneItem + h->blurLaneOff[1], h->nBlurLanes[1], h->d_blur, lt, wide, g.big);
         }
     };
     auto backTail = [&](hipStream_t st, int f0, int Bn) {
@@ -407,6 +407,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // one 1024-thread workgroup per CU (the 512-thread build is reached from here through `need` below, also one per CU), else three of 256
             int residentT = wgs <= h->numCUs ? 1024 : (wgs * 256 <= 768LL * h->numCUs ? 256 : 0);
             if (residentT < h->octThreads[0] || h->octThreadsForced) residentT = 0;   // never fewer threads than the image size asks for
+            if (g.big) residentT = wgs <= h->numCUs ? 1024 : 0;      // (frames beyond 4096 px: the 1024-thread builds are the ones that read two-dword candidates)
             // ... but with the first sweep done by k_fast (leaf tables) what is left of a level is a chain of barriers over a list of at most
             // quota + 3 nodes: when 256 threads still give every node of the list its own thread (the short pass forms) the small workgroup
             // has the cheapest barriers (one frame: 1024 threads 16.7 us, 256 threads 13.6)
@@ -422,17 +423,17 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
             // (128 x 1080p: 87 us with 1024 threads, 57 with 512, 50 with 256; 64 x 1080p: 49 / 34 / 28; 128 x 720p: 87 / 57 / 46) - the sizes by
             // image area were measured with the sweep inside the kernel, where a level-0 workgroup reads ~60 k candidates
             const int queuedT = lt.hist && !h->octThreadsForced ? 256 : 0;
-            for (int l = 0; l < g.nlevels; l++) octT[l] = residentT ? residentT : (queuedT ? queuedT : h->octThreads[l]);
+            for (int l = 0; l < g.nlevels; l++) octT[l] = g.big ? 1024 : (residentT ? residentT : (queuedT ? queuedT : h->octThreads[l]));
             // ... in its scratch-free build (three workgroups per CU instead of six) while the launch is at most four workgroups per CU: little queues
             // behind the first round, and no spilled register is touched.  Round 6, A/B in one call (k_octree_256 -> _256r, us per launch; step): 128 x
             // 1080p 51 -> 33 (2291-2294 -> 2271-2278), 64 x 1080p 28 -> 20, 128 x 720p 47 -> 32 (1167-1171 -> 1151-1157), 128 x 640x480 30 -> 28.5
             // (472-473 -> 468); 256 x 640x480 equal; 512 x 640x480 112 -> 118 (1663 -> 1699: the spilling build keeps its place there, six per CU)
             const bool roomy = residentT != 0 || h->octRoomyForced || (queuedT == 256 && wgs <= 4LL * h->numCUs);
             pollute(st);
-            h->lastKernel[S_OCTREE] = h->d_octArena ? "k_octree_1024g" : "k_octree_" + std::to_string(octT[0]) + (roomy ? "r" : "");
+            h->lastKernel[S_OCTREE] = (h->d_octArena ? "k_octree_1024g" : "k_octree_" + std::to_string(octT[0]) + (roomy ? "r" : "")) + (g.big ? "b" : "");
             launchOctree(st, h->d_lv, g.nlevels, h->d_cells, (int)g.cells.size(), h->d_candSeg, h->d_cellCount, h->d_cellOff,
                          h->d_candPos, h->d_candCount, h->d_nodeOf, h->d_sel, g.selPerFrame,
-                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, roomy, f0, Bn, h->d_octArena, lt);
+                         h->d_levelCount, h->d_levelLap, h->d_lap, h->octM, h->octP, h->octR, h->octXT, octT, roomy, f0, Bn, h->d_octArena, lt, g.big);
             h->leafDirty = false;
         }
         auto joinBlur = [&]() {
@@ -711,8 +712,9 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_ALLOC(h->d_input, (size_t)max_width * max_height * max_batch);
     CREATE_ALLOC(h->d_pyr, h->pyrBytes);
     CREATE_ALLOC(h->d_blur, h->blurBytes);
-    CREATE_ALLOC(h->d_candPos, h->candEntries * sizeof(unsigned));
-    CREATE_ALLOC(h->d_candSeg, h->candEntries * sizeof(unsigned));
+    const size_t candBytes = mg.big ? sizeof(CandFmt<true>::T) : sizeof(CandFmt<false>::T);      // (a handle for frames beyond 4096 px: two dwords per candidate)
+    CREATE_ALLOC(h->d_candPos, h->candEntries * candBytes);
+    CREATE_ALLOC(h->d_candSeg, h->candEntries * candBytes);
     CREATE_ALLOC(h->d_cellCount, sizeof(unsigned) * h->cellCap * max_batch);
     CREATE_ALLOC(h->d_cellOff, sizeof(int) * h->cellCap * max_batch);
     CREATE_ALLOC(h->d_nodeOf, h->candEntries * sizeof(unsigned short));

@@ -89,20 +89,27 @@ int orbx_debug_get_candidates(orbx_handle* h, int frame, int level, orbx_keypoin
     // k_fast wrote always hold them, in the reference's order (cell by cell, raster order inside a cell).
     const FrameGeom& g = h->geom;
     const int nCells = (int)g.cells.size();
-    std::vector<unsigned> counts(L.cellCount), seg(L.candCap);
+    const size_t eb = g.big ? sizeof(CandFmt<true>::T) : sizeof(CandFmt<false>::T);      // one dword per candidate, two for frames beyond 4096 px (orbx_device.hpp)
+    std::vector<unsigned> counts(L.cellCount);
+    std::vector<unsigned long long> seg(L.candCap);      // (room for either format)
     HIP_TRY(h, hipMemcpyAsync(counts.data(), h->d_cellCount + (long long)frame * nCells + L.cellFirst, sizeof(unsigned) * L.cellCount,
                               hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(seg.data(), h->d_candSeg + L.candOff + (long long)frame * L.candCap, sizeof(unsigned) * L.candCap,
+    HIP_TRY(h, hipMemcpyAsync(seg.data(), (const uint8_t*)h->d_candSeg + (size_t)(L.candOff + (long long)frame * L.candCap) * eb, eb * L.candCap,
                               hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     int at = 0;
     for (int c = 0; c < L.cellCount; c++) {
         const int so = g.cells[L.cellFirst + c].segOff;
         for (unsigned i = 0; i < counts[c] && at < n; i++) {
-            const unsigned w = seg[so + i];
             orbx_keypoint& k = out[at++];
-            k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff); k.size = 7.f; k.angle = -1.f;
-            k.response = (float)(w >> 24); k.octave = 0; k.class_id = -1;
+            if (g.big) {
+                const unsigned long long w = seg[so + i];
+                k.x = (float)((unsigned)w & 0xffffu); k.y = (float)((unsigned)w >> 16); k.response = (float)(unsigned)(w >> 32);
+            } else {
+                const unsigned w = ((const unsigned*)seg.data())[so + i];
+                k.x = (float)(w & 0xfff); k.y = (float)((w >> 12) & 0xfff); k.response = (float)(w >> 24);
+            }
+            k.size = 7.f; k.angle = -1.f; k.octave = 0; k.class_id = -1;
         }
     }
     if (at != n) return fail(h, ORBX_ERR_HIP, "candidate count and per-cell counts disagree (internal)");

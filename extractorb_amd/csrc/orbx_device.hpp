@@ -20,6 +20,36 @@ struct Keypoint {             // == orbx_keypoint == cv::KeyPoint (28 bytes)
 };
 static_assert(sizeof(Keypoint) == 28, "cv::KeyPoint layout");
 
+// ---- packed formats between the kernels ----
+// A FAST candidate (k_fast -> k_octree; rectangle coordinates, ORBextractor.cc:857-859) is packed two ways:
+//   narrow (default): one dword  x:12 | y:12 | response:8   - every level of the geometry at most 4096 + 2 x 16 px wide and high;
+//   big   (round 6):  two dwords [x:16 | y:16] [response]   - any larger frame (the reference has no size limit, :1171).
+// The selection entry (k_octree -> k_describe, level coordinates: + kMinBorder) has one format: .x = x:16 | y:16, .y = response:8 << 24 |
+// lapping flag << 23 | rank among the level's lapping keys (23 bits).
+template <bool BIG> struct CandFmt;
+template <> struct CandFmt<false> {
+    typedef unsigned T;
+#if defined(__HIPCC__) || defined(ORBX_OCT_EMU)
+    static __host__ __device__ inline T make(unsigned x, unsigned y, unsigned resp) { return x | (y << 12) | (resp << 24); }
+    static __host__ __device__ inline int x(T w) { return (int)(w & 0xfff); }
+    static __host__ __device__ inline int y(T w) { return (int)((w >> 12) & 0xfff); }
+    static __host__ __device__ inline unsigned xy32(T w) { return (w & 0xfff) | (((w >> 12) & 0xfff) << 16); }
+    static __host__ __device__ inline unsigned respKey(T w) { return w & 0xff000000u; }      // response << 24
+#endif
+};
+template <> struct CandFmt<true> {
+    typedef unsigned long long T;
+#if defined(__HIPCC__) || defined(ORBX_OCT_EMU)
+    static __host__ __device__ inline T make(unsigned x, unsigned y, unsigned resp) { return (T)(x | (y << 16)) | ((T)resp << 32); }
+    static __host__ __device__ inline int x(T w) { return (int)((unsigned)w & 0xffffu); }
+    static __host__ __device__ inline int y(T w) { return (int)((unsigned)w >> 16); }
+    static __host__ __device__ inline unsigned xy32(T w) { return (unsigned)w; }
+    static __host__ __device__ inline unsigned respKey(T w) { return (unsigned)(w >> 32) << 24; }
+#endif
+};
+constexpr int kNarrowMax = 4096;      // the narrow format's level size limit (rectangle coordinates < 4096)
+constexpr int kBigMax = 16384;        // the big format's: box coordinates are shorts, slots 24 bits (makeFrameGeom checks both)
+
 // One kBlurBlockRows-row block of one level for the blur kernel: lanes [firstLane, firstLane + ceil(w/4)) own its 4-column groups.
 // items[0].count holds the number of items.
 struct BlurItem { int firstLane; int count; short level; short y0; };

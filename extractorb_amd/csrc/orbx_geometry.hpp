@@ -129,6 +129,7 @@ struct FrameGeom {
     };
     std::vector<ColumnSet> colSets;          // finest first
     bool colsPacked = false;
+    bool big = false;                        // a level beyond 4096 px: candidates in the two-dword format (CandFmt<true>), 1024-thread quad-tree, no leaf tables
 };
 constexpr int kColPx[] = {40, 56, 80, 112};
 #ifndef ORBX_COL_EDGE_NUM
@@ -153,7 +154,10 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
         L.nCols = (int)(width / (float)kCellW);
         L.nRows = (int)(height / (float)kCellW);
         if (L.nCols < 1 || L.nRows < 1) return "image too small: a pyramid level is narrower than one 30-px FAST cell";
-        if (L.w + 2 * kEdge > 4096 + 2 * kEdge || L.h > 4096) return "image too large: packed coordinates hold 12 bits";
+        // (the reference has no size limit, ORBextractor.cc:1171; here: 16-bit node boxes and the two-dword candidate format up to 16384 px, one-dword
+        // candidates - x:12 | y:12 | response:8 - while every level stays within 4096 px: orbx_device.hpp, CandFmt)
+        if (L.w > kBigMax || L.h > kBigMax) return "image too large: a pyramid level beyond 16384 px";
+        if (L.w > kNarrowMax || L.h > kNarrowMax) g.big = true;
         L.wCell = (int)std::ceil(width / L.nCols);
         L.hCell = (int)std::ceil(height / L.nRows);
         if (L.wCell > 63 || L.hCell > 63) return "unsupported cell size (> 63 px)";
@@ -198,6 +202,7 @@ inline std::string makeFrameGeom(const ScaleTables& t, int rows, int cols, Frame
             }
         }
         L.cellCount = (int)g.cells.size() - L.cellFirst;
+        if (cap >= (1LL << 24)) return "image too large: a pyramid level with 2^24 or more candidate slots (the quad-tree's best keys hold 24-bit slots)";
         L.candCap = (int)cap;
         int nodes = L.quota + 3 > 4 * L.nIni ? L.quota + 3 : 4 * L.nIni;
         L.selCap = (nodes + 2) & ~1;   // even, so the two keypoints a wave of k_describe owns always share a level

@@ -39,9 +39,10 @@ def read_result(path, nlevels):
 
 
 def expected_level(oracle, level, lapping):
-    """(x | y << 12 | response << 24) per kept keypoint in the reference's list order, and the lapping flags (ORBextractor.cc:1143-1147)."""
+    """(x | y << 16, response) per kept keypoint in the reference's list order - the selection entry's .x and the top byte of its .y
+    (extractorb_amd/csrc/orbx_device.hpp) - and the lapping flags (ORBextractor.cc:1143-1147)."""
     k = oracle.level_keypoints(level)
-    w = k["x"].astype(np.uint32) | (k["y"].astype(np.uint32) << 12) | (k["response"].astype(np.uint32) << 24)
+    w = (k["x"].astype(np.uint32) | (k["y"].astype(np.uint32) << 16), k["response"].astype(np.uint32))
     xs = k["x"] if level == 0 else (k["x"] * oracle.scale_factors[level]).astype(np.float32)
     lap = (xs >= np.float32(lapping[0])) & (xs <= np.float32(lapping[1]))
     return w, lap
@@ -59,7 +60,7 @@ def check(oracle, nlevels, lapping, result):
     """Bit-for-bit comparison of the emulated kernel's selection with the oracle; returns a list of mismatch descriptions."""
     bad = []
     for l in range(nlevels):
-        want, lap = expected_level(oracle, l, lapping)
+        (want, want_resp), lap = expected_level(oracle, l, lapping)
         sel, nlap = result[l]
         if len(sel) != len(want):
             bad.append("level %d: %d kept, oracle %d" % (l, len(sel), len(want)))
@@ -67,9 +68,11 @@ def check(oracle, nlevels, lapping, result):
         if not np.array_equal(sel[:, 0], want):
             i = int(np.nonzero(sel[:, 0] != want)[0][0])
             bad.append("level %d: list position %d differs (0x%08x vs 0x%08x)" % (l, i, sel[i, 0], want[i]))
-        if not np.array_equal((sel[:, 1] >> 31).astype(bool), lap) or nlap != int(lap.sum()):
+        if not np.array_equal(sel[:, 1] >> 24, want_resp):
+            bad.append("level %d: responses differ" % l)
+        if not np.array_equal(((sel[:, 1] >> 23) & 1).astype(bool), lap) or nlap != int(lap.sum()):
             bad.append("level %d: lapping flags / count differ" % l)
         rank = np.cumsum(lap) - lap
-        if not np.array_equal(sel[:, 1] & 0x7fffffff, rank.astype(np.uint32)):
+        if not np.array_equal(sel[:, 1] & 0x7fffff, rank.astype(np.uint32)):
             bad.append("level %d: lapping ranks differ" % l)
     return bad

@@ -191,7 +191,7 @@ int main(int argc, char** argv) {
     Exact<uint8_t> arena(z.arena ? z.arenaSlice * (size_t)H.nlevels : 0);
     launchOctree(nullptr, lv.p, H.nlevels, cells.p, nCells, candSeg.p, cellCount.p, cellOff.p, candPos.p, candCount.p, nodeOf.p, sel.p,
                  g.selPerFrame, levelCount.p, levelLap.p, lapArea.p, z.M, z.P, z.R, z.XT, threadsOfLevel, H.roomy != 0, 0, 1,
-                 z.arena ? arena.p : nullptr, lt);
+                 z.arena ? arena.p : nullptr, lt, false);
     if (lt.hist)      // the kernel clears what it loads: the tables are zero again for the next call
         for (size_t i = 0; i < leafHist.n; i++)
             if (leafHist.p[i] != 0 || leafBest.p[i] != 0) { fprintf(stderr, "leaf table entry %zu not cleared\n", i); return 4; }
