@@ -817,9 +817,29 @@ def main():
                 h_end((i - 1) & 1)
             h_end((reps - 1) & 1)
             dt = time.perf_counter() - t1
-            extras["host_to_host_fps"] = round(Bh * reps / dt, 1)
+            in_process_fps = round(Bh * reps / dt, 1)
+            extras["host_to_host_fps"] = in_process_fps
+            extras["host_to_host_fps_in_this_process"] = in_process_fps
+            # This process has imported torch, so liborbx.so runs on the HIP runtime torch BUNDLES (ROCm 7.0 in this image), on which an input copy
+            # and another stream's kernels do not overlap; a C++ host links the system runtime (ROCm 7.2), where they do (round 6:
+            # profiles/r06_host_path.md).  The library's own figure therefore comes from a CHILD process without torch (tools/host_path_rate.py,
+            # the same two-handle loop through ctypes); the in-process one stays beside it.
+            try:
+                import subprocess
+                env_c = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+                env_c["HOST_RATE_BATCHES"] = str(Bh)
+                outc = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "host_path_rate.py"), "--json"], env=env_c, text=True, timeout=180,
+                                               stderr=subprocess.DEVNULL)
+                jc = json.loads(outc.strip().splitlines()[-1])
+                extras["host_to_host_fps"] = jc[str(Bh)]["pipelined_fps"]
+                extras["host_to_host_runtime"] = jc.get("hip_runtime")
+                extras["host_to_host_sync_call_fps"] = jc[str(Bh)]["sync_fps"]
+            except Exception as e_child:      # (the figure then is the in-process one, and says so)
+                extras["host_to_host_runtime"] = "child process failed (%r): in-process figure, torch's bundled HIP runtime" % (e_child,)
             extras["host_to_host_note"] = ("pinned host frames -> H2D -> whole path -> results in pinned host memory, %d frames per call, two handles alternating "
-                                           "(orbx_extract_batch_begin / _end_view through ctypes; PCIe-inclusive; not `value`)" % Bh)
+                                           "(orbx_extract_batch_begin / _end_view through ctypes; PCIe-inclusive; not `value`); measured in a child process on the system HIP runtime "
+                                           "(host_to_host_runtime) - host_to_host_fps_in_this_process is the same loop in this torch process, whose bundled runtime does "
+                                           "not overlap copies with kernels" % Bh)
             # ... and what the input copy alone can do on this box: the same 64-frame slab as a bare pinned hipMemcpyAsync, two streams alternating,
             # nothing else running.  host_to_host_fps x frame bytes against it says whether the host-fed rate is the link's or the pipeline's
             # 
