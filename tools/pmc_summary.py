@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Averages rocprofv3 --pmc counter values per kernel: pmc_summary.py <counter_collection.csv> [...] -> markdown table."""
-import collections, csv, sys
+import collections, csv, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_profile import short
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("orbx::", "").replace("void ", "").split("<")[0]
+        k = short(r["Kernel_Name"])
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in agg for c in agg[k]})

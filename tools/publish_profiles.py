@@ -33,8 +33,9 @@ for name in ("traffic.json", "valu.json"):
 v = {k: x for k, x in json.load(open(os.path.join(ROOT, "profiles", "valu.json")))[workload][batch].items() if not k.startswith("_")}
 stats = {}
 for r in csv.DictReader(open(stem + "_kernel_stats.csv")):
-    n = r["Name"].split("(")[0].replace("orbx::", "").replace("void ", "").split("<")[0]
-    stats[n] = float(r["AverageNs"]) / 1e6
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from summarize_profile import short
+    stats[short(r["Name"])] = float(r["AverageNs"]) / 1e6
 peak = 1024 * 2.4 / 4.0
 out = ["# SQ counters per launch - %s (%s, %s frames per launch); kernel sources %s\n\n" % (desc, workload, batch, src_hash),
        "Two `rocprofv3 --pmc` passes of `%s` (no trace options), averaged per kernel by `tools/pmc_summary.py`:\n" % cmd,
@@ -47,6 +48,8 @@ out = ["# SQ counters per launch - %s (%s, %s frames per launch); kernel sources
        "(peak %.0f G wave-instr/s = 1024 SIMDs x 2.4 GHz / 4); `lower` prices the kernel's full-rate share (static census of its ISA, `tools/valu_census.py`)\n"
        "at 2 cycles.  The true issue-slot occupancy lies between the two.  Duration = average of the same kernel in the kernel stats of this state.\n\n" % peak,
        "| kernel | SQ_INSTS_VALU per launch | per wave | avg duration ms | G wave-instr/s | full-rate share (static) | issue occupancy: lower - upper |\n|---|---|---|---|---|---|---|\n"]
+if "k_describe" in v and "k_describe" not in stats:      # (the sum row of a blur split by level: its duration is the sum of its two launches)
+    stats["k_describe"] = sum(t for k, t in stats.items() if k.startswith("k_describe<"))
 for k in sorted(v):
     if k in stats:
         g = v[k]["SQ_INSTS_VALU"] / (stats[k] * 1e-3) / 1e9

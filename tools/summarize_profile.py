@@ -9,8 +9,25 @@ import collections, csv, json, os, sys
 
 
 def short(name):
+    """kernel name without namespace and template arguments - except k_describe's: a blur split by level launches k_describe<true> (levels below
+    the split, blur per keypoint) AND k_describe<false> (the rest) once each per step; they are different kernels and stay two rows"""
     n = name.split("(")[0].replace("orbx::", "").replace("void ", "")
-    return n.split("<")[0]
+    base = n.split("<")[0]
+    if base == "k_describe" and "<" in n:
+        return "k_describe<%s>" % ("PB" if n.split("<")[1].split(">")[0].strip() in ("true", "1") else "plain")
+    return base
+
+
+def add_step_sums(per):
+    """'k_describe' = the sum of its two launches of a step (what bench.py's event profile, which brackets both, calls k_describe)"""
+    parts = [k for k in per if k.startswith("k_describe<")]
+    if len(parts) > 1:
+        if isinstance(per[parts[0]], dict):
+            per["k_describe"] = {c: sum(per[k].get(c, 0.0) for k in parts) for c in per[parts[0]]}
+        else:
+            per["k_describe"] = int(sum(per[k] for k in parts))
+    elif len(parts) == 1:
+        per["k_describe"] = per[parts[0]]
 
 
 def stats(src, out, title, cmd):
@@ -35,7 +52,8 @@ def traffic(fetch_csv, write_csv, workload, batch, out_json, out_md):
     # coalesced reads, so the read side is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
     fe, wr = collect(fetch_csv, "FETCH_SIZE"), collect(write_csv, "WRITE_SIZE")
     data = json.load(open(out_json)) if os.path.exists(out_json) else {}
-    per = data.setdefault(workload, {}).setdefault(str(batch), {})
+    data.setdefault(workload, {})[str(batch)] = {}      # (a fresh entry: kernels of an earlier round's path do not linger)
+    per = data[workload][str(batch)]
     with open(out_md, "w") as f:
         f.write("# HBM traffic per launch from rocprofv3 --pmc (workload %s, %s frames per launch)\n\n" % (workload, batch))
         f.write("Separate passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass). bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024;\n"
@@ -47,6 +65,9 @@ def traffic(fetch_csv, write_csv, workload, batch, out_json, out_md):
             b = (2 * fe.get(k, 0) + wr.get(k, 0)) * 1024
             per[k] = int(b)
             f.write("| %s | %.0f | %.0f | %d | %d |\n" % (k, fe.get(k, 0), wr.get(k, 0), b, b / int(batch)))
+        add_step_sums(per)
+        tot = sum(v for k, v in per.items() if k.startswith("k_") and not k.startswith("k_describe<") and k != "k_packedSelfTest")
+        f.write("\nSum over the kernels of a step: %d bytes = %.2f MB per frame.\n" % (tot, tot / int(batch) / 1e6))
     json.dump(data, open(out_json, "w"), indent=1, sort_keys=True)
 
 
@@ -54,11 +75,13 @@ def valu(sq_md, workload, batch, out_json):
     lines = [l for l in open(sq_md) if l.startswith("|")]
     names = [c.strip() for c in lines[0].strip().strip("|").split("|")]
     data = json.load(open(out_json)) if os.path.exists(out_json) else {}
-    per = data.setdefault(workload, {}).setdefault(str(batch), {})
+    data.setdefault(workload, {})[str(batch)] = {}
+    per = data[workload][str(batch)]
     for l in lines[2:]:
         cells = [c.strip() for c in l.strip().strip("|").split("|")]
         row = dict(zip(names, cells))
         per[row["kernel"]] = {k: float(row[k]) for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU") if k in row and row[k] != "-"}
+    add_step_sums(per)
     json.dump(data, open(out_json, "w"), indent=1, sort_keys=True)
 
 

@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "extractorb_amd", "csrc")
 FULL = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32"}      # (v_xor_b32: profiles/r04_valu_issue_rate_additions.md)
 # kernel (as bench.py / rocprof name it) -> (source file, mangled-name fragment of the variant the default workload runs)
-KERNELS = {"k_fast": ("k_fast.hip", "k_fastILi48ELi45ELb0E"), "k_blur": ("k_blur.hip", "k_blur"), "k_describe": ("k_describe.hip", "k_describeILb0E"),
+KERNELS = {"k_fast": ("k_fast.hip", "k_fastILi48ELi45ELb0ELb0E"), "k_blur": ("k_blur.hip", "k_blur"), "k_describe<plain>": ("k_describe.hip", "k_describeILb0E"),
+           "k_describe<PB>": ("k_describe.hip", "k_describeILb1E"), "k_octree_256r": ("k_octree.hip", "k_octree_256rE"),
            "k_pyr_first": ("k_pyramid.hip", "k_pyr_firstILb1E"), "k_resize": ("k_pyramid.hip", "k_resizeILb1E"),
-           "k_pyr_cols": ("k_pyramid.hip", "k_pyr_colsILb1ELi512ELi256ELb0E"),
+           "k_pyr_cols": ("k_pyramid.hip", "k_pyr_colsILb1ELi512ELi256E"),
            "k_octree_256": ("k_octree.hip", "k_octree_256E")}
 
 
