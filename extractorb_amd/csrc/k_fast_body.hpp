@@ -405,7 +405,7 @@ __device__ __forceinline__ void fastCell(const CellDesc* __restrict__ cells, int
                     if (nLeafLocal) {
                         const int li = (yc - yc0) * nxl + (xc - xc0);
                         // (LDS by type: with the tables reached through the body's pointer arguments the compiler merged this pair with the
-                        // global pair of the other branch into ONE atomic on a generic pointer - a flat_atomic, DESIGN.md 4i's construct)
+                        // global pair of the other branch into ONE atomic on a generic pointer - a flat_atomic, docs/history/DESIGN_rounds_1-5.md §4i's construct)
                         ldsAtomicAdd(&tHist[li], 1u);
                         ldsAtomicMax(&tBest[li], val);
                     } else {

@@ -20,8 +20,8 @@
 //     reference's running minimum is "smallest (distance, slot)" and a window is one slot range per cell column;
 //   * a request keeps its two smallest keys (distance << 16 | slot); the reference's (bestDist, bestLevel, bestDist2, bestLevel2)
 //     after its sequential scan are the smallest and the second smallest key of the window (the element that ends up providing
-//     bestDist2 is the first in traversal order among those with the second smallest distance — see DESIGN.md §4f).
-// One frame pair: 868 us as a walk (one barrier per request) -> see DESIGN.md §4f for the fixed point's figure.
+//     bestDist2 is the first in traversal order among those with the second smallest distance — see docs/history/DESIGN_rounds_1-5.md §4f).
+// One frame pair: 868 us as a walk (one barrier per request) -> see docs/history/DESIGN_rounds_1-5.md §4f for the fixed point's figure.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

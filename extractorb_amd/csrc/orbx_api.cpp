@@ -44,7 +44,7 @@ void freeAll(orbx_handle* h) {
 
 // Installs the geometry of a rows x cols image: builds its tables, checks that they fit the arenas, and uploads them.
 //
-// Ordering: every table is packed into ONE pinned staging block and copied to its device arena with hipMemcpyAsync ON THE
+// Ordering (docs/history/DESIGN_rounds_1-5.md §4j): every table is packed into ONE pinned staging block and copied to its device arena with hipMemcpyAsync ON THE
 // HANDLE'S STREAM, the stream every kernel of the handle is launched on (the internal side streams only ever start behind an event recorded on
 // it).  So "the tables have landed before the first kernel reads them" is stream order - stated, not assumed - and no call in this path waits
 // for the device as a whole: another handle's work on the same device is not stalled by this handle meeting a new image size.  The staging
@@ -698,7 +698,7 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
 
 // device allocation of orbx_create; the test aid "poison" fills it (tests run with it: no kernel may depend on what hipMalloc returns,
 // which is zeroed pages in a fresh process and another test's leftovers later).  Every fill of this function is enqueued on the handle's OWN
-// stream - the stream the kernels run on - so "filled before first use" is stream order, not an assumption about the null stream.
+// stream - the stream the kernels run on - so "filled before first use" is stream order (docs/history/DESIGN_rounds_1-5.md §4j), not an assumption about the null stream.
 #define CREATE_ALLOC(ptr, bytes)                                                         \
     do {                                                                                 \
         const size_t n_ = (size_t)(bytes);                                               \

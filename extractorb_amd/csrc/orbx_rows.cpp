@@ -344,7 +344,7 @@ int orbx_vocabulary_create(orbx_vocabulary** out, int k, int L, int scoring, int
     orbx_vocabulary* v = new orbx_vocabulary();
     v->device = device; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->nNodes = n_nodes; v->nWords = words;
     // the uploads go through a stream of their own and the function returns when THAT stream has drained: the tables have landed before any
-    // handle's stream can be given the vocabulary, and no other work on the device is waited for
+    // handle's stream can be given the vocabulary, and no other work on the device is waited for (docs/history/DESIGN_rounds_1-5.md §4j)
     hipStream_t us = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) {
         g_createError = "orbx_vocabulary_create: cannot create the upload stream";

@@ -8,7 +8,7 @@
 //  4. the WRITING role's thread dealing as the kernel computes it (k_pyramid.hip: doLevel) - the interior dword columns dealt dword by dword
 //     or walked column-wise in three runs (top mirror, interior, bottom mirror), the frame's columns byte by byte, all through float
 //     reciprocals - replayed for every writer count the launch shapes use (256 / 512 / 768 / 1024 threads): every owned (row, dword) is
-//     written by exactly one thread, from the source row copyMakeBorder's REFLECT_101 names (round 5; DESIGN.md 4j: the one miscompare of
+//     written by exactly one thread, from the source row copyMakeBorder's REFLECT_101 names (round 5; docs/history/DESIGN_rounds_1-5.md §4j: the one miscompare of
 //     a soak was a bordered level 0 of 1014 x 432, w % 4 == 2, whose cause was never found - this closes the host-side candidates);
 //  5. a hash of every table the kernel reads (printed; tests/test_pyramid_columns.py runs the checker under two MALLOC_PERTURB_ values and
 //     a dirtied heap and expects the same hash: no uninitialised byte reaches the tables).

@@ -57,7 +57,7 @@ def test_no_test_hook_is_reachable_from_the_environment():
 
 
 def test_handle_owned_memory_is_only_touched_in_stream_order():
-    """VERDICT round 4, item 4 / DESIGN.md 4j: every fill and copy of the host file names a stream (hipMemsetAsync / hipMemcpyAsync /
+    """VERDICT round 4, item 4 / docs/history/DESIGN_rounds_1-5.md §4j: every fill and copy of the host file names a stream (hipMemsetAsync / hipMemcpyAsync /
     hipMemcpy2DAsync on the handle's stream, or the vocabulary's own upload stream) - no null-stream hipMemcpy / hipMemset whose order against
     the handle's non-blocking stream would be an assumption, and no device-wide barrier that stalls other handles."""
     import re

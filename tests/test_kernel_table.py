@@ -1,4 +1,4 @@
-"""A guard instead of a memory for DESIGN.md §4i's quad-tree anomaly: the register / scratch / memory-
+"""A guard instead of a memory for docs/history/DESIGN_rounds_1-5.md §4i's quad-tree anomaly: the register / scratch / memory-
 instruction table of every kernel in the SHIPPED liborbx.so — read out of the code objects embedded in the library itself — against
 extractorb_amd/csrc/kernel_table.json, which is checked in next to the kernels.  CPU only (llvm-readelf / llvm-objdump from the ROCm image)."""
 import json

@@ -29,7 +29,7 @@ def run(exe, cols, rows, nlevels, sf, env=None):
 
 @pytest.mark.parametrize("cols,rows,nlevels,sf", [(640, 480, 8, 1.2), (752, 480, 8, 1.2), (517, 333, 8, 1.2), (1241, 376, 8, 1.2), (1920, 1080, 8, 1.2),
                                                   (752, 480, 12, 1.1), (800, 600, 3, 2.0), (322, 241, 2, 1.2), (512, 512, 4, 1.5), (1280, 720, 8, 1.2),
-                                                  (1014, 432, 2, 1.5), (1014, 432, 2, 1.2), (1018, 433, 3, 1.3)])      # (w % 4 == 2: DESIGN.md 4j)
+                                                  (1014, 432, 2, 1.5), (1014, 432, 2, 1.2), (1018, 433, 3, 1.3)])      # (w % 4 == 2: docs/history/DESIGN_rounds_1-5.md §4j)
 def test_the_cuts_rebuild_the_level_by_level_pyramid(checker, cols, rows, nlevels, sf):
     out = run(checker, cols, rows, nlevels, sf)
     assert out.startswith("ok") and not out.endswith(": 0 cuts"), out
@@ -49,7 +49,7 @@ def test_random_geometries(checker):
 
 @pytest.mark.parametrize("cols,rows,nlevels,sf", [(1014, 432, 2, 1.5), (640, 480, 8, 1.2), (517, 333, 4, 1.3), (1920, 1080, 8, 1.2)])
 def test_no_uninitialised_byte_reaches_the_tables(checker, cols, rows, nlevels, sf):
-    """the geometry of the one unexplained border miscompare (1014 x 432, two levels) and the benchmark's, built under two
+    """docs/history/DESIGN_rounds_1-5.md §4j: the geometry of the one unexplained border miscompare (1014 x 432, two levels) and the benchmark's, built under two
     MALLOC_PERTURB_ fills (glibc writes the complement of the byte into every malloc'ed block and the byte into every freed one): the hash
     over every table the kernels read - level records, cells, resize coefficients, column records, every region's rectangles / owned
     rectangles / dealing / coefficient lists of every cut - must not move."""

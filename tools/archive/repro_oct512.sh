@@ -1,5 +1,5 @@
 #!/bin/bash
-# Rebuilds the one revision in which a quad-tree variant returned wrong lists and runs the two failing fuzz cases.
+# Rebuilds the one revision in which a quad-tree variant returned wrong lists (docs/history/DESIGN_rounds_1-5.md §4i (a)) and runs the two failing fuzz cases.
 # Part 1 (build container): tools/repro_oct512.sh build        -> build/repro/{tree, lib_fail.so, lib_*.so}
 # Part 2 (GPU box, one gpurun call): tools/repro_oct512.sh run -> per library: the levels that differ from the oracle, three runs each
 # What it showed in round 3: lib_fail fails cases 1 and 4 of fuzz seed 103 with ORBX_OCT_THREADS=512 (64 VGPRs), differently from run to run;

@@ -2,7 +2,7 @@
 """Register / scratch / memory-instruction table of every kernel in the SHIPPED extractorb_amd/liborbx.so, read from the code objects embedded in
 the library itself (clang offload bundles in .hip_fatbin; llvm-readelf --notes for the metadata, llvm-objdump -d for the instructions).
 
-Why: the one wrong-result fault this project has seen lived in a 64-VGPR quad-tree variant whose node arrays
+Why (docs/history/DESIGN_rounds_1-5.md §4i): the one wrong-result fault this project has seen lived in a 64-VGPR quad-tree variant whose node arrays
 were reached with FLAT instructions through generic pointers reloaded from scratch, beside 147 SGPR spills; the source no longer contains that
 construct, and this table is what stops it coming back unnoticed: tests/test_kernel_table.py rebuilds it from the library under test and fails if
   * a kernel whose arrays are LDS or global by construction contains a flat_load / flat_store / flat_atomic,
@@ -107,7 +107,7 @@ def check(current, allowed):
     bad = []
     for k, v in current.items():
         if v.get("flat", 0) and (k not in FLAT_ALLOWED or v["scratch_bytes"]):
-            bad.append("%s: %d FLAT memory instructions (generic pointers: the construct behind DESIGN.md §4i's fault)" % (k, v["flat"]))
+            bad.append("%s: %d FLAT memory instructions (generic pointers: the construct behind docs/history/DESIGN_rounds_1-5.md §4i's fault)" % (k, v["flat"]))
         a = allowed.get(k)
         if a is None:
             bad.append("%s: kernel not in kernel_table.json (regenerate it: python tools/isa/kernel_table.py --write, and look at the diff)" % k)
