@@ -52,10 +52,10 @@ def apply_switches(switches, monkeypatch):
 
 
 def reset_aids():
+    """after every test (conftest.py): also the aids a test set through X.debug_set_option directly"""
     import extractorb_amd as X
-    if ACTIVE_AIDS:
-        X.debug_reset_options()
-        ACTIVE_AIDS.clear()
+    X.debug_reset_options()
+    ACTIVE_AIDS.clear()
 
 
 def record_inputs():

@@ -39,7 +39,9 @@ CONFIGS = [({}, 14, 101), ({"ORBX_OCT_THREADS": "256"}, 8, 102), ({"ORBX_OCT_THR
            ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "3", "aid:pyr_cols_shape": "4"}, 8, 124),
            ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "1", "ORBX_PYR_COL_PX": "80", "aid:pyr_cols_shape": "6", "aid:lds_pollute": "99"}, 8, 125),
            ({"ORBX_PATCH_BLUR": "1", "ORBX_BLUR_SPLIT": "5", "aid:pyr_cols_shape": "1", "aid:poison": "119"}, 8, 127),
-           ({"ORBX_ZERO_COPY": "0", "aid:poison": "33"}, 8, 126)]
+           ({"ORBX_ZERO_COPY": "0", "aid:poison": "33"}, 8, 126),
+           # round 6: frames beyond 4096 px (FUZZ_BIG: the generator draws 4100-7000-px strips and 4100-5200-px-high frames), plain and with polluted LDS
+           ({"FUZZ_BIG": "1"}, 4, 131), ({"FUZZ_BIG": "1", "aid:lds_pollute": "201", "aid:poison": "77"}, 3, 132)]
 _totals = []
 
 

@@ -16,6 +16,13 @@ def draw_case(rng, t):
     rows, cols = int(rng.integers(200, 900)), int(rng.integers(200, 1400))
     nf = int(rng.integers(30, 4000))
     nlevels = int(rng.integers(1, 10))
+    if os.environ.get("FUZZ_BIG"):      # frames beyond 4096 px (two-dword candidates, the ..b quad-tree builds): a wide strip or a tall frame (height <= 2 x width)
+        if rng.random() < 0.6:
+            rows, cols = int(rng.integers(150, 1300)), int(rng.integers(4100, 7000))
+        else:
+            rows, cols = int(rng.integers(4100, 5200)), int(rng.integers(2100, 3000))
+        nf = int(rng.integers(200, 6000))
+        nlevels = int(rng.integers(1, 9))
     sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0]))
     ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1))
     variant = ["noise", "textured", "sparse", "natural"][int(rng.integers(0, 4))]
