@@ -35,8 +35,7 @@ void freeAll(orbx_handle* h) {
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->aux2) (void)hipStreamDestroy(h->aux2);
     if (h->probeStream) { (void)hipStreamSynchronize(h->probeStream); (void)hipStreamDestroy(h->probeStream); }
-    for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); if (h->evUp[i]) (void)hipEventDestroy(h->evUp[i]);
-                                  if (h->evOct[i]) (void)hipEventDestroy(h->evOct[i]); if (h->evDesc[i]) (void)hipEventDestroy(h->evDesc[i]); }
+    for (int i = 0; i < 2; i++) { if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]); if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]); if (h->evUp[i]) (void)hipEventDestroy(h->evUp[i]); }
     void* host[] = {h->h_lap, h->h_out, h->h_in, h->h_pyr, h->h_tab};
     for (void* p : host) if (p) (void)hipHostFree(p);
     for (auto& ev : h->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -284,7 +283,7 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // the blur when everything else is done (2022-2030).  ORBX_SPLIT=0: no overlap of any kind (profiling runs: one kernel at a time).  (Round 2's two
     // half-batches side by side - removed in round 4 - are the "halves" figures above; profiles/r02_split_sweep.md.)
     const bool blurSide = h->splitMode != 0 && bigBatch && !h->profiling && (stages & kStageFront) && (stages & kStageBack);
-    bool blurJoin[2] = {false, false}, descJoin[2] = {false, false};
+    bool blurJoin[2] = {false, false};
     int blurF0[2] = {0, 0}, blurBn[2] = {0, 0};
     auto front = [&](hipStream_t st, int f0, int Bn) {
         // The pyramid region by region: one workgroup takes a region of the image through every level (k_pyr_cols; the coarsest cut that still
@@ -449,21 +448,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
                                h->d_levelLap, d_kps, d_desc, capacity, d_nOut, d_monoOut, d_levelK, d_levelCounts, pb, l0, l1,
                                g.lv[l0].selOff, l1 < g.nlevels ? g.lv[l1].selOff : g.selPerFrame, f0, Bn);
             };
-            if (splitL && blurSide && h->descSide) {
-                // the two description launches side by side (round 6): the plain one - bound by its patch gathers' L1 look-ups, 0.5-0.65 of the issue
-                // rate - goes to the blur's side stream, BEHIND the blur in stream order, and starts together with the issue-bound per-keypoint one
-                const int half = f0 ? 1 : 0;
-                (void)hipEventRecord(h->evOct[half], st);                      // this part's quad-tree
-                (void)hipStreamWaitEvent(h->aux2, h->evOct[half], 0);
-                pollute(h->aux2);
-                launchDescribe(h->aux2, h->d_lv, g.nlevels, h->d_pyr, h->d_blur, h->d_sel, g.selPerFrame, h->d_levelCount, h->d_levelLap, d_kps, d_desc, capacity,
-                               d_nOut, d_monoOut, d_levelK, d_levelCounts, false, splitL, g.nlevels, g.lv[splitL].selOff, g.selPerFrame, f0, Bn);
-                (void)hipEventRecord(h->evDesc[half], h->aux2);
-                descJoin[half] = true;
-                describe(true, 0, splitL);
-                (void)hipStreamWaitEvent(st, h->evDesc[half], 0);
-                if (st == h->stream) descJoin[half] = false;      // (joined into the caller's stream; a part on the internal stream is joined through evJoin - and once more by the guard)
-            } else if (splitL) {
+            if (splitL) {
+                // (side by side on two streams - the plain launch behind the blur on ITS stream, starting together with the per-keypoint one - measured
+                // slower: 1673-1677 vs 1656-1659 us per 512 frames, the stereo stream 1740 vs 1721; docs/history/r06.md)
                 describe(true, 0, splitL);      // (needs no blurred level: in front of the join)
                 joinBlur();
                 describe(false, splitL, g.nlevels);
@@ -474,13 +461,10 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
         }
     };
     auto back = [&](hipStream_t st, int f0, int Bn) { backFast(st, f0, Bn); backTail(st, f0, Bn); };
-    struct BlurJoin {      // a blur (or a description) left on the side stream by an early return is still joined into the caller's stream
-        orbx_handle* h; hipStream_t st; bool* pending; bool* pendingDesc;
-        ~BlurJoin() {
-            for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0);
-            for (int i = 0; i < 2; i++) if (pendingDesc[i]) (void)hipStreamWaitEvent(st, h->evDesc[i], 0);
-        }
-    } blurGuard{h, st, blurJoin, descJoin};
+    struct BlurJoin {      // a blur left on the side stream by an early return is still joined into the caller's stream
+        orbx_handle* h; hipStream_t st; bool* pending;
+        ~BlurJoin() { for (int i = 0; i < 2; i++) if (pending[i]) (void)hipStreamWaitEvent(st, h->evBlur[i], 0); }
+    } blurGuard{h, st, blurJoin};
     const bool doFront = (stages & kStageFront) != 0, doBack = (stages & kStageBack) != 0;
     // Staggered tails (the largest batches: 1.5 x the pixels of `bigBatch` - round 5: 384 x 640x480 1315-1324 -> 1301-1308 us, 256 frames no difference;
     // rounds 3-4: twice; ORBX_SPLIT=3: every big batch): FAST in two halves back to back on the
@@ -792,8 +776,6 @@ int orbx_create(orbx_handle** out, int nfeatures, float scale_factor, int nlevel
     CREATE_TRY(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));      // (default priority: a low-priority blur only starts when everything else is done - 1928 -> 2022 us; high = default)
     for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) CREATE_TRY(hipEventCreateWithFlags(&h->evUp[i], hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) { CREATE_TRY(hipEventCreateWithFlags(&h->evOct[i], hipEventDisableTiming)); CREATE_TRY(hipEventCreateWithFlags(&h->evDesc[i], hipEventDisableTiming)); }
-    h->descSide = envInt("ORBX_DESC_SIDE", 0) != 0;
     CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
     h->splitMode = envInt("ORBX_SPLIT", 1);

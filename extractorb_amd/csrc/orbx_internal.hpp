@@ -211,8 +211,6 @@ struct orbx_handle {
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     long long sharedUploadBytes = -1;      // test aid "shared_upload_bytes" as orbx_create read it (-1: the default limit, uploadFrames)
-    hipEvent_t evOct[2] = {nullptr, nullptr}, evDesc[2] = {nullptr, nullptr};      // the plain description beside the per-keypoint one (enqueueBatch)
-    bool descSide = false;
     hipEvent_t evUp[2] = {nullptr, nullptr};      // uploadFrames: the handle's stream -> the device's shared input-copy queue -> back
     hipStream_t aux2 = nullptr;        // the blur's side stream (pyramid -> {blur, FAST -> quad-tree} -> description), events per half-batch
     hipEvent_t evPyr[2] = {nullptr, nullptr}, evBlur[2] = {nullptr, nullptr};
