@@ -699,12 +699,13 @@ def test_the_default_leaf_table_limit(B):
         assert_same_result(a[f][:3], want, "B=%d frame %d" % (B, f))
 
 
-@pytest.mark.parametrize("shape,nf", [((1944, 2592), 3000), ((3000, 4000), 5000), ((480, 4000), 1500), ((4000, 6000), 5000), ((300, 9000), 2500), ((4200, 2200), 3000)])
+@pytest.mark.parametrize("shape,nf", [((1944, 2592), 3000), ((3000, 4000), 5000), ((480, 4000), 1500), ((4000, 6000), 5000), ((300, 9000), 2500), ((4200, 2200), 3000), ((600, 4500), 30000)])
 def test_large_and_very_wide_images(shape, nf):
     """5- and 12-megapixel frames and a 4000-px-wide strip (several quad-tree roots, hundreds of pyramid regions, thousands of FAST cells), and -
     round 6 - frames BEYOND 4096 px (the reference has no size limit, ORBextractor.cc:1171): a 24-megapixel 6000 x 4000 frame, a 9000-px strip
     with 33 quad-tree roots, a 4200-px-high frame; their candidates travel in the two-dword format, the quad-tree runs in its ...b builds
-    (orbx_device.hpp: CandFmt).  Every stage and the final arrays of one frame against the oracle."""
+    (orbx_device.hpp: CandFmt); 4500 x 600 with 30 000 features takes the build whose node arrays live in an HBM arena (`k_octree_1024gb`).  Every
+    stage and the final arrays of one frame against the oracle."""
     img = synth.frames("natural", 77, 1, *shape)[0]
     o, want = oracle_run(img, nf)
     ex = X.ORBextractor(nf, max_width=shape[1], max_height=shape[0])
