@@ -25,6 +25,7 @@ run --steps 200 --batch 2 --workload mono640_refkf
 run --steps 200 --batch 2 --workload mono640_init
 run --steps 200 --batch 8
 run --steps 100 --batch 64
+run --steps 60 --batch 128
 run --steps 50 --batch 256
 run --steps 15 --batch 1024
 run --steps 10 --batch 2048
@@ -34,7 +35,8 @@ echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd1080" >> gpurun_out/matrix.jso
 echo "# ORBX_PATCH_BLUR=0 --steps 30 --workload hd720" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --workload hd720 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_SPLIT=3 --steps 30 --batch 256" >> gpurun_out/matrix.jsonl; ORBX_SPLIT=3 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 --batch 256 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 echo "# ORBX_PATCH_BLUR=0 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_PATCH_BLUR=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
-echo "# ORBX_PIPE=1 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_PIPE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_BLUR_SPLIT=0 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_BLUR_SPLIT=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
+echo "# ORBX_BLUR_SPLIT=4 --steps 30" >> gpurun_out/matrix.jsonl; ORBX_BLUR_SPLIT=4 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 >> gpurun_out/matrix.jsonl
 run --steps 30 --handles 2
-timeout -k 10 300 python tools/host_path_rate.py > gpurun_out/host_path.txt 2>&1
+HOST_RATE_BATCHES=1,8,64,256,512 timeout -k 10 300 python tools/host_path_rate.py > gpurun_out/host_path.txt 2>&1
 echo done

@@ -3,9 +3,9 @@
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lines = open(os.path.join(ROOT, "gpurun_out", "matrix.jsonl")).read().splitlines()
-print("# bench.py matrix - %s, 1x MI355X, device-resident inputs and outputs\n" % (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].endswith(".jsonl") else "round-4 final"))
+print("# bench.py matrix - %s, 1x MI355X, device-resident inputs and outputs\n" % (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].endswith(".jsonl") else "round-6 final"))
 print("Collected by `tools/bench_matrix.sh` in one gpurun call (`--no-cpu-baseline --no-extras` on every row).  Default frames per call: 512 (640x480 workloads),\n"
-      "128 (hd720, hd1080).  Timed steps run the default overlap where it applies (the blur on its side stream, staggered tails at 512 x 640x480; section 1 of DESIGN.md); the per-kernel figures are bench.py's event-profiled, serial pass.\n")
+      "128 (hd720, hd1080).  Timed steps run the default overlap where it applies (the blur of the coarse levels on its side stream, staggered tails at 512 x 640x480; section 4 of DESIGN.md); the per-kernel figures are bench.py's event-profiled, serial pass.\n")
 print("| bench.py arguments | frames/call | frames/s | ms/step | keypoints/frame | extra | path_frac (HBM) | kernel us per step |\n|---|---|---|---|---|---|---|---|")
 args = None
 for l in lines:
