@@ -263,7 +263,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // A back-only pass (orbx_compute_keypoints_octree) describes from what the front part of the EARLIER call left: if that call blurred per
     // keypoint (form 3) no blurred level exists and this pass must do the same, whatever its own frame count would choose; otherwise the blurred
     // levels exist (or are owed to the FAST launch: blurOwed) and are used.
-    const bool bigBatch = (long long)g.sumPixels * B >= 2 * h->splitMinPixels;
+    // (round 6: "big" from ORBX_SPLIT_MIN_MPX = 120 Mpx of pyramid per call, the same threshold as the per-keypoint blur below - rounds 4-5: twice
+    // that -: 128 x 640x480 with the coarse levels' blur aside and staggered tails 457 -> 450 us)
+    const bool bigBatch = (long long)g.sumPixels * B >= h->splitMinPixels;
     const long long patchPx4 = (long long)h->nfeatures * 43 * 37 * 4;      // 4 x the patches' pixels of horizontal pass
     // Round 6: with the coarse levels split off to k_blur (installGeometry: splitLevel) the per-keypoint form also wins earlier and further - from
     // 120 Mpx of pyramid per call (128 x 640x480: 468 -> 459 us; 64 frames: 232 -> 248, not taken) and up to a ratio of 2.25 (512 x 640x480 x 1200
@@ -473,7 +475,9 @@ int enqueueBatch(orbx_handle* h, int B, const uint8_t* d_imgs, int rows, int col
     // what runs beside it mostly adds its own issue time)
     // (never with the blur riding in the FAST launch, the form of SMALL batches, which an ORBX_SPLIT_MIN_MPX=0 test run also counts as big: the
     // whole-batch pyramid would leave the blur to the FIRST half's FAST launch only — found by the batch-shape fuzz)
-    const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && (long long)g.sumPixels * B >= 3 * h->splitMinPixels && (long long)g.rows * g.cols <= 512 * 1024)) &&
+    // (round 6, with the blur split by level: every big batch of small frames - 256 x 640x480 880 -> 870 us, 320 frames 1085 -> 1063-1069; the stereo
+    // stream at 256 frames equal; rounds 3-5 started at 1.5-2 x the pixels of `bigBatch`)
+    const bool stagger = (h->splitMode == 3 || (h->splitMode == 1 && bigBatch && (long long)g.rows * g.cols <= 512 * 1024)) &&
                          !h->profiling && B >= 2 && bigBatch && doFront && doBack && !blurRidesWithFast(B);
     if (stagger) {
         struct Join {
